@@ -1,0 +1,84 @@
+/*
+ * polardepth.h -- C ABI of libpolardepth.so (MI355X / gfx950 hot path).
+ *
+ * Drop-in boundary for the polarimetric depth hot path.  The reference
+ * (kkaytekin/Supervised-Depth-Estimation-from-Polarized-Images) is pure Python on
+ * PyTorch and has no FFI of its own; the entry points below are what a ctypes
+ * binding inside the reference's modules would call (INTEGRATION.md shows the
+ * stubs).  Each entry point cites the reference code it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only, no framework types;
+ *   - device pointers come from the caller (e.g. tensor.data_ptr()); the caller
+ *     owns every buffer including workspaces; nothing is allocated or freed here;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no entry point
+ *     synchronises the device;
+ *   - return 0 on success, a negative PD_E* code on failure; the message is
+ *     available from pd_last_error() (thread-local);
+ *   - re-entrant: no global mutable state.
+ */
+#ifndef POLARDEPTH_H
+#define POLARDEPTH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PD_OK 0
+#define PD_EINVAL (-22)  /* bad argument (shape, alignment, null pointer) */
+#define PD_ELAUNCH (-5)  /* HIP reported a launch error */
+
+const char* pd_last_error(void);
+int pd_version(void);
+
+/* ------------------------------------------------------------------------- K1
+ * Fused Stokes / DoLP / AoLP / physical-normals kernel.
+ *
+ * Replaces, in one pass over the four polarizer planes:
+ *   polarisation/xolp.py:8-34            Iun_and_xolp   (mode PD_POLAR_LS)
+ *   manydepth/datasets/indoor_dataset.py:430-442  IndoorDataset.get_xolp
+ *   ppp_code/physical_normals_channels.py:15-36   PolarisationImage_channel (mode PD_POLAR_STOKES)
+ *   manydepth/normals_vec.py:11-60       rho_diffuse / rho_spec / calc_normals
+ *   manydepth/networks/pre_encoders.py:78-79,99-113  normalizeInput('XOLP') / get_normals
+ *
+ * Tables: a packed, position-independent blob (AoLP LUT over (I0-I90, I45-I135)
+ * plus the three theta(rho) interpolation tables with scipy interp1d
+ * 'linear'/'extrapolate' semantics).  Build it on the host with one of the two
+ * functions below, copy it to the device once, and pass the device pointer.
+ */
+#define PD_POLAR_LS 0
+#define PD_POLAR_STOKES 1
+
+/* bytes needed for the table blob with n_d / n_s1 / n_s2 table nodes */
+size_t pd_polar_tables_bytes(int n_d, int n_s1, int n_s2);
+/* Pack caller-computed tables (x ascending, y), e.g. the NumPy ones of normals_vec.py:13-47. */
+int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_d,
+                         const double* x_s1, const double* y_s1, int n_s1,
+                         const double* x_s2, const double* y_s2, int n_s2,
+                         void* host_blob, size_t blob_bytes);
+/* Compute the tables with libm for refractive index n (1000 theta nodes, normals_vec.py:13,27)
+ * and pack them.  *blob_bytes_out receives the size actually used. */
+int pd_polar_tables_build(double n, void* host_blob, size_t blob_bytes, size_t* blob_bytes_used);
+
+/*
+ * pol        [B,4,H,W] uint8 device, planes in 0/45/90/135 degree order (pol00, pol01, pol10, pol11)
+ * mask       [B,H,W] uint8 device or NULL (STOKES mode: outputs are 0 where mask == 0)
+ * xolp       [B,2,H,W] fp32 or NULL   ch0 DoLP, ch1 AoLP      == inputs[("xolp",0,0)].float()
+ * xolp_std   [B,2,H,W] fp32 or NULL   (xolp-0.08693199701957657)/0.44430732785457433
+ * normals    [B,9,H,W] fp32 or NULL   cat(N_diff, N_spec1, N_spec2)   == get_normals(xolp).float()
+ * ints       [B,5,H,W] int32 or NULL  exact by-products: d1, d2, idx_diffuse, idx_spec1, idx_spec2
+ * tables     device copy of the blob
+ * H*W must be a multiple of 4; all pointers 16-byte aligned.
+ */
+int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, void* normals,
+                 void* ints, const void* tables, size_t tables_bytes,
+                 int B, int H, int W, int mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLARDEPTH_H */

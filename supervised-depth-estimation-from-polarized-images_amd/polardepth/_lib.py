@@ -1,0 +1,76 @@
+"""ctypes loader for libpolardepth.so (C ABI in include/polardepth.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpolardepth.so")
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class PolarDepthError(RuntimeError):
+    pass
+
+
+_c = ctypes
+_vp, _i, _sz, _dbl = _c.c_void_p, _c.c_int, _c.c_size_t, _c.c_double
+_dp = _c.POINTER(_c.c_double)
+
+# name -> (restype, argtypes); mirrors include/polardepth.h one to one
+SIGNATURES = {
+    "pd_last_error": (_c.c_char_p, []),
+    "pd_version": (_i, []),
+    "pd_polar_tables_bytes": (_sz, [_i, _i, _i]),
+    "pd_polar_tables_pack": (_i, [_dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _i, _vp, _sz]),
+    "pd_polar_tables_build": (_i, [_dbl, _vp, _sz, _c.POINTER(_sz)]),
+    "pd_polar_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+}
+
+
+class _Lib:
+    """Lazy handle; attribute access loads the library or raises LibraryMissing."""
+
+    def __init__(self):
+        self._h = None
+
+    def _load(self):
+        if self._h is None:
+            if not os.path.exists(_SO):
+                raise LibraryMissing(
+                    f"{_SO} not found: build it with `make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}` "
+                    "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+            h = ctypes.CDLL(_SO)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(h, name)
+                fn.restype = res
+                fn.argtypes = args
+            self._h = h
+        return self._h
+
+    def __getattr__(self, name):
+        return getattr(self._load(), name)
+
+    @property
+    def path(self):
+        return _SO
+
+
+lib = _Lib()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.pd_last_error()
+        raise PolarDepthError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device/host pointer of a tensor or None."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,98 @@
+"""Host wrapper of K1, the fused Stokes/DoLP/AoLP/normals kernel (csrc/polar.hip).
+
+Mirrors polarisation/xolp.py:8-34 (Iun_and_xolp), indoor_dataset.py:430-442 (get_xolp),
+normals_vec.py:11-60 and pre_encoders.py:78-79,99-113 of the reference.
+"""
+import ctypes
+import functools
+
+import numpy as np
+import torch
+
+from ._lib import lib, check, ptr, stream_ptr
+
+MODE_LS, MODE_STOKES = 0, 1
+N_THETA = 1000
+
+
+def theta_tables_numpy(n=1.5):
+    """The three theta(rho) tables exactly as the reference builds them (NumPy, fp64).
+
+    normals_vec.py:13-19 (diffuse) and :27-47 (specular split at argmax); each table is
+    returned x-ascending the way scipy.interp1d(assume_sorted=False) stores it.
+    """
+    th = np.linspace(0, np.pi / 2, N_THETA)
+    s = np.sin(th)
+    rho_d = ((n - 1 / n) ** 2 * s ** 2) / (
+        2 + 2 * n ** 2 - (n + 1 / n) ** 2 * s ** 2 + 4 * np.cos(th) * np.sqrt(n ** 2 - s ** 2))
+    rho_s = (2 * s ** 2 * np.cos(th) * np.sqrt(n ** 2 - s ** 2)) / (
+        n ** 2 - s ** 2 - n ** 2 * s ** 2 + 2 * s ** 4)
+    imax = int(np.argmax(rho_s))
+
+    def asc(x, y):
+        ind = np.argsort(x, kind="mergesort")
+        return np.ascontiguousarray(x[ind]), np.ascontiguousarray(y[ind])
+
+    return asc(rho_d, th), asc(rho_s[:imax], th[:imax]), asc(rho_s[imax:], th[imax:])
+
+
+def pack_tables(tables):
+    """[(x,y)]*3 fp64 -> packed host blob (uint8 tensor) via pd_polar_tables_pack."""
+    (xd, yd), (x1, y1), (x2, y2) = tables
+    nbytes = lib.pd_polar_tables_bytes(len(xd), len(x1), len(x2))
+    if nbytes == 0:
+        raise ValueError("theta tables need at least two nodes each")
+    blob = torch.empty(nbytes, dtype=torch.uint8)
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    check(lib.pd_polar_tables_pack(dp(xd), dp(yd), len(xd), dp(x1), dp(y1), len(x1), dp(x2), dp(y2), len(x2),
+                                   ctypes.c_void_p(blob.data_ptr()), nbytes), "pd_polar_tables_pack")
+    return blob
+
+
+def build_tables_libm(n=1.5):
+    """Packed blob computed entirely inside the library (libm); for C-only consumers."""
+    nbytes = lib.pd_polar_tables_bytes(N_THETA, N_THETA, N_THETA)
+    blob = torch.empty(nbytes, dtype=torch.uint8)
+    used = ctypes.c_size_t(0)
+    check(lib.pd_polar_tables_build(float(n), ctypes.c_void_p(blob.data_ptr()), nbytes, ctypes.byref(used)),
+          "pd_polar_tables_build")
+    return blob[:used.value].clone()
+
+
+@functools.lru_cache(maxsize=8)
+def _device_tables(n, device_index):
+    blob = pack_tables(theta_tables_numpy(n))
+    return blob.to(torch.device("cuda", device_index))
+
+
+def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=None):
+    """Run K1 on ``pol`` [B,4,H,W] uint8 (planes 0/45/90/135 deg) on the GPU.
+
+    want: any of "xolp", "xolp_std", "normals", "ints".  Returns a dict of fp32 NCHW tensors
+    ([B,2,H,W], [B,2,H,W], [B,9,H,W]) and the int32 [B,5,H,W] by-products.
+    """
+    if not (isinstance(pol, torch.Tensor) and pol.is_cuda):
+        raise RuntimeError("polar_forward needs a CUDA(HIP) uint8 tensor; there is no CPU fallback")
+    if pol.dtype != torch.uint8 or pol.dim() != 4 or pol.shape[1] != 4:
+        raise ValueError(f"pol must be uint8 [B,4,H,W], got {pol.dtype} {tuple(pol.shape)}")
+    pol = pol.contiguous()
+    B, _, H, W = pol.shape
+    if tables is None:
+        tables = _device_tables(float(n), pol.device.index)
+    out = {}
+    mk = lambda c, dt=torch.float32: torch.empty((B, c, H, W), dtype=dt, device=pol.device)
+    if "xolp" in want:
+        out["xolp"] = mk(2)
+    if "xolp_std" in want:
+        out["xolp_std"] = mk(2)
+    if "normals" in want:
+        out["normals"] = mk(9)
+    if "ints" in want:
+        out["ints"] = mk(5, torch.int32)
+    if mask is not None:
+        mask = mask.to(torch.uint8).contiguous()
+    with torch.cuda.device(pol.device):
+        check(lib.pd_polar_fwd(ptr(pol), ptr(mask), ptr(out.get("xolp")), ptr(out.get("xolp_std")),
+                               ptr(out.get("normals")), ptr(out.get("ints")), ptr(tables), tables.numel(),
+                               B, H, W, mode, stream_ptr()), "pd_polar_fwd")
+    return out

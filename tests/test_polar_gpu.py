@@ -1,0 +1,132 @@
+"""K1 (pd_polar_fwd) on the MI355X vs the CPU oracle: bit-exact DoLP/AoLP/index maps,
+normals within a stated absolute tolerance; full-size size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from polardepth import polar as pdpolar
+from oracle import polar as opolar
+
+pytestmark = pytest.mark.gpu
+NORMALS_ATOL = 2e-6   # fp32 cos/sin(phi) (torch-CPU vs device libm, <= 2 ulp) x fp64 sin(theta), values in [-1, 1]
+
+
+def _run(pol_np, want=("xolp", "xolp_std", "normals", "ints"), **kw):
+    out = pdpolar.polar_forward(torch.from_numpy(pol_np).cuda(), want=want, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu() for k, v in out.items()}
+
+
+def _check_against_oracle(pol_np):
+    got = _run(pol_np)
+    xolp, xstd, normals, ints = opolar.polar_forward(pol_np)
+    assert torch.equal(got["xolp"], xolp), "DoLP/AoLP must be bit-exact"
+    assert torch.equal(got["xolp_std"], xstd), "standardised XOLP must be bit-exact"
+    gi = got["ints"].numpy()
+    np.testing.assert_array_equal(gi[:, 0], ints["d1"])
+    np.testing.assert_array_equal(gi[:, 1], ints["d2"])
+    np.testing.assert_array_equal(gi[:, 2], ints["idx_d"])
+    np.testing.assert_array_equal(gi[:, 3], ints["idx_s1"])
+    np.testing.assert_array_equal(gi[:, 4], ints["idx_s2"])
+    np.testing.assert_allclose(got["normals"].numpy(), normals.numpy(), rtol=0, atol=NORMALS_ATOL)
+
+
+def test_golden_images(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_xolp.npz"))
+    for name in ("rnd", "phys"):
+        _check_against_oracle(np.ascontiguousarray(np.moveaxis(g[name + "_img"], -1, 0)[None]))
+    g3 = np.load(os.path.join(golden_dir, "g3_normals.npz"))
+    pol = np.stack([np.moveaxis(g[n + "_img"], -1, 0) for n in ("phys", "rnd")])
+    got = _run(np.ascontiguousarray(pol), want=("normals", "xolp_std"))
+    # fixture produced by the reference's own get_normals on its lstsq XOLP; differences beyond atol
+    # can only come from branch-cut flips of the lstsq AoLP (none in these two images)
+    np.testing.assert_allclose(got["normals"].numpy(), g3["normals"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(got["xolp_std"].numpy(), g3["xolp_std"], rtol=0, atol=1e-6)
+
+
+def test_all_difference_pairs_exhaustive():
+    """Every (d1,d2) in [-255,255]^2 (the whole AoLP domain) at the darkest and a bright offset."""
+    d = np.arange(-255, 256)
+    d2, d1 = np.meshgrid(d, d, indexing="ij")
+    planes = []
+    for off_frac in (0.0, 1.0):
+        i0 = np.maximum(d1, 0); i90 = np.maximum(-d1, 0)
+        i45 = np.maximum(d2, 0); i135 = np.maximum(-d2, 0)
+        room1 = 255 - np.maximum(i0, i90); room2 = 255 - np.maximum(i45, i135)
+        o1 = (room1 * off_frac).astype(int); o2 = (room2 * off_frac).astype(int)
+        p = np.stack([i0 + o1, i45 + o2, i90 + o1, i135 + o2]).astype(np.uint8)    # [4,511,511]
+        p = np.pad(p, ((0, 0), (0, 1), (0, 1)), mode="edge")                      # 512x512
+        planes.append(p)
+    _check_against_oracle(np.stack(planes))
+
+
+def test_random_uint8_and_degenerate():
+    rng = np.random.default_rng(5)
+    pol = rng.integers(0, 256, (3, 4, 64, 100), dtype=np.uint8)
+    pol[0, :, :4] = 0          # all-zero pixels: 0/0 -> 0
+    pol[0, :, 4:8] = 255       # saturated unpolarised
+    pol[1, 0, :8] = 255; pol[1, 1:, :8] = 0   # rho == 2
+    pol[2, 1] = pol[2, 3]      # I45 == I135: branch cut rows
+    _check_against_oracle(pol)
+
+
+def test_empty_batch_and_bad_shapes():
+    out = pdpolar.polar_forward(torch.zeros((0, 4, 8, 8), dtype=torch.uint8, device="cuda"), want=("xolp",))
+    assert out["xolp"].shape == (0, 2, 8, 8)
+    with pytest.raises(Exception, match="multiple of 4"):
+        pdpolar.polar_forward(torch.zeros((1, 4, 3, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        pdpolar.polar_forward(torch.zeros((1, 3, 4, 4), dtype=torch.uint8, device="cuda"))
+
+
+def test_stokes_mode_with_mask():
+    rng = np.random.default_rng(11)
+    pol = rng.integers(0, 256, (1, 4, 32, 40), dtype=np.uint8)
+    mask = rng.random((1, 32, 40)) > 0.25
+    got = pdpolar.polar_forward(torch.from_numpy(pol).cuda(), mode=pdpolar.MODE_STOKES,
+                                mask=torch.from_numpy(mask).cuda(), want=("xolp", "normals"))
+    img = np.moveaxis(pol[0], 0, -1).astype(np.float64) * mask[0][..., None]   # images are masked first (:117-121)
+    rho, phi, _ = opolar.stokes_channel(img, mask[0])
+    x = got["xolp"].cpu().numpy()[0]
+    with np.errstate(over="ignore"):
+        exp_rho = rho.astype(np.float32)
+    ok = np.isfinite(exp_rho)
+    np.testing.assert_array_equal(x[0][ok], exp_rho[ok])
+    np.testing.assert_array_equal(np.isnan(x[0]), np.isnan(exp_rho))
+    np.testing.assert_array_equal(x[1], phi.astype(np.float32))
+    n = got["normals"].cpu().numpy()[0]
+    assert np.all(n[:, ~mask[0]] == 0)
+    # all-fp64 script variant (physical_normals_channels.py:75-83, 124-129) within fp32 tolerance
+    th_d = opolar.rho_diffuse(rho)
+    nd = opolar.calc_normals_numpy(phi, th_d)
+    fin = mask[0] & np.isfinite(rho) & (rho < 10)
+    np.testing.assert_allclose(np.moveaxis(n[:3], 0, -1)[fin], nd[fin], rtol=0, atol=5e-6)
+
+
+def test_full_size_properties():
+    """BASELINE size (B=8, 512x612): size-independent properties instead of a slow oracle pass."""
+    g = torch.Generator().manual_seed(0)
+    pol = torch.randint(0, 256, (8, 4, 512, 612), dtype=torch.uint8, generator=g)
+    full = _run(pol.numpy(), want=("xolp", "normals", "ints"))
+    # (1) batching invariance: image 5 alone == image 5 inside the batch (bit-exact)
+    one = _run(pol[5:6].numpy(), want=("xolp", "normals"))
+    assert torch.equal(one["xolp"][0], full["xolp"][5]) and torch.equal(one["normals"][0], full["normals"][5])
+    # (2) swapping 0<->90 and 45<->135 negates (d1,d2): DoLP bit-identical, AoLP shifts by pi/2 mod pi
+    sw = _run(pol[:2, [2, 3, 0, 1]].contiguous().numpy(), want=("xolp", "ints"))
+    assert torch.equal(sw["xolp"][:, 0], full["xolp"][:2, 0])
+    assert torch.equal(sw["ints"][:, :2], -full["ints"][:2, :2])
+    polarised = (full["ints"][:2, 0] != 0) | (full["ints"][:2, 1] != 0)
+    dphi = (sw["xolp"][:, 1] - full["xolp"][:2, 1]).abs()[polarised]
+    assert torch.allclose(dphi, torch.full_like(dphi, np.pi / 2), atol=1e-6)
+    # (3) every normal is a unit vector; bins stay inside their tables
+    n = full["normals"].double().reshape(8, 3, 3, 512, 612)
+    assert (n.pow(2).sum(2).sqrt() - 1).abs().max() < 1e-6
+    ints = full["ints"]
+    assert ints[:, 2].min() >= 1 and ints[:, 2].max() <= 999 and ints[:, 3].max() <= 624 and ints[:, 4].max() <= 374
+    # (4) oracle spot check on a 64-row stripe of one image
+    stripe = pol[3:4, :, 100:164].contiguous().numpy()
+    xolp, _, normals, _ = opolar.polar_forward(stripe)
+    assert torch.equal(full["xolp"][3, :, 100:164], xolp[0])
+    np.testing.assert_allclose(full["normals"][3, :, 100:164].numpy(), normals[0].numpy(), rtol=0, atol=NORMALS_ATOL)
