@@ -325,8 +325,9 @@ __global__ __launch_bounds__(kThreads) void polar_kernel(
 extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, void* normals,
                             void* ints, const void* tables, size_t tables_bytes, int B, int H, int W, int mode,
                             void* stream) {
-    PD_REQUIRE(pol && tables, "pd_polar_fwd: pol and tables must not be null");
     PD_REQUIRE(B >= 0 && H > 0 && W > 0, "pd_polar_fwd: bad shape B=%d H=%d W=%d", B, H, W);
+    if (B == 0 && (long)H * W % 4 == 0) return PD_OK;  // empty batch: nothing to do (pointers may be null)
+    PD_REQUIRE(pol && tables, "pd_polar_fwd: pol and tables must not be null");
     PD_REQUIRE(mode == PD_POLAR_LS || mode == PD_POLAR_STOKES, "pd_polar_fwd: unknown mode %d", mode);
     const long P = (long)H * W;
     PD_REQUIRE(P % 4 == 0, "pd_polar_fwd: H*W=%ld must be a multiple of 4", P);
@@ -335,7 +336,6 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
                    pd::aligned16(ints) && pd::aligned16(tables) && (!mask || pd::aligned16(mask)),
                "pd_polar_fwd: pointers must be 16-byte aligned");
     PD_REQUIRE(xolp || xolp_std || normals || ints, "pd_polar_fwd: no output requested");
-    if (B == 0) return PD_OK;
     const long qpi = P / 4, total = qpi * B;
     const bool need_normals = normals != nullptr || ints != nullptr;
     // LDS image size is fixed by the table node counts; validated against the blob size on the

@@ -41,6 +41,9 @@ class _Lib:
                 raise LibraryMissing(
                     f"{_SO} not found: build it with `make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}` "
                     "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+            # torch bundles its own libamdhip64; it must be the HIP runtime of this process, so that
+            # torch's streams / allocations and this library's kernels live in one runtime.
+            import torch  # noqa: F401
             h = ctypes.CDLL(_SO)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(h, name)
