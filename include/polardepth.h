@@ -78,6 +78,49 @@ int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, 
                  void* ints, const void* tables, size_t tables_bytes,
                  int B, int H, int W, int mode, void* stream);
 
+
+/* ------------------------------------------------------------------------- K2
+ * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ *
+ * Replaces torch.nn.Conv2d (+ ReflectionPad2d) and its autograd on the hot path:
+ *   manydepth/networks/pre_encoders.py:15-25       ConvBlock.conv (bias, zero padding, stride 1/2)
+ *   manydepth/networks/resnet_encoder.py:813-818   torchvision resnet18 conv1 / layer1 / layer2
+ *   manydepth/layers.py:364-380                    Conv3x3 = ReflectionPad2d(1) + Conv2d(3)  (decoder)
+ *
+ * Layouts: x is fp32 with explicit element strides (sN,sH,sW,sC) -- NHWC (sC == 1) takes the
+ * 16-byte gather path, anything else (e.g. the NCHW 2/3/9-channel stem inputs) the scalar one;
+ * w is [Cout][KH][KW][Cin] (torch channels_last storage of the [Cout,Cin,KH,KW] parameter);
+ * y is NHWC with row stride ldy >= Cout (ldy > Cout writes into a channel slice of a wider buffer).
+ *
+ * mode  0 zero padding | 1 reflection padding | 2 transposed (data gradient: x is dY on the
+ *       forward output grid [N,H,W,C=Cout_fwd], (Ho,Wo) is the forward INPUT grid, w is the
+ *       transposed weight [Cin_fwd][KH][KW][Cout_fwd] from pd_weight_transpose)
+ * act   0 none | 1 ReLU | 2 ELU(alpha=1) | 3 sigmoid      (applied after bias)
+ * affine != 0: every in-bounds input tap is replaced by (x - sub) / div before the product
+ *       (ShallowEncoder.normalizeInput pre_encoders.py:76-83, resnet_encoder.py:812), scalar path only.
+ * stats  NULL or fp32 [pd_conv2d_stats_rows(M,Cout)][Cout][2]: per-workgroup column sums and sums
+ *       of squares of (conv + bias) -- training-mode BatchNorm statistics (reduced by pd_bn_finalize).
+ */
+int pd_conv2d_tile_m(long M, int Cout);
+long pd_conv2d_stats_rows(long M, int Cout);
+int pd_conv2d(const void* x, const void* w, const void* bias, void* y, void* stats,
+              int N, int H, int W, int C, long sN, long sH, long sW, long sC,
+              int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode, int act,
+              int affine, float sub, float div, long ldy, void* stream);
+
+/* Weight gradient dW[Cout][KH][KW][Cin] (+ optional dbias[Cout]) of the convolution above
+ * (modes 0 and 1).  dy is NHWC on the output grid with row stride ldd.  Partial tiles go to
+ * `workspace` (pd_conv2d_wgrad_workspace bytes) and are summed deterministically; accumulate != 0
+ * adds to dw/dbias instead of overwriting.  Replaces autograd's conv weight/bias gradient. */
+size_t pd_conv2d_wgrad_workspace(long M, int Cout, int K);
+int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* workspace, size_t ws_bytes,
+                    int N, int H, int W, int C, long sN, long sH, long sW, long sC,
+                    int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode,
+                    int affine, float sub, float div, long ldd, int accumulate, void* stream);
+
+/* w [Cout][T][Cin] -> wt [Cin][T][Cout], T = KH*KW: operand of the mode-2 (data gradient) GEMM. */
+int pd_weight_transpose(const void* w, void* wt, int Cout, int T, int Cin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

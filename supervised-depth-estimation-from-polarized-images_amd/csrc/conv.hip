@@ -1,0 +1,599 @@
+// K2 -- implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// One kernel template serves
+//   * forward convolution, zero padding      (nn.Conv2d in pre_encoders.py:15-25, torchvision resnet18)
+//   * forward convolution, reflection padding (layers.py:364-380 Conv3x3 = ReflectionPad2d(1) + Conv2d(3))
+//   * data gradient (transposed convolution, any stride) of either
+// as C[m][n] = sum_k A[m][k] * Bt[n][k]  ("NT" GEMM, both operands K-contiguous):
+//   m = output pixel (n, oh, ow), n = output channel, k = (kh, kw, cin)
+//   A is gathered on the fly from the NHWC (or arbitrarily strided) activation tensor,
+//   Bt is the weight tensor in [Cout][kh][kw][Cin] order (= torch channels_last storage).
+// Tiles: BM x BN x 32 per 256-thread workgroup, staged through LDS (rows padded to 36 floats so
+// that ds_read_b128 fragment reads and ds_write_b128 stores are bank-conflict free), software
+// double-buffered (global->register prefetch of chunk q+1 while chunk q feeds the MFMAs).
+// Each lane reads four consecutive k per ds_read_b128; lanes 0-31 take k = 8g..8g+3 and lanes
+// 32-63 take k = 8g+4..8g+7, which is a legal permutation of the contraction index because A and
+// B use the same one.
+// Epilogue: bias, activation (none / ReLU / ELU / sigmoid), optional per-workgroup column
+// sums and sums of squares (training-mode BatchNorm statistics, reduced later in fp64),
+// NHWC store with an arbitrary row stride (lets a layer write into a slice of a concat buffer).
+//
+// The weight-gradient kernel (contraction over pixels, "TN" GEMM) lives below in the same file.
+#include "pd_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;        // contraction chunk
+constexpr int LDT = BK + 4;   // padded LDS row (floats): 144 B, conflict-free for b128
+constexpr int NT = 256;       // threads per workgroup (4 waves)
+
+enum { MODE_ZERO = 0, MODE_REFLECT = 1, MODE_TRANSPOSED = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    float* stats;            // [gridM][Co][2] or null
+    int N, H, W, C;          // logical dims of x
+    long sN, sH, sW, sC;     // element strides of x
+    int Ho, Wo, Co;          // output grid / channels
+    int KH, KW, stride, pad;
+    int mode, act;
+    int affine;
+    float sub, div;
+    int K;
+    long M;
+    long ldy;                // row stride of y in elements
+    int mtiles, ntiles;
+};
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Decode the input coordinate of tap (kh,kw) for output pixel (oh,ow). Returns false for a zero tap.
+__device__ __forceinline__ bool tap_coord(const ConvArgs& a, int oh, int ow, int kh, int kw, int& ih, int& iw) {
+    if (a.mode == MODE_TRANSPOSED) {
+        int th = oh + a.pad - kh, tw = ow + a.pad - kw;
+        if (th < 0 || tw < 0) return false;
+        if (a.stride > 1) {
+            if ((th % a.stride) | (tw % a.stride)) return false;
+            th /= a.stride; tw /= a.stride;
+        }
+        ih = th; iw = tw;
+        return th < a.H && tw < a.W;
+    }
+    ih = oh * a.stride - a.pad + kh;
+    iw = ow * a.stride - a.pad + kw;
+    if (a.mode == MODE_REFLECT) {
+        if (ih < 0) ih = -ih;
+        if (ih >= a.H) ih = 2 * a.H - 2 - ih;
+        if (iw < 0) iw = -iw;
+        if (iw >= a.W) iw = 2 * a.W - 2 - iw;
+        return true;
+    }
+    return ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+}
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;     // 32x32 MFMA tiles per wave
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int A_VEC_ITERS = BM / 32;          // 16-byte pieces per thread per chunk (A)
+    constexpr int B_VEC_ITERS = BN / 32;
+    constexpr int A_SC_ITERS = BM / 8;            // scalar elements per thread per chunk (A)
+    constexpr int B_SC_ITERS = BN / 8;
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDT];
+    __shared__ int rowinfo[BM][3];                // n (or -1), oh, ow
+    __shared__ float red[4][WN][2];
+
+    // XCD-aware mapping: consecutive logical tiles (which share input halos / the A tile) land
+    // on the same XCD and hence the same L2.  Grid is padded to a multiple of 8.
+    const int nblk = a.mtiles * a.ntiles;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (logical >= nblk) return;
+    const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+
+    for (int r = tid; r < BM; r += NT) {
+        long m = m0 + r;
+        if (m < a.M) {
+            int hw = a.Ho * a.Wo;
+            int n = (int)(m / hw);
+            int rem = (int)(m - (long)n * hw);
+            int oh = rem / a.Wo;
+            rowinfo[r][0] = n; rowinfo[r][1] = oh; rowinfo[r][2] = rem - oh * a.Wo;
+        } else {
+            rowinfo[r][0] = -1; rowinfo[r][1] = 0; rowinfo[r][2] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int nchunks = (a.K + BK - 1) / BK;
+    float4 pa[VEC ? A_VEC_ITERS : 1], pb[VEC ? B_VEC_ITERS : 1];
+    float sa[VEC ? 1 : A_SC_ITERS], sb[VEC ? 1 : B_SC_ITERS];
+
+    auto load_chunk = [&](int q) {
+        if (VEC) {
+            const int pc = tid & 7;
+            const int k = q * BK + 4 * pc;
+            const bool kv = k < a.K;
+            const int tap = k / a.C, c = k - tap * a.C;
+            const int kh = tap / a.KW, kw = tap - kh * a.KW;
+#pragma unroll
+            for (int i = 0; i < A_VEC_ITERS; ++i) {
+                const int r = (tid >> 3) + 32 * i;
+                const int n = rowinfo[r][0];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                int ih, iw;
+                if (kv && n >= 0 && tap_coord(a, rowinfo[r][1], rowinfo[r][2], kh, kw, ih, iw))
+                    v = ldg4(a.x + (long)n * a.sN + (long)ih * a.sH + (long)iw * a.sW + c);
+                pa[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < B_VEC_ITERS; ++i) {
+                const int nr = n0 + (tid >> 3) + 32 * i;
+                pb[i] = (kv && nr < a.Co) ? ldg4(a.w + (long)nr * a.K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int kc = tid & 31;
+            const int k = q * BK + kc;
+            const bool kv = k < a.K;
+            const int tap = k / a.C, c = k - tap * a.C;
+            const int kh = tap / a.KW, kw = tap - kh * a.KW;
+#pragma unroll
+            for (int i = 0; i < A_SC_ITERS; ++i) {
+                const int r = (tid >> 5) + 8 * i;
+                const int n = rowinfo[r][0];
+                float v = 0.f;
+                int ih, iw;
+                if (kv && n >= 0 && tap_coord(a, rowinfo[r][1], rowinfo[r][2], kh, kw, ih, iw)) {
+                    v = a.x[(long)n * a.sN + (long)ih * a.sH + (long)iw * a.sW + (long)c * a.sC];
+                    if (a.affine) v = (v - a.sub) / a.div;
+                }
+                sa[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < B_SC_ITERS; ++i) {
+                const int nr = n0 + (tid >> 5) + 8 * i;
+                sb[i] = (kv && nr < a.Co) ? a.w[(long)nr * a.K + k] : 0.f;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        if (VEC) {
+            const int pc = tid & 7;
+#pragma unroll
+            for (int i = 0; i < A_VEC_ITERS; ++i)
+                *reinterpret_cast<float4*>(&As[buf][(tid >> 3) + 32 * i][4 * pc]) = pa[i];
+#pragma unroll
+            for (int i = 0; i < B_VEC_ITERS; ++i)
+                *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) + 32 * i][4 * pc]) = pb[i];
+        } else {
+            const int kc = tid & 31;
+#pragma unroll
+            for (int i = 0; i < A_SC_ITERS; ++i) As[buf][(tid >> 5) + 8 * i][kc] = sa[i];
+#pragma unroll
+            for (int i = 0; i < B_SC_ITERS; ++i) Bs[buf][(tid >> 5) + 8 * i][kc] = sb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int frow = lane & 31, fk = 4 * (lane >> 5);
+    for (int q = 0; q < nchunks; ++q) {
+        const int buf = q & 1;
+        if (q + 1 < nchunks) load_chunk(q + 1);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const float4*>(&As[buf][wm * WM + 32 * i + frow][8 * g + fk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * WN + 32 * j + frow][8 * g + fk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (q + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col_l = lane & 31;
+    const int rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + 32 * j + col_l;
+        const bool cv = col < a.Co;
+        const float bv = (a.bias && cv) ? a.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + rbase;
+                float v = acc[i][j][r] + bv;
+                if (m < a.M && cv) {
+                    s1 += v;
+                    s2 += v * v;
+                    if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (a.act == ACT_ELU) v = v > 0.f ? v : expm1f(v);
+                    else if (a.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                    a.y[m * a.ldy + col] = v;
+                }
+            }
+        }
+        if (a.stats) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        if (tid < BN) {   // column tid of the block tile: sum over the waves that own it
+            const int w_n = tid / WN, cl = tid - w_n * WN;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w_m = 0; w_m < BM / WM; ++w_m) {
+                t1 += red[w_m * WAVES_N + w_n][cl][0];
+                t2 += red[w_m * WAVES_N + w_n][cl][1];
+            }
+            const int col = n0 + tid;
+            if (col < a.Co) {
+                float* o = a.stats + ((long)mt * a.Co + col) * 2;
+                o[0] = t1; o[1] = t2;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
+    a.mtiles = (int)((a.M + BM - 1) / BM);
+    a.ntiles = (a.Co + BN - 1) / BN;
+    const long nblk = (long)a.mtiles * a.ntiles;
+    const unsigned grid = (unsigned)((nblk + 7) / 8 * 8);
+    if (vec) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3(grid), dim3(NT), 0, st, a);
+    return pd::check_launch("pd_conv2d");
+}
+
+}  // namespace
+
+extern "C" int pd_conv2d_tile_m(long M, int Co) {
+    if (Co <= 32) return 128;   // 128x32 tile: four waves of one 32x32 MFMA tile each
+    return M >= 64 * 1024 ? 128 : 64;
+}
+
+extern "C" long pd_conv2d_stats_rows(long M, int Co) {
+    const int bm = pd_conv2d_tile_m(M, Co);
+    return (M + bm - 1) / bm;
+}
+
+extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, void* y, void* stats,
+                         int N, int H, int W, int C, long sN, long sH, long sW, long sC,
+                         int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
+                         int affine, float sub, float div, long ldy, void* stream) {
+    PD_REQUIRE(x && w && y, "pd_conv2d: null tensor");
+    PD_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && Co > 0, "pd_conv2d: bad dims");
+    PD_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "pd_conv2d: bad filter geometry");
+    PD_REQUIRE(mode >= 0 && mode <= 2 && act >= 0 && act <= 3, "pd_conv2d: bad mode/act");
+    PD_REQUIRE(mode != MODE_REFLECT || (pad < H && pad < W), "pd_conv2d: reflect pad must be < input size");
+    PD_REQUIRE(ldy >= Co, "pd_conv2d: ldy < Cout");
+    if (mode == MODE_TRANSPOSED) {
+        PD_REQUIRE(H == (Ho + 2 * pad - KH) / stride + 1 && W == (Wo + 2 * pad - KW) / stride + 1,
+                   "pd_conv2d: transposed: x grid is not the forward output grid of a %dx%d input", Ho, Wo);
+    } else {
+        PD_REQUIRE(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1,
+                   "pd_conv2d: output grid does not match input/filter geometry");
+    }
+    if (N == 0) return PD_OK;
+    ConvArgs a;
+    a.x = (const float*)x; a.w = (const float*)w; a.bias = (const float*)bias; a.y = (float*)y; a.stats = (float*)stats;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.sN = sN; a.sH = sH; a.sW = sW; a.sC = sC;
+    a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.mode = mode; a.act = act; a.affine = affine; a.sub = sub; a.div = div;
+    a.K = KH * KW * C; a.M = (long)N * Ho * Wo; a.ldy = ldy;
+    const bool vec = (C % 4 == 0) && sC == 1 && (sW % 4 == 0) && (sH % 4 == 0) && (sN % 4 == 0) && !affine &&
+                     pd::aligned16(x) && pd::aligned16(w);
+    hipStream_t st = (hipStream_t)stream;
+    const int bm = pd_conv2d_tile_m(a.M, Co);
+    if (Co > 32) return bm == 128 ? launch_conv<128, 64, 64, 32>(a, vec, st) : launch_conv<64, 64, 32, 32>(a, vec, st);
+    return launch_conv<128, 32, 32, 32>(a, vec, st);
+}
+
+// ===================================================================== weight gradient
+// dW[co][kh][kw][ci] = sum_m dY[m][co] * X[pix(m) + tap][ci]   ("TN" GEMM: contraction over pixels).
+// Workgroup = one 64(co) x 64(k) tile of dW for one slice of the pixel range; slices write
+// partial tiles to a workspace that pd_reduce_rows() sums deterministically (no float atomics).
+// Both operands keep their natural [pixel][channel] layout in LDS; the MFMA fragment of a
+// 32-wide channel group at a fixed pixel is 32 consecutive floats (conflict-free ds_read_b32).
+namespace {
+
+constexpr int WG_T = 64;          // tile edge (co and k)
+constexpr int WG_MC = 32;         // pixels per chunk
+constexpr int WG_LD = WG_T + 8;   // padded LDS row (floats)
+
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* part;      // [S][Co][K]
+    float* bpart;     // [S][Co] or null
+    int N, H, W, C;
+    long sN, sH, sW, sC;
+    int Ho, Wo, Co;
+    int KH, KW, stride, pad, mode;
+    int affine;
+    float sub, div;
+    int K;
+    long M, ldd;      // pixels, row stride of dy
+    long mper;        // pixels per slice (multiple of WG_MC)
+    int S, ktiles, ctiles;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ds[2][WG_MC][WG_LD];
+    __shared__ __attribute__((aligned(16))) float Xs[2][WG_MC][WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int b = blockIdx.x;
+    const int kt = b % a.ktiles; b /= a.ktiles;
+    const int ct = b % a.ctiles; b /= a.ctiles;
+    const int s = b;
+    const int co0 = ct * WG_T, k0 = kt * WG_T;
+    const long mbeg = (long)s * a.mper;
+    const long mend = (mbeg + a.mper < a.M) ? mbeg + a.mper : a.M;
+    const int nchunks = mend > mbeg ? (int)((mend - mbeg + WG_MC - 1) / WG_MC) : 0;
+
+    // fixed per-thread assignment.  VEC: rows r0, r0+16; one 16-byte piece (4 co / 4 k) per row.
+    // scalar X path: row r = tid>>3, eight k columns (tid&7) + 8*i.
+    const int pc = tid & 15, r0 = tid >> 4;
+    int vkh = 0, vkw = 0, vc = 0; bool vkv = false;           // VEC: decode of k = k0 + 4*pc
+    if (VEC) {
+        const int k = k0 + 4 * pc;
+        vkv = k < a.K;
+        const int tap = k / a.C;
+        vc = k - tap * a.C; vkh = tap / a.KW; vkw = tap - vkh * a.KW;
+    }
+    __shared__ int ktab[WG_T][3];
+    if (!VEC) {
+        if (tid < WG_T) {
+            const int k = k0 + tid;
+            const int tap = k / a.C;
+            const int kh = tap / a.KW;
+            ktab[tid][0] = k < a.K ? kh : -1; ktab[tid][1] = tap - kh * a.KW; ktab[tid][2] = k - tap * a.C;
+        }
+        __syncthreads();
+    }
+    // pixel coordinates of this thread's rows, advanced by WG_MC per chunk
+    const int hw = a.Ho * a.Wo;
+    int rn[2], roh[2], row_[2];
+    const int nrows = VEC ? 2 : 1;
+    for (int i = 0; i < nrows; ++i) {
+        const long m = mbeg + (VEC ? r0 + 16 * i : (tid >> 3));
+        rn[i] = (int)(m / hw);
+        const int rem = (int)(m - (long)rn[i] * hw);
+        roh[i] = rem / a.Wo; row_[i] = rem - roh[i] * a.Wo;
+    }
+    auto advance = [&](int i) {
+        row_[i] += WG_MC;
+        while (row_[i] >= a.Wo) { row_[i] -= a.Wo; if (++roh[i] == a.Ho) { roh[i] = 0; ++rn[i]; } }
+    };
+
+    float4 pd[2], px[2];
+    float sx[8];
+    // reuse the forward coordinate logic (zero / reflect padding)
+    ConvArgs ca;
+    ca.H = a.H; ca.W = a.W; ca.stride = a.stride; ca.pad = a.pad; ca.mode = a.mode;
+
+    auto load_chunk = [&](int q) {
+        const long mb = mbeg + (long)q * WG_MC;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long m = mb + r0 + 16 * i;
+            const int co = co0 + 4 * pc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < mend) {
+                const float* p = a.dy + m * a.ldd + co;
+                if (co + 3 < a.Co) v = ldg4(p);
+                else { if (co < a.Co) v.x = p[0]; if (co + 1 < a.Co) v.y = p[1]; if (co + 2 < a.Co) v.z = p[2]; }
+            }
+            pd[i] = v;
+        }
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const long m = mb + r0 + 16 * i;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                int ih, iw;
+                if (vkv && m < mend && tap_coord(ca, roh[i], row_[i], vkh, vkw, ih, iw))
+                    v = ldg4(a.x + (long)rn[i] * a.sN + (long)ih * a.sH + (long)iw * a.sW + vc);
+                px[i] = v;
+                advance(i);
+            }
+        } else {
+            const long m = mb + (tid >> 3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kc = (tid & 7) + 8 * i;
+                float v = 0.f;
+                int ih, iw;
+                const int kh = ktab[kc][0];
+                if (kh >= 0 && m < mend && tap_coord(ca, roh[0], row_[0], kh, ktab[kc][1], ih, iw)) {
+                    v = a.x[(long)rn[0] * a.sN + (long)ih * a.sH + (long)iw * a.sW + (long)ktab[kc][2] * a.sC];
+                    if (a.affine) v = (v - a.sub) / a.div;
+                }
+                sx[i] = v;
+            }
+            advance(0);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Ds[buf][r0 + 16 * i][4 * pc]) = pd[i];
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Xs[buf][r0 + 16 * i][4 * pc]) = px[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Xs[buf][tid >> 3][(tid & 7) + 8 * i] = sx[i];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = a.bpart != nullptr && kt == 0;
+
+    if (nchunks > 0) { load_chunk(0); store_chunk(0); }
+    __syncthreads();
+    const int fi = lane & 31, fk = lane >> 5;
+    for (int q = 0; q < nchunks; ++q) {
+        const int buf = q & 1;
+        if (q + 1 < nchunks) load_chunk(q + 1);
+#pragma unroll
+        for (int st = 0; st < WG_MC / 2; ++st) {
+            const float av = Ds[buf][2 * st + fk][wm * 32 + fi];
+            const float bv = Xs[buf][2 * st + fk][wn * 32 + fi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (do_bias && tid < WG_T) {
+#pragma unroll 8
+            for (int r = 0; r < WG_MC; ++r) bsum += Ds[buf][r][tid];
+        }
+        if (q + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D layout: col = lane&31 -> k, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co
+    const int k = k0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc[r];
+    }
+    if (do_bias && tid < WG_T && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = bsum;
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int S, long n, int accumulate) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int j = 0; j < S; ++j) s += part[(long)j * n + i];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+// w [Co][T][Ci] -> wt [Ci][T][Co]  (T = KH*KW): operand layout of the data-gradient GEMM
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                               int Co, int T, int Ci) {
+    const long n = (long)Co * T * Ci;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int co = (int)(i % Co);
+        const long r = i / Co;
+        const int t = (int)(r % T);
+        const int ci = (int)(r / T);
+        wt[i] = w[((long)co * T + t) * Ci + ci];
+    }
+}
+
+void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
+    const long tiles = (long)((Co + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T);
+    long s = (1536 + tiles - 1) / tiles;
+    const long smax = (M + 511) / 512;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    long per = (M + s - 1) / s;
+    per = (per + WG_MC - 1) / WG_MC * WG_MC;
+    s = (M + per - 1) / per;
+    if (s < 1) s = 1;
+    *S = (int)s; *mper = per;
+}
+
+}  // namespace
+
+extern "C" size_t pd_conv2d_wgrad_workspace(long M, int Co, int K) {
+    int S; long mper;
+    wgrad_plan(M, Co, K, &S, &mper);
+    return ((size_t)S * Co * K + (size_t)S * Co) * sizeof(float);
+}
+
+extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* workspace, size_t ws_bytes,
+                               int N, int H, int W, int C, long sN, long sH, long sW, long sC,
+                               int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode,
+                               int affine, float sub, float div, long ldd, int accumulate, void* stream) {
+    PD_REQUIRE(x && dy && dw && workspace, "pd_conv2d_wgrad: null tensor");
+    PD_REQUIRE(mode == MODE_ZERO || mode == MODE_REFLECT, "pd_conv2d_wgrad: mode must be 0 or 1");
+    PD_REQUIRE(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1,
+               "pd_conv2d_wgrad: output grid does not match input/filter geometry");
+    PD_REQUIRE(ldd >= Co && (ldd % 4 == 0 || Co < 4) , "pd_conv2d_wgrad: bad dy row stride");
+    if (N == 0) return PD_OK;
+    WgradArgs a;
+    a.x = (const float*)x; a.dy = (const float*)dy;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.sN = sN; a.sH = sH; a.sW = sW; a.sC = sC;
+    a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.mode = mode;
+    a.affine = affine; a.sub = sub; a.div = div;
+    a.K = KH * KW * C; a.M = (long)N * Ho * Wo; a.ldd = ldd;
+    wgrad_plan(a.M, Co, a.K, &a.S, &a.mper);
+    const size_t need = pd_conv2d_wgrad_workspace(a.M, Co, a.K);
+    PD_REQUIRE(ws_bytes >= need, "pd_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    a.part = (float*)workspace;
+    a.bpart = dbias ? a.part + (size_t)a.S * Co * a.K : nullptr;
+    a.ktiles = (a.K + WG_T - 1) / WG_T; a.ctiles = (Co + WG_T - 1) / WG_T;
+    const bool vec = (C % 4 == 0) && sC == 1 && (sW % 4 == 0) && (sH % 4 == 0) && (sN % 4 == 0) && !affine &&
+                     pd::aligned16(x);
+    PD_REQUIRE(pd::aligned16(dy) && (ldd % 4 == 0 || Co < 4), "pd_conv2d_wgrad: dy must be 16-byte aligned rows");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((long)a.ktiles * a.ctiles * a.S);
+    if (vec) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(grid), dim3(NT), 0, st, a);
+    int rc = pd::check_launch("pd_conv2d_wgrad");
+    if (rc) return rc;
+    const long nw = (long)Co * a.K;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((nw + 255) / 256 > 2048 ? 2048 : (nw + 255) / 256)), dim3(256), 0, st,
+                       a.part, (float*)dw, a.S, nw, accumulate);
+    if (dbias)
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((Co + 255) / 256)), dim3(256), 0, st,
+                           a.bpart, (float*)dbias, a.S, (long)Co, accumulate);
+    return pd::check_launch("pd_conv2d_wgrad/reduce");
+}
+
+extern "C" int pd_weight_transpose(const void* w, void* wt, int Co, int T, int Ci, void* stream) {
+    PD_REQUIRE(w && wt && Co > 0 && T > 0 && Ci > 0, "pd_weight_transpose: bad arguments");
+    const long n = (long)Co * T * Ci;
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)w, (float*)wt, Co, T, Ci);
+    return pd::check_launch("pd_weight_transpose");
+}

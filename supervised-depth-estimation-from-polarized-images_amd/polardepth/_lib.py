@@ -17,6 +17,7 @@ class PolarDepthError(RuntimeError):
 _c = ctypes
 _vp, _i, _sz, _dbl = _c.c_void_p, _c.c_int, _c.c_size_t, _c.c_double
 _dp = _c.POINTER(_c.c_double)
+_l, _f = _c.c_long, _c.c_float
 
 # name -> (restype, argtypes); mirrors include/polardepth.h one to one
 SIGNATURES = {
@@ -26,6 +27,14 @@ SIGNATURES = {
     "pd_polar_tables_pack": (_i, [_dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _i, _vp, _sz]),
     "pd_polar_tables_build": (_i, [_dbl, _vp, _sz, _c.POINTER(_sz)]),
     "pd_polar_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "pd_conv2d_tile_m": (_i, [_l, _i]),
+    "pd_conv2d_stats_rows": (_l, [_l, _i]),
+    "pd_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                       _i, _f, _f, _l, _vp]),
+    "pd_conv2d_wgrad_workspace": (_sz, [_l, _i, _i]),
+    "pd_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i,
+                             _i, _i, _f, _f, _l, _i, _vp]),
+    "pd_weight_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),
 }
 
 

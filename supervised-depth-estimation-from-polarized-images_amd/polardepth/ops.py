@@ -1,0 +1,139 @@
+"""Low-level tensor ops on the HIP library (no autograd here; see functional.py).
+
+Activations are fp32, logically NCHW, physically NHWC (torch.channels_last); weights are
+[Cout,Cin,kh,kw] logically and [Cout][kh][kw][Cin] physically (channels_last), i.e. exactly the
+operand layout of the implicit-GEMM kernels -- no repacking on the forward path.
+"""
+import torch
+
+from ._lib import lib, check, ptr, stream_ptr
+
+MODE_ZERO, MODE_REFLECT, MODE_TRANSPOSED = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
+CL = torch.channels_last
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("polardepth ops need CUDA(HIP) tensors; there is no CPU fallback")
+
+
+def empty_nhwc(n, c, h, w, device):
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=device, memory_format=CL)
+
+
+def is_nhwc(t):
+    n, c, h, w = t.shape
+    return t.stride() == (h * w * c, 1, w * c, c) or t.is_contiguous(memory_format=CL)
+
+
+def as_nhwc(t):
+    return t if is_nhwc(t) else t.contiguous(memory_format=CL)
+
+
+def weight_cl(w):
+    """Weight in [Cout][kh][kw][Cin] storage."""
+    return w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
+
+
+def conv_out_size(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, want_stats=False,
+               affine=None, out=None):
+    """y = act(conv(x, w) + bias).  x: [N,C,H,W] any strides; returns channels_last [N,Co,Ho,Wo].
+
+    want_stats -> also returns the per-workgroup BatchNorm partials [rows, Co, 2] (sum, sum of squares
+    of the pre-activation output).  affine=(sub, div) applies (x-sub)/div to in-bounds input taps.
+    out: optional pre-allocated NHWC tensor whose channel slice [:, c0:c0+Co] receives the result
+    (pass the sliced view; its channel stride must be 1).
+    """
+    _require_cuda(x, w, bias)
+    N, C, H, W = x.shape
+    Co, Ci, KH, KW = w.shape
+    assert Ci == C, f"channel mismatch {Ci} vs {C}"
+    w = weight_cl(w)
+    Ho, Wo = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
+    if out is None:
+        out = empty_nhwc(N, Co, Ho, Wo, x.device)
+    assert out.shape == (N, Co, Ho, Wo) and out.stride(1) == 1
+    ldy = out.stride(3)
+    assert out.stride(2) == Wo * ldy and out.stride(0) == Ho * Wo * ldy
+    stats = None
+    if want_stats:
+        rows = lib.pd_conv2d_stats_rows(N * Ho * Wo, Co)
+        stats = torch.empty((rows, Co, 2), dtype=torch.float32, device=x.device)
+    sub, div = (affine if affine is not None else (0.0, 1.0))
+    sN, sC, sH, sW = x.stride()
+    check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
+                        Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub, div, ldy,
+                        stream_ptr()), "pd_conv2d")
+    return (out, stats) if want_stats else out
+
+
+def weight_transposed(w):
+    """[Co,Ci,kh,kw] (channels_last) -> operand of the data-gradient GEMM: [Ci][kh][kw][Co] storage,
+    returned as a logical [Ci,Co,kh,kw] channels_last tensor."""
+    Co, Ci, KH, KW = w.shape
+    w = weight_cl(w)
+    wt = torch.empty((Ci, Co, KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
+    check(lib.pd_weight_transpose(ptr(w), ptr(wt), Co, KH * KW, Ci, stream_ptr()), "pd_weight_transpose")
+    return wt
+
+
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None):
+    """dX of a zero-padded convolution: transposed convolution of dy (NHWC) with w."""
+    _require_cuda(dy, w)
+    dy = as_nhwc(dy)
+    N, Co, Hy, Wy = dy.shape
+    _, Ci, KH, KW = w.shape
+    H, W = in_hw
+    if wt is None:
+        wt = weight_transposed(w)
+    dx = empty_nhwc(N, Ci, H, W, dy.device)
+    sN, sC, sH, sW = dy.stride()
+    check(lib.pd_conv2d(ptr(dy), ptr(wt), None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,
+                        H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci,
+                        stream_ptr()), "pd_conv2d(dgrad)")
+    return dx
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = device.index
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, dw=None, dbias=None,
+                 want_bias=False, accumulate=False):
+    """dW (channels_last [Co,Ci,kh,kw]) and optionally dbias of conv(x, w) given dy (NHWC)."""
+    _require_cuda(x, dy)
+    dy = as_nhwc(dy)
+    N, C, H, W = x.shape
+    Co, Ci, KH, KW = w_shape
+    assert Ci == C
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    if dw is None:
+        dw = torch.empty(w_shape, dtype=torch.float32, device=x.device).contiguous(memory_format=CL)
+        accumulate = False
+    assert dw.is_contiguous(memory_format=CL) or dw.numel() == dw.shape[0] * dw.shape[1]
+    if want_bias and dbias is None:
+        dbias = torch.empty(Co, dtype=torch.float32, device=x.device)
+    M, K = N * Ho * Wo, KH * KW * C
+    nbytes = lib.pd_conv2d_wgrad_workspace(M, Co, K)
+    ws = _workspace(nbytes, x.device)
+    sub, div = (affine if affine is not None else (0.0, 1.0))
+    sN, sC, sH, sW = x.stride()
+    check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), N, H, W, C,
+                              sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride, pad, mode,
+                              int(affine is not None), sub, div, dy.stride(3), int(accumulate), stream_ptr()),
+          "pd_conv2d_wgrad")
+    return (dw, dbias) if (want_bias or dbias is not None) else dw

@@ -1,0 +1,109 @@
+"""K2 (pd_conv2d / pd_conv2d_wgrad) vs a plain PyTorch fp32 CPU reference of the same op.
+
+Tolerance: fp32 MFMA accumulates like an fmaf chain in a fixed k order (exact fp32), the CPU
+reference in another order; |err| <= ~1e-6 * sum|a*b|.  Checked as rtol 2e-5 on the output scale."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from polardepth import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, tol=2e-5):
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+CASES = [
+    # N, C, H, W, Co, k, s, p, mode
+    (2, 64, 16, 20, 64, 3, 1, 1, 0),      # ResidualBlock conv
+    (2, 64, 16, 20, 64, 5, 1, 2, 0),      # Conv2 5x5
+    (1, 128, 9, 11, 256, 5, 1, 2, 0),     # joint Conv1, odd sizes, M tail
+    (2, 192, 8, 10, 256, 1, 1, 0, 0),     # fc1 1x1
+    (2, 64, 16, 20, 128, 3, 2, 1, 0),     # resnet layer2 3x3 s2
+    (2, 64, 16, 20, 128, 1, 2, 0, 0),     # resnet downsample 1x1 s2
+    (2, 2, 32, 40, 64, 7, 2, 3, 0),       # XOLP stem (scalar gather)
+    (1, 9, 32, 40, 64, 7, 2, 3, 0),       # normals stem
+    (2, 96, 16, 20, 32, 3, 1, 1, 1),      # decoder upconv(1,1), reflect
+    (2, 16, 32, 40, 16, 3, 1, 1, 1),      # decoder tail Cin=16, Cout=16
+    (2, 32, 16, 20, 1, 3, 1, 1, 1),       # dispconv Cout=1
+    (3, 512, 4, 5, 512, 3, 1, 1, 0),      # deep layer, tiny M
+]
+
+
+def _ref_conv(x, w, b, s, p, mode):
+    if mode == 1:
+        x = F.pad(x, (p, p, p, p), mode="reflect")
+        p = 0
+    return F.conv2d(x, w, b, stride=s, padding=p)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_forward_dgrad_wgrad(case):
+    N, C, H, W, Co, k, s, p, mode = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    ref = _ref_conv(xr, wr, br, s, p, mode)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    y, stats = ops.conv2d_fwd(xd, wd, b.cuda(), stride=s, pad=p, mode=mode, want_stats=True)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    _close(y.cpu(), ref.detach())
+    # BatchNorm partials: column sums / sums of squares of the output
+    tot = stats.double().sum(0).cpu()
+    rf = ref.detach().double()
+    _close(tot[:, 0], rf.sum((0, 2, 3)), 1e-5)
+    _close(tot[:, 1], (rf ** 2).sum((0, 2, 3)), 1e-5)
+
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    dw, db = ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p, mode=mode, want_bias=True)
+    _close(dw.cpu(), wr.grad)
+    _close(db.cpu(), br.grad)
+    if mode == 0:
+        dx = ops.conv2d_dgrad(dyd, wd, (H, W), stride=s, pad=p)
+        _close(dx.cpu(), xr.grad)
+
+
+def test_conv_nchw_input_with_affine_and_activations():
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(2, 3, 24, 32, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    ref = F.conv2d((x - 0.45) / 0.225, w, None, stride=2, padding=3)
+    xd = x.cuda()                                   # NCHW strides, scalar gather path
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    y = ops.conv2d_fwd(xd, wd, None, stride=2, pad=3, affine=(0.45, 0.225))
+    _close(y.cpu(), ref)
+    dy = torch.randn(ref.shape, generator=g)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d((x - 0.45) / 0.225, wr, None, stride=2, padding=3).backward(dy)
+    dw = ops.conv2d_wgrad(xd, dy.cuda(), w.shape, stride=2, pad=3, affine=(0.45, 0.225))
+    _close(dw.cpu(), wr.grad)
+    for act, fn in ((ops.ACT_RELU, F.relu), (ops.ACT_ELU, F.elu), (ops.ACT_SIGMOID, torch.sigmoid)):
+        ya = ops.conv2d_fwd(xd, wd, None, stride=2, pad=3, affine=(0.45, 0.225), act=act)
+        _close(ya.cpu(), fn(ref), 3e-5)
+
+
+def test_conv_writes_into_concat_slice_and_accumulates_wgrad():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 32, 8, 12, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    buf = torch.zeros(2, 192, 8, 12, device="cuda").contiguous(memory_format=torch.channels_last)
+    ops.conv2d_fwd(xd, wd, None, stride=1, pad=1, out=buf[:, 128:192])
+    ref = F.conv2d(x, w, None, padding=1)
+    _close(buf[:, 128:192].cpu(), ref)
+    assert buf[:, :128].abs().max().item() == 0
+    dy = torch.randn(ref.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    dw = ops.conv2d_wgrad(xd, dy, w.shape, stride=1, pad=1)
+    dw2 = ops.conv2d_wgrad(xd, dy, w.shape, stride=1, pad=1, dw=dw.clone(), accumulate=True)
+    _close(dw2.cpu(), 2 * dw.cpu(), 1e-6)
