@@ -1,0 +1,702 @@
+// K3 -- fused memory-bound kernels around the convolutions (all NHWC fp32, 16 bytes per lane):
+//   BatchNorm statistics finalisation (fp64), BN-apply + ReLU + 2x2 max-pool + dropout + residual
+//   (+ReLU) forward, and the two-pass backward of the same chain;
+//   3x3/s2 max-pool (ResNet stem), bilinear x2 upsample + skip concat (decoder), activation
+//   derivative, reflection-padding fold, fused Adam.
+// Reference ops replaced: pre_encoders.py:27-34,43-46 (ConvBlock / ResidualBlock tail),
+// torchvision BasicBlock bn/relu/add, resnet maxpool (resnet_encoder.py:813-818),
+// layers.py:446-449 upsample + depth_decoder.py:64-67 cat, trainer.py:238-240,442 Adam.
+#include "pd_common.h"
+#include <cstdint>
+
+namespace {
+
+constexpr int EW_T = 256;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+
+// ---------------------------------------------------------------- Philox4x32-10 (dropout masks)
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += W0; k.y += W1;
+    }
+    return c;
+}
+
+// keep-mask scaled by 1/(1-p) for the 4 channels of output element quad `q`
+__device__ __forceinline__ float4 dropout_scale(long q, uint64_t seed, uint64_t offset, float p) {
+    const uint4 r = philox4x32_10(make_uint4((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)offset,
+                                             (uint32_t)(offset >> 32)),
+                                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const uint32_t thr = (uint32_t)fminf(p * 4294967296.f, 4294967040.f);
+    const float s = 1.f / (1.f - p);
+    return make_float4(r.x >= thr ? s : 0.f, r.y >= thr ? s : 0.f, r.z >= thr ? s : 0.f, r.w >= thr ? s : 0.f);
+}
+
+// ---------------------------------------------------------------- column reductions for BN
+// partial [R][C][2] fp32 -> acc [C][2] fp64 (atomics; a handful per workgroup)
+__global__ __launch_bounds__(EW_T) void colsum_kernel(const float* __restrict__ part, double* __restrict__ acc,
+                                                      long R, int C, int rows_per_block) {
+    // thread -> (channel pair slot, row lane): 32 channels x 8 row lanes
+    const int cgroups = (C + 31) / 32;
+    const int cg = blockIdx.x % cgroups;
+    const long rb = (long)(blockIdx.x / cgroups) * rows_per_block;
+    const int c = cg * 32 + (threadIdx.x & 31);
+    const int rl = threadIdx.x >> 5;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C) {
+        const long rend = rb + rows_per_block < R ? rb + rows_per_block : R;
+        for (long r = rb + rl; r < rend; r += 8) {
+            const float2 v = *reinterpret_cast<const float2*>(part + (r * C + c) * 2);
+            s0 += v.x; s1 += v.y;
+        }
+    }
+    __shared__ double red[8][32][2];
+    red[rl][threadIdx.x & 31][0] = s0; red[rl][threadIdx.x & 31][1] = s1;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < C) {
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { t0 += red[i][threadIdx.x][0]; t1 += red[i][threadIdx.x][1]; }
+        atomicAdd(&acc[2 * c], t0);
+        atomicAdd(&acc[2 * c + 1], t1);
+    }
+}
+
+// training-mode statistics -> affine coefficients (+ running stats update, torch semantics)
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ rmean,
+                                       float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
+                                       float* __restrict__ smean, float* __restrict__ sinvstd, int C, double count,
+                                       float momentum, float eps, int training) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, invstd;
+    if (training) {
+        const double m = acc[2 * c] / count;
+        double var = acc[2 * c + 1] / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    } else {
+        mean = rmean[c];
+        invstd = 1.f / sqrtf(rvar[c] + eps);
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - mean * sc;
+    if (smean) { smean[c] = mean; sinvstd[c] = invstd; }
+}
+
+// backward: acc = (sum g, sum g*xhat) -> dgamma, dbeta, coef = (mean g, mean g*xhat)
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef, int C, double count,
+                                       int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double sg = acc[2 * c], sgx = acc[2 * c + 1];
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sgx;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sg;
+    coef[c] = (float)(sg / count);
+    coef[C + c] = (float)(sgx / count);
+}
+
+// ---------------------------------------------------------------- BN-apply chain
+struct ChainArgs {
+    const float* x;        // raw conv output [N,H,W,C] contiguous
+    const float* scale;    // [C] or null (identity)
+    const float* shift;
+    const float* res;      // residual on the output grid, row stride ld_res, or null
+    float* out;            // output grid [N,Ho,Wo,C], row stride ld_out
+    long ld_res, ld_out;
+    int N, H, W, C;        // input grid
+    int relu_pre, pool, relu_post;
+    float drop_p;
+    uint64_t seed, offset;
+    // backward only
+    const float* dy;       // grad of out, row stride ld_dy
+    long ld_dy;
+    const float* mean;     // saved batch mean / invstd (null in identity mode)
+    const float* invstd;
+    const float* coef;     // [2][C] (apply pass)
+    float* dx;             // [N,H,W,C] contiguous
+    float* dres;           // grad of the residual input, contiguous [N,Ho,Wo,C], or null
+    float* partial;        // [blocks][C][2]
+};
+
+__device__ __forceinline__ float4 affine4(float4 v, float4 s, float4 b) {
+    return make_float4(v.x * s.x + b.x, v.y * s.y + b.y, v.z * s.z + b.z, v.w * s.w + b.w);
+}
+__device__ __forceinline__ float4 relu4(float4 v) {
+    return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+__global__ __launch_bounds__(EW_T) void chain_fwd_kernel(const ChainArgs a) {
+    const int cq = a.C >> 2;
+    const int Ho = a.pool ? a.H >> 1 : a.H, Wo = a.pool ? a.W >> 1 : a.W;
+    const long total = (long)a.N * Ho * Wo * cq;
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        const int c4 = (int)(i % cq) * 4;
+        const long pix = i / cq;                    // output pixel index
+        const float4 s = a.scale ? ld4(a.scale + c4) : f4(1.f);
+        const float4 b = a.scale ? ld4(a.shift + c4) : f4(0.f);
+        float4 v;
+        if (a.pool) {
+            const int wo = (int)(pix % Wo);
+            const long t = pix / Wo;
+            const int ho = (int)(t % Ho);
+            const long n = t / Ho;
+            const float* p = a.x + (((n * a.H + 2 * ho) * a.W) + 2 * wo) * a.C + c4;
+            float4 v00 = affine4(ld4(p), s, b), v01 = affine4(ld4(p + a.C), s, b);
+            float4 v10 = affine4(ld4(p + (long)a.W * a.C), s, b), v11 = affine4(ld4(p + (long)a.W * a.C + a.C), s, b);
+            if (a.relu_pre) { v00 = relu4(v00); v01 = relu4(v01); v10 = relu4(v10); v11 = relu4(v11); }
+            v = max4(max4(v00, v01), max4(v10, v11));
+        } else {
+            v = affine4(ld4(a.x + pix * a.C + c4), s, b);
+            if (a.relu_pre) v = relu4(v);
+        }
+        if (a.drop_p > 0.f) v = mul4(v, dropout_scale(i, a.seed, a.offset, a.drop_p));
+        if (a.res) v = add4(v, ld4(a.res + pix * a.ld_res + c4));
+        if (a.relu_post) v = relu4(v);
+        st4(a.out + pix * a.ld_out + c4, v);
+    }
+}
+
+// gradient w.r.t. the BN output z at input pixel (n,h,w), channels c4..c4+3; also returns xhat.
+// Recomputes the forward masks from x (and `out` for the post-add ReLU).
+__device__ __forceinline__ float4 chain_grad(const ChainArgs& a, long n, int h, int w, int c4, float4 xv,
+                                             float4 s, float4 b) {
+    const int Ho = a.pool ? a.H >> 1 : a.H, Wo = a.pool ? a.W >> 1 : a.W;
+    const int ho = a.pool ? h >> 1 : h, wo = a.pool ? w >> 1 : w;
+    if (a.pool && (ho >= Ho || wo >= Wo)) return f4(0.f);   // odd trailing row/col is dropped by the pool
+    const long opix = (n * Ho + ho) * Wo + wo;
+    float4 g = ld4(a.dy + opix * a.ld_dy + c4);
+    if (a.relu_post) {
+        const float4 o = ld4(a.out + opix * a.ld_out + c4);
+        g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+    }
+    if (a.drop_p > 0.f) g = mul4(g, dropout_scale(opix * (a.C >> 2) + (c4 >> 2), a.seed, a.offset, a.drop_p));
+    float4 z = affine4(xv, s, b);
+    if (a.pool) {
+        // route to the first maximum of the 2x2 window (scan order), like torch max_pool2d
+        const float* p = a.x + (((n * a.H + 2 * ho) * a.W) + 2 * wo) * a.C + c4;
+        float4 v[4];
+        v[0] = affine4(ld4(p), s, b); v[1] = affine4(ld4(p + a.C), s, b);
+        v[2] = affine4(ld4(p + (long)a.W * a.C), s, b); v[3] = affine4(ld4(p + (long)a.W * a.C + a.C), s, b);
+        if (a.relu_pre) { v[0] = relu4(v[0]); v[1] = relu4(v[1]); v[2] = relu4(v[2]); v[3] = relu4(v[3]); }
+        const int me = ((h & 1) << 1) | (w & 1);
+        int ax = 0, ay = 0, az = 0, aw = 0;
+        float mx = v[0].x, my = v[0].y, mz = v[0].z, mw = v[0].w;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            if (v[j].x > mx) { mx = v[j].x; ax = j; }
+            if (v[j].y > my) { my = v[j].y; ay = j; }
+            if (v[j].z > mz) { mz = v[j].z; az = j; }
+            if (v[j].w > mw) { mw = v[j].w; aw = j; }
+        }
+        g = make_float4(ax == me ? g.x : 0.f, ay == me ? g.y : 0.f, az == me ? g.z : 0.f, aw == me ? g.w : 0.f);
+    }
+    if (a.relu_pre)
+        g = make_float4(z.x > 0.f ? g.x : 0.f, z.y > 0.f ? g.y : 0.f, z.z > 0.f ? g.z : 0.f, z.w > 0.f ? g.w : 0.f);
+    return g;
+}
+
+template <bool APPLY>
+__global__ __launch_bounds__(EW_T) void chain_bwd_kernel(const ChainArgs a) {
+    const int cq = a.C >> 2;
+    const long total = (long)a.N * a.H * a.W * cq;
+    float4 sg = f4(0.f), sgx = f4(0.f);
+    // 256 % cq == 0 (checked on the host): every thread keeps its channel quad across the loop
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        const int c4 = (int)(i % cq) * 4;
+        const long pix = i / cq;
+        const int w = (int)(pix % a.W);
+        const long t = pix / a.W;
+        const int h = (int)(t % a.H);
+        const long n = t / a.H;
+        const float4 s = a.scale ? ld4(a.scale + c4) : f4(1.f);
+        const float4 b = a.scale ? ld4(a.shift + c4) : f4(0.f);
+        const float4 xv = ld4(a.x + pix * a.C + c4);
+        const float4 g = chain_grad(a, n, h, w, c4, xv, s, b);
+        float4 xh = f4(0.f);
+        if (a.mean) {
+            const float4 m = ld4(a.mean + c4), is = ld4(a.invstd + c4);
+            xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
+        }
+        if (!APPLY) {
+            sg = add4(sg, g);
+            sgx = add4(sgx, mul4(g, xh));
+        } else {
+            float4 d;
+            if (a.mean) {
+                const float4 c1 = ld4(a.coef + c4), c2 = ld4(a.coef + a.C + c4);
+                d = make_float4(s.x * (g.x - c1.x - xh.x * c2.x), s.y * (g.y - c1.y - xh.y * c2.y),
+                                s.z * (g.z - c1.z - xh.z * c2.z), s.w * (g.w - c1.w - xh.w * c2.w));
+            } else {
+                d = mul4(g, s);
+            }
+            st4(a.dx + pix * a.C + c4, d);
+        }
+    }
+    if (!APPLY) {
+        __shared__ float red[EW_T][8];
+        float* r = red[threadIdx.x];
+        r[0] = sg.x; r[1] = sg.y; r[2] = sg.z; r[3] = sg.w; r[4] = sgx.x; r[5] = sgx.y; r[6] = sgx.z; r[7] = sgx.w;
+        __syncthreads();
+        // threads t, t+cq, t+2cq ... share a channel quad
+        if ((int)threadIdx.x < cq) {
+            float acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = threadIdx.x; t < EW_T; t += cq)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] += red[t][j];
+            float* o = a.partial + ((long)blockIdx.x * a.C + 4 * threadIdx.x) * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[2 * j] = acc8[j]; o[2 * j + 1] = acc8[4 + j]; }
+        }
+    }
+}
+
+// grad of the residual input of a post-add ReLU block: dres = dy * (out > 0)
+__global__ __launch_bounds__(EW_T) void relu_mask_kernel(const float* __restrict__ dy, long ld_dy,
+                                                         const float* __restrict__ out, long ld_out,
+                                                         float* __restrict__ d, long npix, int C) {
+    const int cq = C >> 2;
+    const long total = npix * cq;
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        const int c4 = (int)(i % cq) * 4;
+        const long pix = i / cq;
+        const float4 g = ld4(dy + pix * ld_dy + c4), o = ld4(out + pix * ld_out + c4);
+        st4(d + pix * C + c4, make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f,
+                                          o.w > 0.f ? g.w : 0.f));
+    }
+}
+
+// ---------------------------------------------------------------- 3x3 stride-2 pad-1 max pool
+__global__ __launch_bounds__(EW_T) void maxpool3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int N, int H, int W, int C, int Ho, int Wo) {
+    const int cq = C >> 2;
+    const long total = (long)N * Ho * Wo * cq;
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        const int c4 = (int)(i % cq) * 4;
+        long pix = i / cq;
+        const int wo = (int)(pix % Wo); pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const long n = pix / Ho;
+        float4 m = f4(-INFINITY);
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int h = 2 * ho - 1 + dh;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int w = 2 * wo - 1 + dw;
+                if (w < 0 || w >= W) continue;
+                m = max4(m, ld4(x + ((n * H + h) * W + w) * C + c4));
+            }
+        }
+        st4(y + i * 4, m);
+    }
+}
+
+__global__ __launch_bounds__(EW_T) void maxpool3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                                            int Wo) {
+    const int cq = C >> 2;
+    const long total = (long)N * H * W * cq;
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        const int c4 = (int)(i % cq) * 4;
+        long pix = i / cq;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H);
+        const long n = pix / H;
+        float4 acc = f4(0.f);
+        // windows (ho,wo) with 2*ho-1 <= h <= 2*ho+1
+        for (int ho = (h) >> 1; ho <= (h + 1) >> 1; ++ho) {
+            if (ho < 0 || ho >= Ho) continue;
+            for (int wo = (w) >> 1; wo <= (w + 1) >> 1; ++wo) {
+                if (wo < 0 || wo >= Wo) continue;
+                // first maximum of the window in scan order (torch max_pool2d_with_indices)
+                float mv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int mi[4] = {-1, -1, -1, -1};
+                for (int dh = 0; dh < 3; ++dh) {
+                    const int hh = 2 * ho - 1 + dh;
+                    if (hh < 0 || hh >= H) continue;
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int ww = 2 * wo - 1 + dw;
+                        if (ww < 0 || ww >= W) continue;
+                        const float4 v = ld4(x + ((n * H + hh) * W + ww) * C + c4);
+                        const int id = hh * W + ww;
+                        if (v.x > mv[0]) { mv[0] = v.x; mi[0] = id; }
+                        if (v.y > mv[1]) { mv[1] = v.y; mi[1] = id; }
+                        if (v.z > mv[2]) { mv[2] = v.z; mi[2] = id; }
+                        if (v.w > mv[3]) { mv[3] = v.w; mi[3] = id; }
+                    }
+                }
+                const float4 g = ld4(dy + ((n * Ho + ho) * Wo + wo) * C + c4);
+                const int me = h * W + w;
+                acc.x += mi[0] == me ? g.x : 0.f; acc.y += mi[1] == me ? g.y : 0.f;
+                acc.z += mi[2] == me ? g.z : 0.f; acc.w += mi[3] == me ? g.w : 0.f;
+            }
+        }
+        st4(dx + i * 4, acc);
+    }
+}
+
+// ---------------------------------------------------------------- bilinear x2 upsample (+ concat)
+// out[n, y, x, 0:Ca] = bilinear(a)[n, y, x]  (align_corners=False, scale 2), out[..., Ca:Ca+Cs] = skip
+__global__ __launch_bounds__(EW_T) void upcat_fwd_kernel(const float* __restrict__ a, const float* __restrict__ skip,
+                                                         long ld_skip, float* __restrict__ out, int N, int H, int W,
+                                                         int Ca, int Cs) {
+    const int Ct = Ca + Cs, cq = Ct >> 2;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)N * Ho * Wo * cq;
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        const int c4 = (int)(i % cq) * 4;
+        long pix = i / cq;
+        const long opix = pix;
+        const int x = (int)(pix % Wo); pix /= Wo;
+        const int y = (int)(pix % Ho);
+        const long n = pix / Ho;
+        float4 v;
+        if (c4 < Ca) {
+            // torch: src = max(0, 0.5*(dst+0.5)-0.5); i0 = floor(src); i1 = min(i0+1, size-1); l1 = src-i0
+            const float sy = fmaxf(0.5f * (y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (x + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+            const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const float* b = a + n * H * W * Ca + c4;
+            const float4 v00 = ld4(b + ((long)y0 * W + x0) * Ca), v01 = ld4(b + ((long)y0 * W + x1) * Ca);
+            const float4 v10 = ld4(b + ((long)y1 * W + x0) * Ca), v11 = ld4(b + ((long)y1 * W + x1) * Ca);
+            v = make_float4(ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x),
+                            ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y),
+                            ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z),
+                            ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w));
+        } else {
+            v = ld4(skip + opix * ld_skip + (c4 - Ca));
+        }
+        st4(out + opix * Ct + c4, v);
+    }
+}
+
+// da[n,h,w,:] = sum over the (up to 4x4) output pixels that read a[h,w], times their bilinear weights
+__global__ __launch_bounds__(EW_T) void up_bwd_kernel(const float* __restrict__ dout, long ld_d,
+                                                      float* __restrict__ da, int N, int H, int W, int Ca) {
+    const int cq = Ca >> 2;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)N * H * W * cq;
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        const int c4 = (int)(i % cq) * 4;
+        long pix = i / cq;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H);
+        const long n = pix / H;
+        float4 acc = f4(0.f);
+        for (int y = 2 * h - 2; y <= 2 * h + 2; ++y) {
+            if (y < 0 || y >= Ho) continue;
+            const float sy = fmaxf(0.5f * (y + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
+            const float ly1 = sy - y0;
+            const float wy = (y0 == h ? 1.f - ly1 : 0.f) + (y1 == h ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int x = 2 * w - 2; x <= 2 * w + 2; ++x) {
+                if (x < 0 || x >= Wo) continue;
+                const float sx = fmaxf(0.5f * (x + 0.5f) - 0.5f, 0.f);
+                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+                const float lx1 = sx - x0;
+                const float wx = (x0 == w ? 1.f - lx1 : 0.f) + (x1 == w ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                const float4 g = ld4(dout + ((n * Ho + y) * (long)Wo + x) * ld_d + c4);
+                const float ww = wy * wx;
+                acc.x += ww * g.x; acc.y += ww * g.y; acc.z += ww * g.z; acc.w += ww * g.w;
+            }
+        }
+        st4(da + i * 4, acc);
+    }
+}
+
+// ---------------------------------------------------------------- activation derivative
+// dz = dy * f'(.) expressed through the activation OUTPUT y.  act: 1 ReLU, 2 ELU, 3 sigmoid
+__global__ __launch_bounds__(EW_T) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ dz, long n, int act) {
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < n; i += (long)gridDim.x * EW_T) {
+        const float g = dy[i], o = y[i];
+        float d;
+        if (act == 1) d = o > 0.f ? g : 0.f;
+        else if (act == 2) d = o > 0.f ? g : g * (o + 1.f);
+        else d = g * o * (1.f - o);
+        dz[i] = d;
+    }
+}
+
+// ---------------------------------------------------------------- reflection-pad fold
+// dxp [N,H+2,W+2,C] (gradient on the padded grid, pad 1) -> dx [N,H,W,C]
+__global__ __launch_bounds__(EW_T) void reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx,
+                                                            int N, int H, int W, int C) {
+    const long total = (long)N * H * W * C;
+    const int Hp = H + 2, Wp = W + 2;
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        const int c = (int)(i % C);
+        long pix = i / C;
+        const int w = (int)(pix % W); pix /= W;
+        const int h = (int)(pix % H);
+        const long n = pix / H;
+        // padded rows that map to h: h+1 always; 0 if h == 1; Hp-1 if h == H-2
+        int hs[3], ws[3], nh = 0, nw = 0;
+        hs[nh++] = h + 1; if (h == 1) hs[nh++] = 0; if (h == H - 2) hs[nh++] = Hp - 1;
+        ws[nw++] = w + 1; if (w == 1) ws[nw++] = 0; if (w == W - 2) ws[nw++] = Wp - 1;
+        float acc = 0.f;
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) acc += dxp[((n * Hp + hs[a]) * Wp + ws[b]) * C + c];
+        dx[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- fused Adam over a flat buffer
+__global__ __launch_bounds__(EW_T) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, float grad_scale) {
+    for (long i = (blockIdx.x * (long)EW_T + threadIdx.x) * 4; i < n; i += (long)gridDim.x * EW_T * 4) {
+        if (i + 3 < n) {
+            float4 pp = ld4(p + i), gg = ld4(g + i), mm = ld4(m + i), vv = ld4(v + i);
+            float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float gr = G[j] * grad_scale + wd * P[j];
+                M[j] = beta1 * M[j] + (1.f - beta1) * gr;
+                V[j] = beta2 * V[j] + (1.f - beta2) * gr * gr;
+                // torch.optim.Adam: p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+                P[j] -= (lr / bc1) * (M[j] / (sqrtf(V[j]) / bc2_sqrt + eps));
+            }
+            st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
+        } else {
+            for (long j = i; j < n; ++j) {
+                float gr = g[j] * grad_scale + wd * p[j];
+                m[j] = beta1 * m[j] + (1.f - beta1) * gr;
+                v[j] = beta2 * v[j] + (1.f - beta2) * gr * gr;
+                p[j] -= (lr / bc1) * (m[j] / (sqrtf(v[j]) / bc2_sqrt + eps));
+            }
+        }
+    }
+}
+
+inline unsigned ew_grid(long work_items) {
+    long b = (work_items + EW_T - 1) / EW_T;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" int pd_bn_fwd_finalize(const void* partial, long R, int C, double count, const void* gamma,
+                                  const void* beta, void* running_mean, void* running_var, float momentum, float eps,
+                                  void* acc_ws, void* scale, void* shift, void* save_mean, void* save_invstd,
+                                  int training, void* stream) {
+    PD_REQUIRE(C > 0 && scale && shift, "pd_bn_fwd_finalize: bad arguments");
+    PD_REQUIRE(!training || (partial && acc_ws && R > 0 && count > 0), "pd_bn_fwd_finalize: training needs partials");
+    PD_REQUIRE(training || (running_mean && running_var), "pd_bn_fwd_finalize: eval needs running stats");
+    hipStream_t st = (hipStream_t)stream;
+    if (training) {
+        if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * C, st) != hipSuccess)
+            return pd::fail(PD_ELAUNCH, "pd_bn_fwd_finalize: memset failed");
+        const int cgroups = (C + 31) / 32;
+        const int rpb = 256;
+        const long rblocks = (R + rpb - 1) / rpb;
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(cgroups * rblocks)), dim3(EW_T), 0, st,
+                           (const float*)partial, (double*)acc_ws, R, C, rpb);
+    }
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, (const double*)acc_ws,
+                       (const float*)gamma, (const float*)beta, (float*)running_mean, (float*)running_var,
+                       (float*)scale, (float*)shift, (float*)save_mean, (float*)save_invstd, C, count, momentum, eps,
+                       training);
+    return pd::check_launch("pd_bn_fwd_finalize");
+}
+
+extern "C" int pd_bn_bwd_finalize(const void* partial, long R, int C, double count, void* acc_ws, void* dgamma,
+                                  void* dbeta, void* coef, int accumulate, void* stream) {
+    PD_REQUIRE(partial && acc_ws && coef && C > 0 && R > 0 && count > 0, "pd_bn_bwd_finalize: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * C, st) != hipSuccess)
+        return pd::fail(PD_ELAUNCH, "pd_bn_bwd_finalize: memset failed");
+    const int cgroups = (C + 31) / 32;
+    const int rpb = 256;
+    const long rblocks = (R + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(cgroups * rblocks)), dim3(EW_T), 0, st, (const float*)partial,
+                       (double*)acc_ws, R, C, rpb);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, (const double*)acc_ws,
+                       (float*)dgamma, (float*)dbeta, (float*)coef, C, count, accumulate);
+    return pd::check_launch("pd_bn_bwd_finalize");
+}
+
+static int chain_check(int N, int H, int W, int C, int pool) {
+    PD_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_chain: bad dims (C must be a multiple of 4)");
+    PD_REQUIRE(!pool || (H >= 2 && W >= 2), "pd_chain: pooling needs H,W >= 2");
+    return PD_OK;
+}
+
+extern "C" long pd_chain_bwd_rows(int N, int H, int W, int C) {
+    const long items = (long)N * H * W * (C / 4);
+    long b = (items + EW_T - 1) / EW_T;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return b;
+}
+
+extern "C" int pd_chain_fwd(const void* x, const void* scale, const void* shift, const void* res, void* out,
+                            int N, int H, int W, int C, long ld_res, long ld_out, int relu_pre, int pool,
+                            float drop_p, uint64_t seed, uint64_t offset, int relu_post, void* stream) {
+    int rc = chain_check(N, H, W, C, pool);
+    if (rc) return rc;
+    PD_REQUIRE(x && out && (!scale || shift), "pd_chain_fwd: null tensor");
+    PD_REQUIRE(ld_out >= C && ld_out % 4 == 0 && (!res || (ld_res >= C && ld_res % 4 == 0)), "pd_chain_fwd: bad row stride");
+    PD_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "pd_chain_fwd: dropout p must be in [0,1)");
+    if (N == 0) return PD_OK;
+    ChainArgs a{};
+    a.x = (const float*)x; a.scale = (const float*)scale; a.shift = (const float*)shift; a.res = (const float*)res;
+    a.out = (float*)out; a.ld_res = ld_res; a.ld_out = ld_out; a.N = N; a.H = H; a.W = W; a.C = C;
+    a.relu_pre = relu_pre; a.pool = pool; a.relu_post = relu_post; a.drop_p = drop_p; a.seed = seed; a.offset = offset;
+    const long items = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / 4);
+    hipLaunchKernelGGL(chain_fwd_kernel, dim3(ew_grid(items)), dim3(EW_T), 0, (hipStream_t)stream, a);
+    return pd::check_launch("pd_chain_fwd");
+}
+
+static int chain_bwd_common(ChainArgs& a, const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
+                            const void* scale, const void* shift, const void* mean, const void* invstd, int N, int H,
+                            int W, int C, int relu_pre, int pool, float drop_p, uint64_t seed, uint64_t offset,
+                            int relu_post) {
+    int rc = chain_check(N, H, W, C, pool);
+    if (rc) return rc;
+    PD_REQUIRE(dy && x && (!relu_post || out) && (!scale || shift) && (!mean || invstd), "pd_chain_bwd: null tensor");
+    PD_REQUIRE(ld_dy >= C && ld_dy % 4 == 0 && (!relu_post || (ld_out >= C && ld_out % 4 == 0)), "pd_chain_bwd: bad row stride");
+    a.dy = (const float*)dy; a.ld_dy = ld_dy; a.x = (const float*)x; a.out = (float*)out; a.ld_out = ld_out;
+    a.scale = (const float*)scale; a.shift = (const float*)shift; a.mean = (const float*)mean; a.invstd = (const float*)invstd;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.relu_pre = relu_pre; a.pool = pool; a.relu_post = relu_post;
+    a.drop_p = drop_p; a.seed = seed; a.offset = offset;
+    return PD_OK;
+}
+
+extern "C" int pd_chain_bwd_reduce(const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
+                                   const void* scale, const void* shift, const void* mean, const void* invstd,
+                                   void* partial, int N, int H, int W, int C, int relu_pre, int pool, float drop_p,
+                                   uint64_t seed, uint64_t offset, int relu_post, void* stream) {
+    ChainArgs a{};
+    int rc = chain_bwd_common(a, dy, ld_dy, x, out, ld_out, scale, shift, mean, invstd, N, H, W, C, relu_pre, pool,
+                              drop_p, seed, offset, relu_post);
+    if (rc) return rc;
+    PD_REQUIRE(partial && mean, "pd_chain_bwd_reduce: partial and mean/invstd are required");
+    PD_REQUIRE(EW_T % (C / 4) == 0, "pd_chain_bwd_reduce: C/4 must divide 256");
+    if (N == 0) return PD_OK;
+    a.partial = (float*)partial;
+    hipLaunchKernelGGL(chain_bwd_kernel<false>, dim3((unsigned)pd_chain_bwd_rows(N, H, W, C)), dim3(EW_T), 0,
+                       (hipStream_t)stream, a);
+    return pd::check_launch("pd_chain_bwd_reduce");
+}
+
+extern "C" int pd_chain_bwd_apply(const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
+                                  const void* scale, const void* shift, const void* mean, const void* invstd,
+                                  const void* coef, void* dx, void* dres, int N, int H, int W, int C, int relu_pre,
+                                  int pool, float drop_p, uint64_t seed, uint64_t offset, int relu_post, void* stream) {
+    ChainArgs a{};
+    int rc = chain_bwd_common(a, dy, ld_dy, x, out, ld_out, scale, shift, mean, invstd, N, H, W, C, relu_pre, pool,
+                              drop_p, seed, offset, relu_post);
+    if (rc) return rc;
+    PD_REQUIRE(dx && (!mean || coef), "pd_chain_bwd_apply: dx (and coef with batch statistics) required");
+    PD_REQUIRE(!dres || relu_post, "pd_chain_bwd_apply: dres is only produced for post-add ReLU blocks");
+    if (N == 0) return PD_OK;
+    a.coef = (const float*)coef; a.dx = (float*)dx;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(chain_bwd_kernel<true>, dim3((unsigned)pd_chain_bwd_rows(N, H, W, C)), dim3(EW_T), 0, st, a);
+    if (dres) {
+        const long npix = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+        hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(npix * (C / 4))), dim3(EW_T), 0, st, (const float*)dy, ld_dy,
+                           (const float*)out, ld_out, (float*)dres, npix, C);
+    }
+    return pd::check_launch("pd_chain_bwd_apply");
+}
+
+extern "C" int pd_maxpool3s2_fwd(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    PD_REQUIRE(x && y && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_maxpool3s2_fwd: bad arguments");
+    if (N == 0) return PD_OK;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * (C / 4))), dim3(EW_T), 0,
+                       (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, Ho, Wo);
+    return pd::check_launch("pd_maxpool3s2_fwd");
+}
+
+extern "C" int pd_maxpool3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+    PD_REQUIRE(x && dy && dx && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_maxpool3s2_bwd: bad arguments");
+    if (N == 0) return PD_OK;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(EW_T), 0,
+                       (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo);
+    return pd::check_launch("pd_maxpool3s2_bwd");
+}
+
+extern "C" int pd_upcat_fwd(const void* a, const void* skip, long ld_skip, void* out, int N, int H, int W, int Ca,
+                            int Cs, void* stream) {
+    PD_REQUIRE(a && out && N >= 0 && H > 0 && W > 0 && Ca > 0 && Ca % 4 == 0 && Cs >= 0 && Cs % 4 == 0,
+               "pd_upcat_fwd: bad arguments");
+    PD_REQUIRE(Cs == 0 || (skip && ld_skip >= Cs && ld_skip % 4 == 0), "pd_upcat_fwd: bad skip tensor");
+    if (N == 0) return PD_OK;
+    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(ew_grid((long)N * 4 * H * W * ((Ca + Cs) / 4))), dim3(EW_T), 0,
+                       (hipStream_t)stream, (const float*)a, (const float*)skip, ld_skip, (float*)out, N, H, W, Ca, Cs);
+    return pd::check_launch("pd_upcat_fwd");
+}
+
+extern "C" int pd_up_bwd(const void* dout, long ld_d, void* da, int N, int H, int W, int Ca, void* stream) {
+    PD_REQUIRE(dout && da && N >= 0 && H > 0 && W > 0 && Ca > 0 && Ca % 4 == 0 && ld_d >= Ca && ld_d % 4 == 0,
+               "pd_up_bwd: bad arguments");
+    if (N == 0) return PD_OK;
+    hipLaunchKernelGGL(up_bwd_kernel, dim3(ew_grid((long)N * H * W * (Ca / 4))), dim3(EW_T), 0, (hipStream_t)stream,
+                       (const float*)dout, ld_d, (float*)da, N, H, W, Ca);
+    return pd::check_launch("pd_up_bwd");
+}
+
+extern "C" int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int act, void* stream) {
+    PD_REQUIRE(dy && y && dz && n >= 0 && act >= 1 && act <= 3, "pd_act_bwd: bad arguments");
+    if (n == 0) return PD_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(EW_T), 0, (hipStream_t)stream, (const float*)dy,
+                       (const float*)y, (float*)dz, n, act);
+    return pd::check_launch("pd_act_bwd");
+}
+
+extern "C" int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, int C, void* stream) {
+    PD_REQUIRE(dxp && dx && N >= 0 && H >= 2 && W >= 2 && C > 0, "pd_reflect_fold: bad arguments");
+    if (N == 0) return PD_OK;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3(ew_grid((long)N * H * W * C)), dim3(EW_T), 0, (hipStream_t)stream,
+                       (const float*)dxp, (float*)dx, N, H, W, C);
+    return pd::check_launch("pd_reflect_fold");
+}
+
+extern "C" int pd_adam_step(void* p, const void* g, void* m, void* v, long n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, long step, float grad_scale, void* stream) {
+    PD_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "pd_adam_step: bad arguments");
+    PD_REQUIRE(pd::aligned16(p) && pd::aligned16(g) && pd::aligned16(m) && pd::aligned16(v), "pd_adam_step: unaligned");
+    if (n == 0) return PD_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid((n + 3) / 4)), dim3(EW_T), 0, (hipStream_t)stream, (float*)p,
+                       (const float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
+                       grad_scale);
+    return pd::check_launch("pd_adam_step");
+}

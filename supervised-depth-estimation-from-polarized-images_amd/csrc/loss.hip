@@ -1,0 +1,519 @@
+// K5 -- multi-scale supervised loss (forward + analytic backward), wavefront-reduced.
+//
+// Reference restated (per scale s of opt.scales):
+//   trainer.py:538-543   disp_s -> F.interpolate(H x W, bilinear, align_corners=False) -> disp_to_depth
+//   layers.py:62-71      disp_to_depth
+//   trainer.py:1241-1251 mask = (gt >= min) & (gt <= max);  L1 = sum|gt - depth|*mask / sum(mask)
+//   trainer.py:1298-1309 LN = sum((2 - cos(n_gt, n_pred)) * mask) / sum(mask), normals via
+//                        kornia.geometry.depth.depth_to_normals (kornia 0.5.11: unproject with K,
+//                        Sobel/8 with replicate padding, cross product, L2 normalise)
+//   trainer.py:1256-1260 + layers.py:452-465  edge-aware smoothness of the mean-normalised disparity
+//   trainer.py:1262-1265 loss_s = L1 + w_N * LN + w_sm * smooth / 2^s ;  loss = sum_s loss_s / S
+// All sums are reduced per wavefront (shuffles), then per workgroup, written as fp32 partials and
+// finished in fp64 by a one-block kernel -- no float atomics, run-to-run deterministic.
+#include "pd_common.h"
+
+namespace {
+
+constexpr int LT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum of K values; result valid in thread 0
+template <int K>
+__device__ __forceinline__ void block_sum(float (&v)[K], float* smem /* [4][K] */) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) smem[wave * K + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = smem[k] + smem[K + k] + smem[2 * K + k] + smem[3 * K + k];
+}
+
+inline unsigned lgrid(long n) {
+    long b = (n + LT - 1) / LT;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// torch upsample_bilinear2d source index (align_corners=False)
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    const float s = fmaxf(scale * (dst + 0.5f) - 0.5f, 0.f);
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1);
+    l1 = s - i0;
+}
+
+// ------------------------------------------------------------------ disp -> full-res depth
+__global__ __launch_bounds__(LT) void disp_to_depth_kernel(const float* __restrict__ disp, float* __restrict__ depth,
+                                                           float* __restrict__ updisp, int N, int hs, int ws, int H,
+                                                           int W, float min_disp, float max_disp) {
+    const long total = (long)N * H * W;
+    const float sh = (float)hs / H, sw = (float)ws / W;
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const long n = t / H;
+        int y0, y1, x0, x1; float ly1, lx1;
+        src_index(y, sh, hs, y0, y1, ly1);
+        src_index(x, sw, ws, x0, x1, lx1);
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* d = disp + n * hs * ws;
+        const float up = ly0 * (lx0 * d[y0 * ws + x0] + lx1 * d[y0 * ws + x1]) +
+                         ly1 * (lx0 * d[y1 * ws + x0] + lx1 * d[y1 * ws + x1]);
+        const float scaled = min_disp + (max_disp - min_disp) * up;
+        depth[i] = 1.f / scaled;
+        if (updisp) updisp[i] = up;
+    }
+}
+
+// d(disp_s) = bilinear^T( g_up ), gather form: every low-res pixel sums its footprint
+__global__ __launch_bounds__(LT) void up_gather_bwd_kernel(const float* __restrict__ gup, float* __restrict__ gdisp,
+                                                           int N, int hs, int ws, int H, int W, int accumulate) {
+    const long total = (long)N * hs * ws;
+    const float sh = (float)hs / H, sw = (float)ws / W;
+    const int fh = H / hs, fw = W / ws;   // integer zoom factors (checked on the host)
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const int xs = (int)(i % ws);
+        const long t = i / ws;
+        const int ys = (int)(t % hs);
+        const long n = t / hs;
+        float acc = 0.f;
+        const int ylo = max(0, (ys - 1) * fh), yhi = min(H - 1, (ys + 2) * fh - 1);
+        const int xlo = max(0, (xs - 1) * fw), xhi = min(W - 1, (xs + 2) * fw - 1);
+        for (int y = ylo; y <= yhi; ++y) {
+            int y0, y1; float ly1;
+            src_index(y, sh, hs, y0, y1, ly1);
+            const float wy = (y0 == ys ? 1.f - ly1 : 0.f) + (y1 == ys ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            const float* g = gup + (n * H + y) * (long)W;
+            for (int x = xlo; x <= xhi; ++x) {
+                int x0, x1; float lx1;
+                src_index(x, sw, ws, x0, x1, lx1);
+                const float wx = (x0 == xs ? 1.f - lx1 : 0.f) + (x1 == xs ? lx1 : 0.f);
+                if (wx != 0.f) acc += wy * wx * g[x];
+            }
+        }
+        gdisp[i] = accumulate ? gdisp[i] + acc : acc;
+    }
+}
+
+// ------------------------------------------------------------------ supervised depth + normals terms
+struct Cam { float fx, fy, cx, cy; };
+__device__ __forceinline__ Cam load_cam(const float* K, long n) {
+    const float* k = K + n * 16;  // [4][4]
+    return Cam{k[0], k[5], k[2], k[6]};
+}
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// Sobel/8 gradients of the unprojected points around (x,y) with replicate padding
+__device__ __forceinline__ void sobel_xyz(const float* __restrict__ D, int H, int W, int x, int y, Cam c, V3& A, V3& B) {
+    A = V3{0, 0, 0}; B = V3{0, 0, 0};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = min(max(y + dy, 0), H - 1);
+        const float sy = dy == 0 ? 2.f : 1.f, ddy = (float)dy;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = min(max(x + dx, 0), W - 1);
+            const float sx = dx == 0 ? 2.f : 1.f, ddx = (float)dx;
+            const float d = D[(long)yy * W + xx];
+            const float X = (xx - c.cx) / c.fx * d, Y = (yy - c.cy) / c.fy * d;
+            const float kx = sy * ddx * 0.125f, ky = ddy * sx * 0.125f;
+            A.x += kx * X; A.y += kx * Y; A.z += kx * d;
+            B.x += ky * X; B.y += ky * Y; B.z += ky * d;
+        }
+    }
+}
+
+__device__ __forceinline__ V3 normalize12(V3 v, float& nv) {
+    nv = sqrtf(dot(v, v));
+    const float inv = 1.f / fmaxf(nv, 1e-12f);
+    return V3{v.x * inv, v.y * inv, v.z * inv};
+}
+
+// partial[block][3] = (sum |gt - d| m, sum (2 - cos) m, sum m)
+__global__ __launch_bounds__(LT) void sup_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                     const float* __restrict__ K, float* __restrict__ partial, int N,
+                                                     int H, int W, float min_d, float max_d, int with_normals) {
+    __shared__ float sm[4 * 3];
+    const long total = (long)N * H * W;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const long n = t / H;
+        const float g = gt[i];
+        const float m = (g >= min_d && g <= max_d) ? 1.f : 0.f;
+        if (m == 0.f) continue;   // every term is multiplied by the mask
+        acc[0] += fabsf(g - pred[i]);
+        acc[2] += 1.f;
+        if (with_normals) {
+            const Cam c = load_cam(K, n);
+            V3 A, B; float nv;
+            sobel_xyz(pred + n * H * W, H, W, x, y, c, A, B);
+            const V3 np_ = normalize12(cross(A, B), nv);
+            sobel_xyz(gt + n * H * W, H, W, x, y, c, A, B);
+            const V3 ng = normalize12(cross(A, B), nv);
+            const float n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f), n2 = fmaxf(sqrtf(dot(np_, np_)), 1e-8f);
+            const float cs = (ng.x / n1) * (np_.x / n2) + (ng.y / n1) * (np_.y / n2) + (ng.z / n1) * (np_.z / n2);
+            acc[1] += 2.f - cs;
+        }
+    }
+    block_sum<3>(acc, sm);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 3] = acc[0]; partial[blockIdx.x * 3 + 1] = acc[1]; partial[blockIdx.x * 3 + 2] = acc[2]; }
+}
+
+// pass A: per pixel p, (dL/dA_p, dL/dB_p) of the normals term  -> ab [N,H,W,6]
+// wts = (w_L1, w_LN, w_sm) for this scale (device), sums = (.., .., sum mask) of the forward
+__global__ __launch_bounds__(LT) void sup_bwd_a_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                       const float* __restrict__ K, const float* __restrict__ wts,
+                                                       const double* __restrict__ sums, float* __restrict__ ab, int N,
+                                                       int H, int W, float min_d, float max_d) {
+    const long total = (long)N * H * W;
+    const float wln = (float)((double)wts[1] / sums[2]);
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const long n = t / H;
+        const float g = gt[i];
+        V3 dA{0, 0, 0}, dB{0, 0, 0};
+        if (g >= min_d && g <= max_d) {
+            const Cam c = load_cam(K, n);
+            V3 A, B, Ag, Bg; float nv, nvg;
+            sobel_xyz(pred + n * H * W, H, W, x, y, c, A, B);
+            const V3 v = cross(A, B);
+            const V3 nn = normalize12(v, nv);
+            sobel_xyz(gt + n * H * W, H, W, x, y, c, Ag, Bg);
+            const V3 ng = normalize12(cross(Ag, Bg), nvg);
+            const float n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f);
+            const V3 gh{ng.x / n1, ng.y / n1, ng.z / n1};
+            // cos = gh . (nn / max(|nn|, eps));  loss = -wln * cos (+ const)
+            const float nl = sqrtf(dot(nn, nn));
+            V3 wn;   // dL/d nn
+            if (nl > 1e-8f) {
+                const float inv = 1.f / nl, pr = dot(gh, nn) * inv * inv * inv;
+                wn = V3{-wln * (gh.x * inv - pr * nn.x), -wln * (gh.y * inv - pr * nn.y), -wln * (gh.z * inv - pr * nn.z)};
+            } else {
+                wn = V3{-wln * gh.x * 1e8f, -wln * gh.y * 1e8f, -wln * gh.z * 1e8f};
+            }
+            V3 wv;   // dL/d v, v -> nn = v / max(|v|, 1e-12)
+            if (nv > 1e-12f) {
+                const float inv = 1.f / nv, pr = dot(wn, nn);
+                wv = V3{(wn.x - pr * nn.x) * inv, (wn.y - pr * nn.y) * inv, (wn.z - pr * nn.z) * inv};
+            } else {
+                wv = V3{wn.x * 1e12f, wn.y * 1e12f, wn.z * 1e12f};
+            }
+            dA = cross(B, wv);   // d(A x B).w / dA = B x w
+            dB = cross(wv, A);   // d(A x B).w / dB = w x A
+        }
+        float* o = ab + i * 6;
+        o[0] = dA.x; o[1] = dA.y; o[2] = dA.z; o[3] = dB.x; o[4] = dB.y; o[5] = dB.z;
+    }
+}
+
+// separable replicate-padding weights: sum of taps delta in {-1,0,1} of p that land on q
+__device__ __forceinline__ void tap_weights(int q, int p, int n, float& wd, float& ws) {
+    wd = 0.f; ws = 0.f;
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {
+        const int t = min(max(p + d, 0), n - 1);
+        if (t == q) { wd += (float)d; ws += d == 0 ? 2.f : 1.f; }
+    }
+}
+
+// pass B: d loss / d depth(q) = L1 term + r(q) . sum_p (...), then through depth = 1/(a + b*up)
+__global__ __launch_bounds__(LT) void sup_bwd_b_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                       const float* __restrict__ K, const float* __restrict__ wts,
+                                                       const double* __restrict__ sums, const float* __restrict__ ab,
+                                                       float* __restrict__ gout, int N, int H, int W, float min_d,
+                                                       float max_d, float disp_range, int with_normals, int to_disp) {
+    const long total = (long)N * H * W;
+    const float wl1 = (float)((double)wts[0] / sums[2]);
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const long n = t / H;
+        const float g = gt[i], d = pred[i];
+        float gd = 0.f;
+        if (g >= min_d && g <= max_d) gd = wl1 * (d > g ? 1.f : (d < g ? -1.f : 0.f));
+        if (with_normals) {
+            const Cam c = load_cam(K, n);
+            V3 s{0, 0, 0};
+            for (int py = max(y - 1, 0); py <= min(y + 1, H - 1); ++py) {
+                float dyw, syw;
+                tap_weights(y, py, H, dyw, syw);
+                for (int px = max(x - 1, 0); px <= min(x + 1, W - 1); ++px) {
+                    float dxw, sxw;
+                    tap_weights(x, px, W, dxw, sxw);
+                    const float ka = syw * dxw * 0.125f, kb = dyw * sxw * 0.125f;
+                    const float* o = ab + ((n * H + py) * (long)W + px) * 6;
+                    s.x += ka * o[0] + kb * o[3]; s.y += ka * o[1] + kb * o[4]; s.z += ka * o[2] + kb * o[5];
+                }
+            }
+            gd += (x - c.cx) / c.fx * s.x + (y - c.cy) / c.fy * s.y + s.z;
+        }
+        // depth = 1 / (min_disp + range * up)  ->  d depth / d up = -range * depth^2
+        gout[i] = to_disp ? gd * (-disp_range * d * d) : gd;
+    }
+}
+
+// ------------------------------------------------------------------ edge-aware smoothness
+__global__ __launch_bounds__(1024) void image_mean_kernel(const float* __restrict__ disp, float* __restrict__ mean, int P) {
+    __shared__ double sm[16];
+    const float* d = disp + (long)blockIdx.x * P;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < P; i += 1024) s += d[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += sm[i];
+        mean[blockIdx.x] = (float)(t / P);
+    }
+}
+
+__device__ __forceinline__ float color_grad(const float* __restrict__ img, long base, long plane, long a, long b) {
+    // mean over 3 channels of |I[a] - I[b]|, img NCHW planar
+    return (fabsf(img[base + a] - img[base + b]) + fabsf(img[base + plane + a] - img[base + plane + b]) +
+            fabsf(img[base + 2 * plane + a] - img[base + 2 * plane + b])) / 3.f;
+}
+
+// partial[block][2] = (sum_x |dx norm| e^{-|dx I|}, sum_y ...)
+__global__ __launch_bounds__(LT) void smooth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ img,
+                                                        const float* __restrict__ mean, float* __restrict__ partial,
+                                                        int N, int h, int w) {
+    __shared__ float sm[4 * 2];
+    const long P = (long)h * w, total = N * P;
+    float acc[2] = {0.f, 0.f};
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const int x = (int)(i % w);
+        const long t = i / w;
+        const int y = (int)(t % h);
+        const long n = t / h;
+        const float inv = 1.f / (mean[n] + 1e-7f);
+        const float v = disp[i] * inv;
+        const long ib = n * 3 * P, p = (long)y * w + x;
+        if (x + 1 < w) acc[0] += fabsf(v - disp[i + 1] * inv) * expf(-color_grad(img, ib, P, p, p + 1));
+        if (y + 1 < h) acc[1] += fabsf(v - disp[i + w] * inv) * expf(-color_grad(img, ib, P, p, p + w));
+    }
+    block_sum<2>(acc, sm);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = acc[0]; partial[blockIdx.x * 2 + 1] = acc[1]; }
+}
+
+// G = d smooth / d norm (already times the scale weight); gd_acc[n] += sum_i G_i * disp_i
+__global__ __launch_bounds__(LT) void smooth_bwd_g_kernel(const float* __restrict__ disp, const float* __restrict__ img,
+                                                          const float* __restrict__ mean, const float* __restrict__ wts,
+                                                          float* __restrict__ G, double* __restrict__ gd_acc, int N,
+                                                          int h, int w) {
+    const long P = (long)h * w, total = N * P;
+    const float wx = wts[2] / (float)((double)N * h * (w - 1)), wy = wts[2] / (float)((double)N * (h - 1) * w);
+    __shared__ float sm[4];
+    // blocks never straddle images when P % LT == 0; otherwise fall back to per-thread atomics
+    for (long i0 = blockIdx.x * (long)LT; i0 < total; i0 += (long)gridDim.x * LT) {
+        const long i = i0 + threadIdx.x;
+        float gsum = 0.f; long n = 0; float gi = 0.f;
+        if (i < total) {
+            const int x = (int)(i % w);
+            const long t = i / w;
+            const int y = (int)(t % h);
+            n = t / h;
+            const float inv = 1.f / (mean[n] + 1e-7f);
+            const float v = disp[i] * inv;
+            const long ib = n * 3 * P, p = (long)y * w + x;
+            auto sgn = [](float a) { return a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f); };
+            if (x + 1 < w) gi += wx * sgn(v - disp[i + 1] * inv) * expf(-color_grad(img, ib, P, p, p + 1));
+            if (x > 0) gi -= wx * sgn(disp[i - 1] * inv - v) * expf(-color_grad(img, ib, P, p - 1, p));
+            if (y + 1 < h) gi += wy * sgn(v - disp[i + w] * inv) * expf(-color_grad(img, ib, P, p, p + w));
+            if (y > 0) gi -= wy * sgn(disp[i - w] * inv - v) * expf(-color_grad(img, ib, P, p - w, p));
+            G[i] = gi;
+            gsum = gi * disp[i];
+        }
+        const long nfirst = i0 / P, nlast = (min(i0 + LT, total) - 1) / P;
+        if (nfirst == nlast) {
+            float s = wave_sum(gsum);
+            if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(&gd_acc[nfirst], (double)(sm[0] + sm[1] + sm[2] + sm[3]));
+            __syncthreads();
+        } else if (i < total) {
+            atomicAdd(&gd_acc[n], (double)gsum);
+        }
+    }
+}
+
+__global__ __launch_bounds__(LT) void smooth_bwd_final_kernel(const float* __restrict__ G, const float* __restrict__ mean,
+                                                              const double* __restrict__ gd_acc, float* __restrict__ gdisp,
+                                                              int N, long P, int accumulate) {
+    const long total = N * P;
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const long n = i / P;
+        const float me = mean[n] + 1e-7f;
+        const float v = G[i] / me - (float)(gd_acc[n] / ((double)me * me * (double)P));
+        gdisp[i] = accumulate ? gdisp[i] + v : v;
+    }
+}
+
+// ------------------------------------------------------------------ scalar bookkeeping
+// vals layout: [0] loss, then per scale s: [1+3s] loss/s, [2+3s] supervised_depth_loss/s, [3+3s] normals loss
+// sums layout (double): per scale 5: sum|.|m, sum(2-cos)m, sum m, smooth_x_sum, smooth_y_sum
+struct LossMeta {
+    int S;
+    int sup_rows[8], sm_rows[8], N[8], h[8], w[8], scale_id[8];
+};
+
+__global__ void loss_finalize_kernel(const float* __restrict__ sup_part, const float* __restrict__ sm_part,
+                                     const LossMeta m, int part_stride, float w_normals, float w_smooth,
+                                     double* __restrict__ sums, float* __restrict__ vals) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double total = 0.0;
+    for (int s = 0; s < m.S; ++s) {
+        double a[5] = {0, 0, 0, 0, 0};
+        const float* sp = sup_part + (long)s * part_stride * 3;
+        for (int r = 0; r < m.sup_rows[s]; ++r) { a[0] += sp[r * 3]; a[1] += sp[r * 3 + 1]; a[2] += sp[r * 3 + 2]; }
+        const float* mp = sm_part + (long)s * part_stride * 2;
+        for (int r = 0; r < m.sm_rows[s]; ++r) { a[3] += mp[r * 2]; a[4] += mp[r * 2 + 1]; }
+        for (int j = 0; j < 5; ++j) sums[s * 5 + j] = a[j];
+        const int N = m.N[s], h = m.h[s], w = m.w[s];
+        const double l1 = a[0] / a[2], ln = a[1] / a[2];
+        const double smooth = a[3] / ((double)N * h * (w - 1)) + a[4] / ((double)N * (h - 1) * w);
+        const double ls = l1 + (double)w_normals * ln + (double)w_smooth * smooth / (double)(1 << m.scale_id[s]);
+        vals[1 + 3 * s] = (float)ls;
+        vals[2 + 3 * s] = (float)l1;
+        vals[3 + 3 * s] = (float)ln;
+        total += ls;
+    }
+    vals[0] = (float)(total / m.S);
+}
+
+// per-scale weights (w_L1, w_LN, w_sm) from the upstream gradient of vals
+__global__ void loss_weights_kernel(const float* __restrict__ gvals, const LossMeta m, float w_normals, float w_smooth,
+                                    float* __restrict__ wts) {
+    const int s = threadIdx.x;
+    if (s >= m.S) return;
+    const float gl = gvals[0] / m.S + gvals[1 + 3 * s];
+    wts[3 * s] = gl + gvals[2 + 3 * s];
+    wts[3 * s + 1] = gl * w_normals + gvals[3 + 3 * s];
+    wts[3 * s + 2] = gl * w_smooth / (float)(1 << m.scale_id[s]);
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" int pd_loss_rows(long n) { return (int)lgrid(n); }
+
+extern "C" int pd_disp_to_depth(const void* disp, void* depth, void* updisp, int N, int hs, int ws, int H, int W,
+                                float min_depth, float max_depth, void* stream) {
+    PD_REQUIRE(disp && depth && N >= 0 && hs > 0 && ws > 0 && H >= hs && W >= ws, "pd_disp_to_depth: bad arguments");
+    PD_REQUIRE(min_depth > 0 && max_depth > min_depth, "pd_disp_to_depth: bad depth range");
+    if (N == 0) return PD_OK;
+    hipLaunchKernelGGL(disp_to_depth_kernel, dim3(lgrid((long)N * H * W)), dim3(LT), 0, (hipStream_t)stream,
+                       (const float*)disp, (float*)depth, (float*)updisp, N, hs, ws, H, W, 1.f / max_depth,
+                       1.f / min_depth);
+    return pd::check_launch("pd_disp_to_depth");
+}
+
+extern "C" int pd_up_gather_bwd(const void* gup, void* gdisp, int N, int hs, int ws, int H, int W, int accumulate,
+                                void* stream) {
+    PD_REQUIRE(gup && gdisp && N >= 0 && hs > 0 && ws > 0, "pd_up_gather_bwd: bad arguments");
+    PD_REQUIRE(H % hs == 0 && W % ws == 0, "pd_up_gather_bwd: full size must be an integer multiple of the scale size");
+    if (N == 0) return PD_OK;
+    hipLaunchKernelGGL(up_gather_bwd_kernel, dim3(lgrid((long)N * hs * ws)), dim3(LT), 0, (hipStream_t)stream,
+                       (const float*)gup, (float*)gdisp, N, hs, ws, H, W, accumulate);
+    return pd::check_launch("pd_up_gather_bwd");
+}
+
+extern "C" int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, void* partial, int N, int H, int W,
+                               float min_depth, float max_depth, int with_normals, void* stream) {
+    PD_REQUIRE(pred && gt && partial && (K || !with_normals) && N > 0 && H > 0 && W > 0, "pd_sup_loss_fwd: bad arguments");
+    hipLaunchKernelGGL(sup_fwd_kernel, dim3(lgrid((long)N * H * W)), dim3(LT), 0, (hipStream_t)stream,
+                       (const float*)pred, (const float*)gt, (const float*)K, (float*)partial, N, H, W, min_depth,
+                       max_depth, with_normals);
+    return pd::check_launch("pd_sup_loss_fwd");
+}
+
+extern "C" int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* wts, const void* sums,
+                               void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
+                               int with_normals, int to_disp, void* stream) {
+    PD_REQUIRE(pred && gt && wts && sums && gout && N > 0 && H > 0 && W > 0, "pd_sup_loss_bwd: bad arguments");
+    PD_REQUIRE(!with_normals || (K && ab_ws), "pd_sup_loss_bwd: normals term needs K and the [N,H,W,6] workspace");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = lgrid((long)N * H * W);
+    if (with_normals)
+        hipLaunchKernelGGL(sup_bwd_a_kernel, dim3(grid), dim3(LT), 0, st, (const float*)pred, (const float*)gt,
+                           (const float*)K, (const float*)wts, (const double*)sums, (float*)ab_ws, N, H, W, min_depth,
+                           max_depth);
+    hipLaunchKernelGGL(sup_bwd_b_kernel, dim3(grid), dim3(LT), 0, st, (const float*)pred, (const float*)gt,
+                       (const float*)K, (const float*)wts, (const double*)sums, (const float*)ab_ws, (float*)gout, N, H,
+                       W, min_depth, max_depth, 1.f / min_depth - 1.f / max_depth, with_normals, to_disp);
+    return pd::check_launch("pd_sup_loss_bwd");
+}
+
+extern "C" int pd_smooth_fwd(const void* disp, const void* img, void* mean, void* partial, int N, int h, int w,
+                             void* stream) {
+    PD_REQUIRE(disp && img && mean && partial && N > 0 && h > 1 && w > 1, "pd_smooth_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(image_mean_kernel, dim3(N), dim3(1024), 0, st, (const float*)disp, (float*)mean, h * w);
+    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(lgrid((long)N * h * w)), dim3(LT), 0, st, (const float*)disp,
+                       (const float*)img, (const float*)mean, (float*)partial, N, h, w);
+    return pd::check_launch("pd_smooth_fwd");
+}
+
+extern "C" int pd_smooth_bwd(const void* disp, const void* img, const void* mean, const void* wts, void* g_ws,
+                             void* gd_acc, void* gdisp, int N, int h, int w, int accumulate, void* stream) {
+    PD_REQUIRE(disp && img && mean && wts && g_ws && gd_acc && gdisp && N > 0 && h > 1 && w > 1, "pd_smooth_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(gd_acc, 0, sizeof(double) * N, st) != hipSuccess) return pd::fail(PD_ELAUNCH, "pd_smooth_bwd: memset");
+    const unsigned grid = lgrid((long)N * h * w);
+    hipLaunchKernelGGL(smooth_bwd_g_kernel, dim3(grid), dim3(LT), 0, st, (const float*)disp, (const float*)img,
+                       (const float*)mean, (const float*)wts, (float*)g_ws, (double*)gd_acc, N, h, w);
+    hipLaunchKernelGGL(smooth_bwd_final_kernel, dim3(grid), dim3(LT), 0, st, (const float*)g_ws, (const float*)mean,
+                       (const double*)gd_acc, (float*)gdisp, N, (long)h * w, accumulate);
+    return pd::check_launch("pd_smooth_bwd");
+}
+
+extern "C" int pd_loss_finalize(const void* sup_part, const int* sup_rows, const void* sm_part, const int* sm_rows,
+                                const int* dims /* per scale N,h,w */, const int* scale_ids, int S, int part_stride,
+                                float w_normals, float w_smooth, void* sums, void* vals, void* stream) {
+    PD_REQUIRE(sup_part && sup_rows && sm_part && sm_rows && dims && scale_ids && sums && vals && S > 0 && S <= 8,
+               "pd_loss_finalize: bad arguments");
+    LossMeta m{};
+    m.S = S;
+    for (int s = 0; s < S; ++s) {
+        m.sup_rows[s] = sup_rows[s]; m.sm_rows[s] = sm_rows[s];
+        m.N[s] = dims[3 * s]; m.h[s] = dims[3 * s + 1]; m.w[s] = dims[3 * s + 2]; m.scale_id[s] = scale_ids[s];
+        PD_REQUIRE(sup_rows[s] <= part_stride && sm_rows[s] <= part_stride, "pd_loss_finalize: rows exceed part_stride");
+    }
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)sup_part,
+                       (const float*)sm_part, m, part_stride, w_normals, w_smooth, (double*)sums, (float*)vals);
+    return pd::check_launch("pd_loss_finalize");
+}
+
+extern "C" int pd_loss_weights(const void* gvals, const int* scale_ids, int S, float w_normals, float w_smooth,
+                               void* wts, void* stream) {
+    PD_REQUIRE(gvals && scale_ids && wts && S > 0 && S <= 8, "pd_loss_weights: bad arguments");
+    LossMeta m{};
+    m.S = S;
+    for (int s = 0; s < S; ++s) m.scale_id[s] = scale_ids[s];
+    hipLaunchKernelGGL(loss_weights_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)gvals, m,
+                       w_normals, w_smooth, (float*)wts);
+    return pd::check_launch("pd_loss_weights");
+}

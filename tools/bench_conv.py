@@ -1,0 +1,51 @@
+"""Kernel timing of the implicit-GEMM conv kernels on the network's dominant shapes (B=16, 512x640)."""
+import json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "supervised-depth-estimation-from-polarized-images_amd"))
+from polardepth import ops  # noqa: E402
+
+B = int(os.environ.get("B", 16))
+SHAPES = [  # name, C, H, W, Co, k, s, p, mode
+    ("enc.ResBlock1 3x3 64->64 @256x320", 64, 256, 320, 64, 3, 1, 1, 0),
+    ("enc.Conv2 5x5 64->64 @256x320", 64, 256, 320, 64, 5, 1, 2, 0),
+    ("enc.Conv3 5x5 64->64 @128x160", 64, 128, 160, 64, 5, 1, 2, 0),
+    ("joint.ResBlock1 3x3 128->128 @64x80", 128, 64, 80, 128, 3, 1, 1, 0),
+    ("joint.Conv1 5x5 128->256 @64x80", 128, 64, 80, 256, 5, 1, 2, 0),
+    ("joint.ResBlock3 3x3 256 @32x40", 256, 32, 40, 256, 3, 1, 1, 0),
+    ("joint.Conv2 5x5 256->512 @32x40", 256, 32, 40, 512, 5, 1, 2, 0),
+    ("joint.ResBlock5 3x3 512 @16x20", 512, 16, 20, 512, 3, 1, 1, 0),
+    ("dec.upconv(1,1) 96->32 @256x320 refl", 96, 256, 320, 32, 3, 1, 1, 1),
+    ("dec.upconv(0,1) 16->16 @512x640 refl", 16, 512, 640, 16, 3, 1, 1, 1),
+    ("stem normals 7x7s2 9->64 @512x640", 9, 512, 640, 64, 7, 2, 3, 0),
+]
+
+
+def timeit(fn, iters=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+for name, C, H, W, Co, k, s, p, mode in SHAPES:
+    x = torch.randn(B, C, H, W, device="cuda")
+    if C >= 16:
+        x = x.contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, C, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+    y = ops.conv2d_fwd(x, w, None, stride=s, pad=p, mode=mode)
+    Ho, Wo = y.shape[2:]
+    flops = 2.0 * B * Ho * Wo * Co * C * k * k
+    t_f = timeit(lambda: ops.conv2d_fwd(x, w, None, stride=s, pad=p, mode=mode, out=y))
+    dy = torch.randn_like(y)
+    t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, w.shape, stride=s, pad=p, mode=mode))
+    res = {"layer": name, "GF": round(flops / 1e9, 2), "fwd_ms": round(t_f, 3), "fwd_TF": round(flops / t_f / 1e9, 1),
+           "wgrad_ms": round(t_w, 3), "wgrad_TF": round(flops / t_w / 1e9, 1)}
+    if mode == 0 and C >= 16:
+        wt = ops.weight_transposed(w)
+        t_d = timeit(lambda: ops.conv2d_dgrad(dy, w, (H, W), stride=s, pad=p, wt=wt))
+        res.update(dgrad_ms=round(t_d, 3), dgrad_TF=round(flops / t_d / 1e9, 1))
+    print(json.dumps(res), flush=True)
