@@ -121,6 +121,85 @@ int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* 
 /* w [Cout][T][Cin] -> wt [Cin][T][Cout], T = KH*KW: operand of the mode-2 (data gradient) GEMM. */
 int pd_weight_transpose(const void* w, void* wt, int Cout, int T, int Cin, void* stream);
 
+/* ------------------------------------------------------------------------- K3
+ * Memory-bound kernels fused around the convolutions (NHWC fp32, 16 bytes per lane).
+ *
+ * pd_bn_fwd_finalize: BatchNorm2d statistics.  training != 0: reduces the conv epilogue partials
+ *   [R][C][2] in fp64 (acc_ws: 2*C doubles), updates running_mean/var with torch semantics
+ *   (momentum, unbiased variance) and emits scale = gamma*invstd, shift = beta - mean*scale plus
+ *   the saved mean / invstd; training == 0: coefficients from the running statistics.
+ *   Replaces nn.BatchNorm2d's statistics pass (pre_encoders.py:19,29; torchvision BasicBlock.bn*).
+ * pd_chain_fwd: out = relu_post( dropout( pool2x2( relu_pre( x*scale + shift ) ) ) + res )
+ *   i.e. the tail of pre_encoders.ConvBlock (:28-34) + the ResidualBlock add (:46), or the
+ *   torchvision BasicBlock tail (bn -> +identity -> relu).  scale == NULL means identity.
+ *   Dropout masks come from Philox4x32-10(seed, offset, element) and are regenerated in backward.
+ * pd_chain_bwd_reduce / pd_bn_bwd_finalize / pd_chain_bwd_apply: the two-pass backward
+ *   (per-channel sum g, sum g*xhat -> dgamma, dbeta -> dx of the raw conv output; optional dres
+ *   = dy * (out > 0) for post-add ReLU blocks).
+ */
+int pd_bn_fwd_finalize(const void* partial, long R, int C, double count, const void* gamma, const void* beta,
+                       void* running_mean, void* running_var, float momentum, float eps, void* acc_ws,
+                       void* scale, void* shift, void* save_mean, void* save_invstd, int training, void* stream);
+int pd_bn_bwd_finalize(const void* partial, long R, int C, double count, void* acc_ws, void* dgamma, void* dbeta,
+                       void* coef, int accumulate, void* stream);
+long pd_chain_bwd_rows(int N, int H, int W, int C);
+int pd_chain_fwd(const void* x, const void* scale, const void* shift, const void* res, void* out,
+                 int N, int H, int W, int C, long ld_res, long ld_out, int relu_pre, int pool,
+                 float drop_p, uint64_t seed, uint64_t offset, int relu_post, void* stream);
+int pd_chain_bwd_reduce(const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
+                        const void* scale, const void* shift, const void* mean, const void* invstd,
+                        void* partial, int N, int H, int W, int C, int relu_pre, int pool, float drop_p,
+                        uint64_t seed, uint64_t offset, int relu_post, void* stream);
+int pd_chain_bwd_apply(const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
+                       const void* scale, const void* shift, const void* mean, const void* invstd,
+                       const void* coef, void* dx, void* dres, int N, int H, int W, int C, int relu_pre,
+                       int pool, float drop_p, uint64_t seed, uint64_t offset, int relu_post, void* stream);
+
+/* nn.MaxPool2d(3, 2, 1) of the ResNet stem (resnet_encoder.py:814) and its gradient. */
+int pd_maxpool3s2_fwd(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int pd_maxpool3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+
+/* Decoder glue: out[N,2H,2W,Ca+Cs] = cat(bilinear_x2(a), skip)  (layers.py:446-449 upsample,
+ * depth_decoder.py:64-67 cat) and the gradient of the upsampled part (gather form). */
+int pd_upcat_fwd(const void* a, const void* skip, long ld_skip, void* out, int N, int H, int W, int Ca, int Cs,
+                 void* stream);
+int pd_up_bwd(const void* dout, long ld_d, void* da, int N, int H, int W, int Ca, void* stream);
+
+/* dz = dy * f'(.) through the activation OUTPUT y: act 1 ReLU, 2 ELU (layers.py:337), 3 sigmoid. */
+int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int act, void* stream);
+/* Gradient of ReflectionPad2d(1): dxp [N,H+2,W+2,C] -> dx [N,H,W,C]  (layers.py:372). */
+int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, int C, void* stream);
+/* torch.optim.Adam step (trainer.py:238,442) over one flat fp32 buffer; grads are pre-multiplied
+ * by grad_scale (1/world_size after the RCCL sum). */
+int pd_adam_step(void* p, const void* g, void* m, void* v, long n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, long step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------- K5
+ * Multi-scale supervised loss (trainer.py:1126-1150,1241-1265,1298-1309; layers.py:62-71,452-465).
+ * Per scale: pd_disp_to_depth (bilinear to H x W + disp_to_depth), pd_sup_loss_fwd (masked L1 and
+ * the kornia depth_to_normals cosine term as wavefront-reduced partial sums), pd_smooth_fwd;
+ * pd_loss_finalize turns the partials into vals = [loss, (loss/s, supervised_depth_loss/s,
+ * normals_loss/s) per scale] on the device.  Backward: pd_loss_weights, pd_sup_loss_bwd,
+ * pd_up_gather_bwd, pd_smooth_bwd.  No host synchronisation anywhere.
+ */
+int pd_loss_rows(long n);
+int pd_disp_to_depth(const void* disp, void* depth, void* updisp, int N, int hs, int ws, int H, int W,
+                     float min_depth, float max_depth, void* stream);
+int pd_up_gather_bwd(const void* gup, void* gdisp, int N, int hs, int ws, int H, int W, int accumulate, void* stream);
+int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, void* partial, int N, int H, int W,
+                    float min_depth, float max_depth, int with_normals, void* stream);
+int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* wts, const void* sums,
+                    void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
+                    int with_normals, int to_disp, void* stream);
+int pd_smooth_fwd(const void* disp, const void* img, void* mean, void* partial, int N, int h, int w, void* stream);
+int pd_smooth_bwd(const void* disp, const void* img, const void* mean, const void* wts, void* g_ws, void* gd_acc,
+                  void* gdisp, int N, int h, int w, int accumulate, void* stream);
+int pd_loss_finalize(const void* sup_part, const int* sup_rows, const void* sm_part, const int* sm_rows,
+                     const int* dims, const int* scale_ids, int S, int part_stride, float w_normals,
+                     float w_smooth, void* sums, void* vals, void* stream);
+int pd_loss_weights(const void* gvals, const int* scale_ids, int S, float w_normals, float w_smooth, void* wts,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,8 @@ _c = ctypes
 _vp, _i, _sz, _dbl = _c.c_void_p, _c.c_int, _c.c_size_t, _c.c_double
 _dp = _c.POINTER(_c.c_double)
 _l, _f = _c.c_long, _c.c_float
+_u64 = _c.c_uint64
+_ip = _c.POINTER(_c.c_int)
 
 # name -> (restype, argtypes); mirrors include/polardepth.h one to one
 SIGNATURES = {
@@ -35,6 +37,30 @@ SIGNATURES = {
     "pd_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i,
                              _i, _i, _f, _f, _l, _i, _vp]),
     "pd_weight_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pd_bn_fwd_finalize": (_i, [_vp, _l, _i, _dbl, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pd_bn_bwd_finalize": (_i, [_vp, _l, _i, _dbl, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pd_chain_bwd_rows": (_l, [_i, _i, _i, _i]),
+    "pd_chain_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _i, _i, _f, _u64, _u64, _i, _vp]),
+    "pd_chain_bwd_reduce": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u64,
+                                 _u64, _i, _vp]),
+    "pd_chain_bwd_apply": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f,
+                                _u64, _u64, _i, _vp]),
+    "pd_maxpool3s2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_maxpool3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_upcat_fwd": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pd_up_bwd": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp]),
+    "pd_act_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+    "pd_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _vp]),
+    "pd_loss_rows": (_i, [_l]),
+    "pd_disp_to_depth": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
+    "pd_up_gather_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "pd_sup_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    "pd_sup_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
+    "pd_smooth_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pd_smooth_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_loss_finalize": (_i, [_vp, _ip, _vp, _ip, _ip, _ip, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "pd_loss_weights": (_i, [_vp, _ip, _i, _f, _f, _vp, _vp]),
 }
 
 

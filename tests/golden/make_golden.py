@@ -27,6 +27,7 @@ import torch
 REF = os.environ.get("PD_REFERENCE", "/root/reference")
 OUT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))  # repo root (oracle/)
+sys.path.insert(0, OUT)
 
 
 def _ref_imports():
@@ -114,7 +115,176 @@ def make_polar():
     print("polar goldens written")
 
 
-GROUPS = {"polar": make_polar}
+# ------------------------------------------------------------------ group: nets
+def _grad_summary(module):
+    return {k: p.grad.detach().clone() for k, p in module.named_parameters() if p.grad is not None}
+
+
+def make_nets():
+    from synth_weights import fill_state_dict
+    pre, dec = ref_networks()
+    rng = torch.Generator().manual_seed(1)
+    out = {}
+    xolp = torch.stack([torch.rand(2, 64, 96, generator=rng) * 0.6,
+                        (torch.rand(2, 64, 96, generator=rng) - 0.5) * 3.1], 1)          # [2,2,64,96] rho, phi
+    out["xolp"] = xolp
+
+    def run(name, mod, args, input_grad=True):
+        """eval output, train(dropout=0) output, and the train-mode grads of a seeded scalar objective."""
+        fill_state_dict(mod, 0, prefix=name + ".")
+        mod.eval()
+        with torch.no_grad():
+            y = mod(*args)
+        ys = y if isinstance(y, (list, tuple)) else [y]
+        for i, t in enumerate(ys):
+            out[f"{name}.eval.{i}"] = t.clone()
+        mod.train()
+        for p in mod.parameters():
+            p.grad = None
+        args_g = [a.clone().requires_grad_(input_grad) if a is not None else None for a in args]
+        y = mod(*args_g)
+        ys = y if isinstance(y, (list, tuple)) else [y]
+        obj = 0
+        for i, t in enumerate(ys):
+            out[f"{name}.train.{i}"] = t.detach().clone()
+            w = torch.randn(t.shape, generator=torch.Generator().manual_seed(100 + i))
+            obj = obj + (t * w).sum()
+        obj.backward()
+        for k, g in _grad_summary(mod).items():
+            # keep fixtures small: full tensor for small grads, strided sample + abs-sum for big ones
+            if g.numel() <= 20000:
+                out[f"{name}.grad.{k}"] = g
+            else:
+                out[f"{name}.gradsample.{k}"] = g.flatten()[::max(1, g.numel() // 4096)].clone()
+                out[f"{name}.gradabssum.{k}"] = g.abs().sum()
+        for i, a in enumerate(args_g):
+            if a is not None and a.grad is not None:
+                out[f"{name}.ingrad.{i}"] = a.grad.clone()
+        for k, v in mod.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                if v.numel() <= 64:
+                    out[f"{name}.buf.{k}"] = v.clone()
+
+    run("xolp_encoder", pre.ShallowEncoder('XOLP', 2, 0.0), [xolp], input_grad=False)
+    run("normals_encoder", pre.ShallowNormalsEncoder(9, 0.0), [xolp], input_grad=False)   # numpy bounce: no input grad
+    rgbf = torch.randn(2, 128, 8, 12, generator=rng)
+    xf = torch.randn(2, 64, 8, 12, generator=rng)
+    nf = torch.randn(2, 64, 8, 12, generator=rng)
+    out["joint.rgbf"], out["joint.xf"], out["joint.nf"] = rgbf, xf, nf
+    run("joint3", pre.JointEncoder(0.0, True, True), [rgbf, xf, nf])
+    run("joint_x", pre.JointEncoder(0.0, False, True), [rgbf, xf, None])
+    run("joint_n", pre.JointEncoder(0.0, True, False), [rgbf, None, nf])
+    run("joint_rgb", pre.JointEncoder(0.0, False, False), [rgbf, None, None])
+
+    # DepthDecoder: list-of-features input
+    import numpy as _np
+    feats = [torch.randn(2, c, 64 // d, 96 // d, generator=rng) for c, d in
+             ((64, 2), (64, 4), (128, 8), (256, 16), (512, 32))]
+    for i, f in enumerate(feats):
+        out[f"dec.feat.{i}"] = f
+    dd = dec.DepthDecoder(_np.array([64, 64, 128, 256, 512]), range(4))
+    fill_state_dict(dd, 0, prefix="mono_depth.")
+    fg = [f.clone().requires_grad_(True) for f in feats]
+    res = dd(fg)
+    obj = 0
+    for s in range(4):
+        out[f"dec.disp.{s}"] = res[("disp", s)].detach().clone()
+        obj = obj + (res[("disp", s)] * torch.randn(res[("disp", s)].shape, generator=torch.Generator().manual_seed(200 + s))).sum()
+    obj.backward()
+    for i, f in enumerate(fg):
+        out[f"dec.featgrad.{i}"] = f.grad.clone()
+    for k, g in _grad_summary(dd).items():
+        if g.numel() <= 20000:
+            out[f"dec.grad.{k}"] = g
+        else:
+            out[f"dec.gradsample.{k}"] = g.flatten()[::max(1, g.numel() // 4096)].clone()
+            out[f"dec.gradabssum.{k}"] = g.abs().sum()
+    np.savez_compressed(os.path.join(OUT, "g4_nets.npz"), **{k: v.numpy() for k, v in out.items()})
+    print("nets goldens written:", len(out), "arrays")
+
+
+# ------------------------------------------------------------------ group: loss
+def _import_ref_trainer():
+    """manydepth.trainer under harmless stubs."""
+    _ref_imports()
+    from oracle import losses as olosses
+    tb = types.ModuleType("torch.utils.tensorboard"); tb.SummaryWriter = object
+    sys.modules["torch.utils.tensorboard"] = tb
+    for name in ("kornia", "kornia.geometry", "kornia.geometry.depth", "roma", "manydepth.datasets", "manydepth.dpt"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    # kornia is not installed: the normals term is served by the build's own restatement
+    # (self-consistency fixture); the pure-reference fixture uses normals_loss_weight = 0.
+    sys.modules["kornia.geometry.depth"].depth_to_normals = olosses.depth_to_normals
+    if "manydepth.networks" not in sys.modules:
+        sys.modules["manydepth.networks"] = types.ModuleType("manydepth.networks")
+    import manydepth.trainer as T
+    return T
+
+
+def synth_batch(B=2, H=64, W=96, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    inputs = {}
+    for s in range(4):
+        inputs[("color", 0, s)] = torch.rand(B, 3, H >> s, W >> s, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    depth = 1.0 + 0.6 * torch.sin(xx / 17.0)[None] * torch.cos(yy / 11.0)[None] + 0.1 * torch.rand(B, H, W, generator=g)
+    depth[torch.rand(B, H, W, generator=g) < 0.1] = 0.0          # invalid pixels
+    depth[:, :, -5:] = 0.0
+    depth[0, 3, 3] = 2.5                                           # beyond max_depth
+    inputs["depth"] = depth[:, None].contiguous()
+    K = torch.eye(4)[None].repeat(B, 1, 1)
+    K[:, 0, 0] = 0.65 * W; K[:, 1, 1] = 0.65 * W; K[:, 0, 2] = W / 2; K[:, 1, 2] = H / 2
+    inputs[("K", 0)] = K
+    disps = {("disp", s): torch.sigmoid(torch.randn(B, 1, H >> s, W >> s, generator=g)) for s in range(4)}
+    return inputs, disps
+
+
+def make_loss():
+    T = _import_ref_trainer()
+    import manydepth.layers as L
+    import torch.nn.functional as F
+    out = {}
+    inputs, disps = synth_batch()
+    for k, v in inputs.items():
+        out["in." + "_".join(map(str, k)) if isinstance(k, tuple) else "in." + k] = v
+    for (_, s), v in disps.items():
+        out[f"disp.{s}"] = v
+    for tag, lam in (("lam0", 0.0), ("lam035", 0.35)):
+        opt = types.SimpleNamespace(scales=[0, 1, 2, 3], v1_multiscale=False, train_dpt=False, depth_supervision=True,
+                                    depth_supervision_only=True, min_depth=0.1, max_depth=2.0,
+                                    normals_loss_weight=lam, disparity_smoothness=1e-3, supervise_pose=False,
+                                    height=64, width=96)
+        fake = types.SimpleNamespace(opt=opt, num_scales=4, device=torch.device("cpu"))
+        fake.compute_supervised_normals_losses = types.MethodType(T.Trainer.compute_supervised_normals_losses, fake)
+        dl = {k: v.clone().requires_grad_(True) for k, v in disps.items()}
+        outputs = dict(dl)
+        for s in range(4):       # trainer.py:531-545
+            up = F.interpolate(dl[("disp", s)], [64, 96], mode="bilinear", align_corners=False)
+            outputs[("depth", 0, s)] = L.disp_to_depth(up, 0.1, 2.0)[1]
+        losses = T.Trainer.compute_losses(fake, {k: v for k, v in inputs.items()}, outputs, is_multi=False)
+        losses["loss"].backward()
+        for k, v in losses.items():
+            out[f"{tag}.{k}"] = torch.as_tensor(v).detach()
+        for s in range(4):
+            out[f"{tag}.ddisp.{s}"] = dl[("disp", s)].grad.clone()
+            out[f"{tag}.depth.{s}"] = outputs[("depth", 0, s)].detach().clone()
+    # G6: small layer functions straight from manydepth.layers
+    g = torch.Generator().manual_seed(11)
+    a, b = torch.rand(2, 3, 24, 32, generator=g), torch.rand(2, 3, 24, 32, generator=g)
+    out["ssim.x"], out["ssim.y"], out["ssim.out"] = a, b, L.SSIM()(a, b)
+    d = torch.rand(2, 1, 24, 32, generator=g)
+    out["smooth.disp"], out["smooth.out"] = d, L.get_smooth_loss(d, a)
+    sd, dp = L.disp_to_depth(d, 0.1, 2.0)
+    out["d2d.scaled"], out["d2d.depth"] = sd, dp
+    gt, pr = 0.2 + 1.5 * torch.rand(500, generator=g), 0.2 + 1.5 * torch.rand(500, generator=g)
+    out["err.gt"], out["err.pred"] = gt, pr
+    out["err.out"] = torch.stack(L.compute_depth_errors(gt, pr))
+    np.savez_compressed(os.path.join(OUT, "g5_loss.npz"), **{k: v.numpy() for k, v in out.items()})
+    print("loss goldens written:", len(out), "arrays")
+
+
+GROUPS = {"polar": make_polar, "nets": make_nets, "loss": make_loss}
 
 if __name__ == "__main__":
     torch.manual_seed(0)
