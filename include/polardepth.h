@@ -78,6 +78,10 @@ int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, 
                  void* ints, const void* tables, size_t tables_bytes,
                  int B, int H, int W, int mode, void* stream);
 
+/* get_normals() on an existing fp32 XOLP tensor (pre_encoders.py:99-113, the path taken when a
+ * data loader already produced inputs[("xolp",0,0)]): xolp [B,2,H,W] -> normals [B,9,H,W]. */
+int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tables, size_t tables_bytes,
+                               int B, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------- K2
  * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).

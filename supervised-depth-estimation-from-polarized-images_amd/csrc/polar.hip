@@ -174,6 +174,53 @@ __device__ __forceinline__ double interp(const Tab& t, int idx, float v) {
     return t.slope[idx] * (static_cast<double>(v) - t.xlo[idx]) + t.ylo[idx];
 }
 
+// theta lookups + the three physical normals of one pixel (normals_vec.py:11-60, pre_encoders.py:99-113)
+__device__ __forceinline__ void normals9(float rho, float phi, const Tab& td, const Tab& t1, const Tab& t2,
+                                         float (&v)[9], int (&bi)[3]) {
+    const float kHalfPi = static_cast<float>(1.5707963267948966);
+    bi[0] = bin_index(td, rho); bi[1] = bin_index(t1, rho); bi[2] = bin_index(t2, rho);
+    const double thd = interp(td, bi[0], rho);
+    const double th1 = interp(t1, bi[1], rho);
+    const double th2 = interp(t2, bi[2], rho);
+    double sd, cd, s1, c1, s2, c2;
+    sincos(thd, &sd, &cd);
+    sincos(th1, &s1, &c1);
+    sincos(th2, &s2, &c2);
+    float sp, cp, sq, cq;
+    sincosf(phi, &sp, &cp);             // torch.cos/sin on the fp32 AoLP
+    sincosf(phi + kHalfPi, &sq, &cq);   // phi + np.pi/2 evaluated in fp32 (pre_encoders.py:108-109)
+    v[0] = static_cast<float>(static_cast<double>(cp) * sd);
+    v[1] = static_cast<float>(static_cast<double>(sp) * sd);
+    v[2] = static_cast<float>(cd);
+    v[3] = static_cast<float>(static_cast<double>(cq) * s1);
+    v[4] = static_cast<float>(static_cast<double>(sq) * s1);
+    v[5] = static_cast<float>(c1);
+    v[6] = static_cast<float>(static_cast<double>(cq) * s2);
+    v[7] = static_cast<float>(static_cast<double>(sq) * s2);
+    v[8] = static_cast<float>(c2);
+}
+
+// stage keys + bins of the three tables into LDS (16-byte copies) and build the views
+__device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char* smem, int nthreads, Tab& td, Tab& t1,
+                                             Tab& t2) {
+    const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
+    const uint4* src = reinterpret_cast<const uint4*>(blob + h->off_lds);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const int n16 = h->lds_bytes / 16;
+    for (int i = threadIdx.x; i < n16; i += nthreads) dst[i] = src[i];
+    const int nk = h->n_d + h->n_s1 + h->n_s2;
+    const float* keys = reinterpret_cast<const float*>(smem);
+    const double* xlo = reinterpret_cast<const double*>(smem + ((nk + 3) / 4 * 4) * 4);
+    const double* ylo = xlo + nk;
+    const double* slope = ylo + nk;
+    td = Tab{keys, xlo, ylo, slope, h->n_d};
+    int o = h->n_d;
+    t1 = Tab{keys + o, xlo + o, ylo + o, slope + o, h->n_s1};
+    o += h->n_s1;
+    t2 = Tab{keys + o, xlo + o, ylo + o, slope + o, h->n_s2};
+    __syncthreads();
+}
+
 struct Px {
     float rho, phi;
     int d1, d2;
@@ -218,27 +265,9 @@ __global__ __launch_bounds__(kThreads) void polar_kernel(
     const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
     const float* lut = reinterpret_cast<const float*>(blob + h->off_lut);
     Tab td, t1, t2;
-    if (NORMALS) {
-        // stage keys + bins into LDS with 16-byte copies
-        const uint4* src = reinterpret_cast<const uint4*>(blob + h->off_lds);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        const int n16 = h->lds_bytes / 16;
-        for (int i = threadIdx.x; i < n16; i += kThreads) dst[i] = src[i];
-        const int nk = h->n_d + h->n_s1 + h->n_s2;
-        const float* keys = reinterpret_cast<const float*>(smem);
-        const double* xlo = reinterpret_cast<const double*>(smem + ((nk + 3) / 4 * 4) * 4);
-        const double* ylo = xlo + nk;
-        const double* slope = ylo + nk;
-        td = Tab{keys, xlo, ylo, slope, h->n_d};
-        int o = h->n_d;
-        t1 = Tab{keys + o, xlo + o, ylo + o, slope + o, h->n_s1};
-        o += h->n_s1;
-        t2 = Tab{keys + o, xlo + o, ylo + o, slope + o, h->n_s2};
-        __syncthreads();
-    }
+    if (NORMALS) stage_tables(blob, smem, kThreads, td, t1, t2);
     const float kMean = static_cast<float>(0.08693199701957657);
     const float kStd = static_cast<float>(0.44430732785457433);
-    const float kHalfPi = static_cast<float>(1.5707963267948966);
 
     for (long q = blockIdx.x * (long)kThreads + threadIdx.x; q < total_quads; q += (long)gridDim.x * kThreads) {
         const long b = q / quads_per_img;
@@ -266,28 +295,10 @@ __global__ __launch_bounds__(kThreads) void polar_kernel(
             o_i[0][j] = p.d1;
             o_i[1][j] = p.d2;
             if (NORMALS) {
-                const int id = bin_index(td, p.rho), i1 = bin_index(t1, p.rho), i2 = bin_index(t2, p.rho);
-                o_i[2][j] = id; o_i[3][j] = i1; o_i[4][j] = i2;
-                const double thd = interp(td, id, p.rho);
-                const double th1 = interp(t1, i1, p.rho);
-                const double th2 = interp(t2, i2, p.rho);
-                double sd, cd, s1, c1, s2, c2;
-                sincos(thd, &sd, &cd);
-                sincos(th1, &s1, &c1);
-                sincos(th2, &s2, &c2);
-                float sp, cp, sq, cq;
-                sincosf(p.phi, &sp, &cp);             // torch.cos/sin on the fp32 AoLP
-                sincosf(p.phi + kHalfPi, &sq, &cq);   // phi + np.pi/2 evaluated in fp32 (pre_encoders.py:108-109)
+                int bi[3];
                 float v[9];
-                v[0] = static_cast<float>(static_cast<double>(cp) * sd);
-                v[1] = static_cast<float>(static_cast<double>(sp) * sd);
-                v[2] = static_cast<float>(cd);
-                v[3] = static_cast<float>(static_cast<double>(cq) * s1);
-                v[4] = static_cast<float>(static_cast<double>(sq) * s1);
-                v[5] = static_cast<float>(c1);
-                v[6] = static_cast<float>(static_cast<double>(cq) * s2);
-                v[7] = static_cast<float>(static_cast<double>(sq) * s2);
-                v[8] = static_cast<float>(c2);
+                normals9(p.rho, p.phi, td, t1, t2, v, bi);
+                o_i[2][j] = bi[0]; o_i[3][j] = bi[1]; o_i[4][j] = bi[2];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) o_n[c][j] = (MODE == PD_POLAR_STOKES && !on) ? 0.f : v[c];
             }
@@ -320,7 +331,55 @@ __global__ __launch_bounds__(kThreads) void polar_kernel(
     }
 }
 
+// get_normals() on an existing fp32 XOLP tensor (pre_encoders.py:99-113): [B,2,H,W] -> [B,9,H,W]
+__global__ __launch_bounds__(kThreads) void normals_from_xolp_kernel(const float* __restrict__ xolp,
+                                                                     float* __restrict__ normals,
+                                                                     const char* __restrict__ blob, long P,
+                                                                     long quads_per_img, long total_quads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Tab td, t1, t2;
+    stage_tables(blob, smem, kThreads, td, t1, t2);
+    for (long q = blockIdx.x * (long)kThreads + threadIdx.x; q < total_quads; q += (long)gridDim.x * kThreads) {
+        const long b = q / quads_per_img;
+        const long p4 = (q - b * quads_per_img) * 4;
+        const float4 r4 = *reinterpret_cast<const float4*>(xolp + (b * 2) * P + p4);
+        const float4 f4 = *reinterpret_cast<const float4*>(xolp + (b * 2 + 1) * P + p4);
+        const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, ff[4] = {f4.x, f4.y, f4.z, f4.w};
+        float o_n[9][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[9]; int bi[3];
+            normals9(rr[j], ff[j], td, t1, t2, v, bi);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) o_n[c][j] = v[c];
+        }
+        float* o = normals + (b * 9) * P + p4;
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+            *reinterpret_cast<float4*>(o + c * P) = make_float4(o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
+    }
+}
+
 }  // namespace
+
+extern "C" int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tables, size_t tables_bytes,
+                                          int B, int H, int W, void* stream) {
+    PD_REQUIRE(B >= 0 && H > 0 && W > 0, "pd_polar_normals_from_xolp: bad shape");
+    const long P = (long)H * W;
+    PD_REQUIRE(P % 4 == 0, "pd_polar_normals_from_xolp: H*W=%ld must be a multiple of 4", P);
+    if (B == 0) return PD_OK;
+    PD_REQUIRE(xolp && normals && tables, "pd_polar_normals_from_xolp: null pointer");
+    PD_REQUIRE(pd::aligned16(xolp) && pd::aligned16(normals) && pd::aligned16(tables), "pd_polar_normals_from_xolp: unaligned");
+    PD_REQUIRE(tables_bytes >= sizeof(PolarHeader), "pd_polar_normals_from_xolp: tables blob too small");
+    const size_t lds = tables_bytes - (sizeof(PolarHeader) + ((size_t(kLutCount) * 4 + 15) / 16 * 16));
+    PD_REQUIRE(lds <= 64 * 1024, "pd_polar_normals_from_xolp: theta tables need %zu bytes of LDS", lds);
+    const long qpi = P / 4, total = qpi * B;
+    long blocks = (total + kThreads - 1) / kThreads;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(normals_from_xolp_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream,
+                       (const float*)xolp, (float*)normals, (const char*)tables, P, qpi, total);
+    return pd::check_launch("pd_polar_normals_from_xolp");
+}
 
 extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, void* normals,
                             void* ints, const void* tables, size_t tables_bytes, int B, int H, int W, int mode,

@@ -1,0 +1,53 @@
+"""DepthDecoder (reference manydepth/networks/depth_decoder.py:15-75) on HIP kernels.
+
+Per level: upconv(i,0) [reflect conv + ELU, one kernel] -> bilinear x2 + skip concat [one kernel]
+-> upconv(i,1) -> dispconv + sigmoid [one kernel].  ModuleList order and keys (``decoder.0..9``
+upconvs, ``decoder.10..13`` dispconvs) follow depth_decoder.py:29-53.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from manydepth.layers import ConvBlock, Conv3x3
+from polardepth import functional as PF
+from polardepth import ops
+
+
+class DepthDecoder(nn.Module):
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True, uncertainty=False):
+        super().__init__()
+        if uncertainty:
+            raise NotImplementedError("uncertainty heads are not on the supervised hot path")
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.upsample_mode = 'nearest'      # attribute kept; like the reference it is unused (bilinear is applied)
+        self.scales = scales
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        self.convs = OrderedDict()
+        for i in range(4, -1, -1):
+            cin = self.num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1]
+            self.convs[("upconv", i, 0)] = ConvBlock(cin, self.num_ch_dec[i])
+            cin = self.num_ch_dec[i]
+            if self.use_skips and i > 0:
+                cin += self.num_ch_enc[i - 1]
+            self.convs[("upconv", i, 1)] = ConvBlock(cin, self.num_ch_dec[i])
+        for s in self.scales:
+            self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], self.num_output_channels)
+        self.decoder = nn.ModuleList(list(self.convs.values()))
+        self.sigmoid = nn.Sigmoid()
+        self.uncertainty = False
+
+    def forward(self, input_features):
+        self.outputs = {}
+        x = input_features[-1]
+        for i in range(4, -1, -1):
+            x = self.convs[("upconv", i, 0)](x)
+            skip = input_features[i - 1] if self.use_skips and i > 0 else None
+            x = PF.upcat(x, skip)
+            x = self.convs[("upconv", i, 1)](x)
+            if i in self.scales:
+                self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act=ops.ACT_SIGMOID)
+        return self.outputs

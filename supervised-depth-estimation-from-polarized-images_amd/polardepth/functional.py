@@ -1,0 +1,372 @@
+"""Autograd glue: each Function's forward/backward is a short sequence of HIP kernels.
+
+torch.autograd is used only as the tape; no ATen compute kernel runs inside these Functions.
+Parameter gradients are *accumulated by the kernels straight into* ``param.grad`` (a view of the
+flat gradient buffer when a ParamStore owns the parameters) and the Functions return ``None``
+for them, so there is no per-parameter AccumulateGrad pass; ``zero_grad`` is one memset.
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import lib, check, ptr, stream_ptr
+
+CL = torch.channels_last
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+# ------------------------------------------------------------------ dropout RNG stream (Philox)
+class DropoutState:
+    """(seed, offset) pairs for the Philox4x32-10 dropout masks; one offset per call site and step."""
+    seed = 0x5EEDC0DE
+    offset = 0
+
+    @classmethod
+    def manual_seed(cls, seed):
+        cls.seed, cls.offset = int(seed) & (2 ** 63 - 1), 0
+
+    @classmethod
+    def next(cls):
+        cls.offset += 1
+        return cls.seed, cls.offset
+
+
+# ------------------------------------------------------------------ helpers
+def grad_buf(p):
+    """The tensor that receives the gradient of parameter p (allocated zeroed on first use)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)          # preserve_format: channels_last weights stay channels_last
+    return p.grad
+
+
+def _ready(p):
+    hook = getattr(p, "_pd_grad_ready", None)
+    if hook is not None:
+        hook()
+
+
+def nhwc_view(t):
+    """Return (tensor, row_stride) with channel stride 1 and regular pixel strides; copies only if needed."""
+    n, c, h, w = t.shape
+    s = t.stride()
+    if s[1] == 1 and s[2] == w * s[3] and s[0] == h * w * s[3] and s[3] >= c and s[3] % 4 == 0:
+        return t, s[3]
+    if c == 1 and t.is_contiguous():
+        return t, 1
+    t = t.contiguous(memory_format=CL)
+    return t, c
+
+
+def _f32(dev, *shape):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+class BNParams:
+    """Bundle handed to ConvBNChain: affine params, running buffers and mode."""
+    __slots__ = ("gamma", "beta", "running_mean", "running_var", "training", "momentum", "eps")
+
+    def __init__(self, bn, training):
+        self.gamma, self.beta = bn.weight, bn.bias
+        self.running_mean, self.running_var = bn.running_mean, bn.running_var
+        self.training = training
+        self.momentum = BN_MOMENTUM if bn.momentum is None else bn.momentum
+        self.eps = bn.eps
+
+
+class ChainCfg:
+    __slots__ = ("stride", "pad", "relu_pre", "pool", "drop_p", "relu_post", "affine", "bn", "seed", "offset")
+
+    def __init__(self, stride=1, pad=0, relu_pre=True, pool=False, drop_p=0.0, relu_post=False, affine=None, bn=None):
+        self.stride, self.pad, self.relu_pre, self.pool = stride, pad, relu_pre, pool
+        self.drop_p, self.relu_post, self.affine, self.bn = float(drop_p), relu_post, affine, bn
+        self.seed = self.offset = 0
+
+
+# ------------------------------------------------------------------ conv -> BN -> ReLU -> pool -> dropout -> +res -> ReLU
+class ConvBNChainFn(torch.autograd.Function):
+    """pre_encoders.ConvBlock (+ ResidualBlock add) and torchvision conv/bn/relu(/add) as one node."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, res, cfg):
+        bn = cfg.bn
+        dev = x.device
+        N = x.shape[0]
+        Co = weight.shape[0]
+        if not (x.stride(1) == 1) and x.shape[1] % 4 == 0:
+            x = ops.as_nhwc(x)
+        training = bn.training
+        if training:
+            z, part = ops.conv2d_fwd(x, weight, bias, cfg.stride, cfg.pad, want_stats=True, affine=cfg.affine)
+        else:
+            z, part = ops.conv2d_fwd(x, weight, bias, cfg.stride, cfg.pad, affine=cfg.affine), None
+        _, _, Hz, Wz = z.shape
+        scale, shift, mean, invstd = _f32(dev, Co), _f32(dev, Co), _f32(dev, Co), _f32(dev, Co)
+        acc = torch.empty(2 * Co, dtype=torch.float64, device=dev) if training else None
+        check(lib.pd_bn_fwd_finalize(ptr(part), 0 if part is None else part.shape[0], Co, float(N * Hz * Wz),
+                                     ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
+                                     bn.momentum, bn.eps, ptr(acc), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                     int(training), stream_ptr()), "pd_bn_fwd_finalize")
+        Ho, Wo = (Hz // 2, Wz // 2) if cfg.pool else (Hz, Wz)
+        out = ops.empty_nhwc(N, Co, Ho, Wo, dev)
+        ld_res = 0
+        if res is not None:
+            res, ld_res = nhwc_view(res)
+        drop = cfg.drop_p if training else 0.0
+        if drop > 0:
+            cfg.seed, cfg.offset = DropoutState.next()
+        check(lib.pd_chain_fwd(ptr(z), ptr(scale), ptr(shift), ptr(res), ptr(out), N, Hz, Wz, Co, ld_res, Co,
+                               int(cfg.relu_pre), int(cfg.pool), drop, cfg.seed, cfg.offset, int(cfg.relu_post),
+                               stream_ptr()), "pd_chain_fwd")
+        ctx.cfg, ctx.drop, ctx.training, ctx.has_res = cfg, drop, training, res is not None
+        ctx.params = (weight, bias, gamma, beta)
+        ctx.save_for_backward(x, z, out, scale, shift, mean, invstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg = ctx.cfg
+        x, z, out, scale, shift, mean, invstd = ctx.saved_tensors
+        weight, bias, gamma, beta = ctx.params
+        dev = dy.device
+        N, Co, Hz, Wz = z.shape
+        dy, ld_dy = nhwc_view(dy)
+        st = stream_ptr()
+        mean_p, invstd_p, coef = (mean, invstd, _f32(dev, 2 * Co)) if ctx.training else (None, None, None)
+        if ctx.training:
+            rows = lib.pd_chain_bwd_rows(N, Hz, Wz, Co)
+            part = _f32(dev, rows, Co, 2)
+            check(lib.pd_chain_bwd_reduce(ptr(dy), ld_dy, ptr(z), ptr(out), Co, ptr(scale), ptr(shift), ptr(mean),
+                                          ptr(invstd), ptr(part), N, Hz, Wz, Co, int(cfg.relu_pre), int(cfg.pool),
+                                          ctx.drop, cfg.seed, cfg.offset, int(cfg.relu_post), st), "pd_chain_bwd_reduce")
+            acc = torch.empty(2 * Co, dtype=torch.float64, device=dev)
+            dgamma = grad_buf(gamma) if gamma is not None and gamma.requires_grad else None
+            dbeta = grad_buf(beta) if beta is not None and beta.requires_grad else None
+            check(lib.pd_bn_bwd_finalize(ptr(part), rows, Co, float(N * Hz * Wz), ptr(acc), ptr(dgamma), ptr(dbeta),
+                                         ptr(coef), 1, st), "pd_bn_bwd_finalize")
+        dz = ops.empty_nhwc(N, Co, Hz, Wz, dev)
+        want_dres = ctx.has_res and cfg.relu_post and ctx.needs_input_grad[5]
+        dres = ops.empty_nhwc(*out.shape, dev) if want_dres else None
+        check(lib.pd_chain_bwd_apply(ptr(dy), ld_dy, ptr(z), ptr(out), Co, ptr(scale), ptr(shift), ptr(mean_p),
+                                     ptr(invstd_p), ptr(coef), ptr(dz), ptr(dres), N, Hz, Wz, Co, int(cfg.relu_pre),
+                                     int(cfg.pool), ctx.drop, cfg.seed, cfg.offset, int(cfg.relu_post), st),
+              "pd_chain_bwd_apply")
+        if ctx.has_res and not cfg.relu_post and ctx.needs_input_grad[5]:
+            dres = dy                     # out = f(x) + res: the residual gradient is dy itself
+        if weight.requires_grad:
+            # the bias feeds a BatchNorm: its gradient is identically zero (mean subtraction)
+            ops.conv2d_wgrad(x, dz, weight.shape, cfg.stride, cfg.pad, affine=cfg.affine, dw=grad_buf(weight),
+                             accumulate=True)
+            if bias is not None and bias.requires_grad:
+                grad_buf(bias)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad(dz, weight, (x.shape[2], x.shape[3]), cfg.stride, cfg.pad)
+        for p in (weight, bias, gamma, beta):
+            if p is not None:
+                _ready(p)
+        return dx, None, None, None, None, dres, None
+
+
+def conv_bn_chain(x, conv, bn, cfg, res=None, training=True):
+    cfg.bn = BNParams(bn, training)
+    return ConvBNChainFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, res, cfg)
+
+
+# ------------------------------------------------------------------ decoder: reflect conv + activation
+class ReflectConvActFn(torch.autograd.Function):
+    """layers.Conv3x3 (ReflectionPad2d(1) + Conv2d(3)) followed by ELU (ConvBlock) or sigmoid (dispconv)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = ops.as_nhwc(x)
+        y = ops.conv2d_fwd(x, weight, bias, 1, 1, mode=ops.MODE_REFLECT, act=act)
+        ctx.act = act
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, bias = ctx.params
+        N, Co, H, W = y.shape
+        dy = dy.contiguous(memory_format=CL) if not (dy.is_contiguous(memory_format=CL) or Co == 1) else dy
+        if Co == 1 and not dy.is_contiguous():
+            dy = dy.contiguous()
+        if ctx.act != ops.ACT_NONE:
+            dz = torch.empty_like(y)
+            check(lib.pd_act_bwd(ptr(dy), ptr(y), ptr(dz), y.numel(), ctx.act, stream_ptr()), "pd_act_bwd")
+        else:
+            dz = dy
+        if weight.requires_grad:
+            db = grad_buf(bias) if bias is not None and bias.requires_grad else None
+            ops.conv2d_wgrad(x, dz, weight.shape, 1, 1, mode=ops.MODE_REFLECT, dw=grad_buf(weight), dbias=db,
+                             accumulate=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Ci = x.shape[1]
+            # gradient on the reflection-padded grid (a zero-pad transposed conv), then fold the border
+            dxp = ops.conv2d_dgrad(dz, weight, (H + 2, W + 2), 1, 0)
+            dx = ops.empty_nhwc(N, Ci, H, W, dy.device)
+            check(lib.pd_reflect_fold(ptr(dxp), ptr(dx), N, H, W, Ci, stream_ptr()), "pd_reflect_fold")
+        for p in (weight, bias):
+            if p is not None:
+                _ready(p)
+        return dx, None, None, None
+
+
+def reflect_conv_act(x, conv, act):
+    return ReflectConvActFn.apply(x, conv.weight, conv.bias, act)
+
+
+class UpCatFn(torch.autograd.Function):
+    """cat([bilinear_x2(a), skip], 1)  (layers.upsample + depth_decoder.py:64-67)."""
+
+    @staticmethod
+    def forward(ctx, a, skip):
+        a = ops.as_nhwc(a)
+        N, Ca, H, W = a.shape
+        Cs, ld_s = 0, 0
+        if skip is not None:
+            skip, ld_s = nhwc_view(skip)
+            Cs = skip.shape[1]
+        out = ops.empty_nhwc(N, Ca + Cs, 2 * H, 2 * W, a.device)
+        check(lib.pd_upcat_fwd(ptr(a), ptr(skip), ld_s, ptr(out), N, H, W, Ca, Cs, stream_ptr()), "pd_upcat_fwd")
+        ctx.dims = (N, Ca, Cs, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, Ca, Cs, H, W = ctx.dims
+        dout, ld = nhwc_view(dout)
+        da = ops.empty_nhwc(N, Ca, H, W, dout.device)
+        check(lib.pd_up_bwd(ptr(dout), ld, ptr(da), N, H, W, Ca, stream_ptr()), "pd_up_bwd")
+        dskip = dout[:, Ca:] if Cs and ctx.needs_input_grad[1] else None
+        return da, dskip
+
+
+def upcat(a, skip=None):
+    return UpCatFn.apply(a, skip)
+
+
+class MaxPool3s2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) (resnet_encoder.py:814)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = ops.as_nhwc(x)
+        N, C, H, W = x.shape
+        y = ops.empty_nhwc(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x.device)
+        check(lib.pd_maxpool3s2_fwd(ptr(x), ptr(y), N, H, W, C, stream_ptr()), "pd_maxpool3s2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = ops.as_nhwc(dy)
+        dx = torch.empty_like(x)
+        check(lib.pd_maxpool3s2_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, C, stream_ptr()), "pd_maxpool3s2_bwd")
+        return dx
+
+
+def maxpool3s2(x):
+    return MaxPool3s2Fn.apply(x)
+
+
+# ------------------------------------------------------------------ multi-scale loss
+class LossCfg:
+    def __init__(self, scales, min_depth, max_depth, normals_loss_weight, disparity_smoothness, height, width):
+        self.scales = list(scales)
+        self.min_depth, self.max_depth = float(min_depth), float(max_depth)
+        self.w_normals, self.w_smooth = float(normals_loss_weight), float(disparity_smoothness)
+        self.H, self.W = int(height), int(width)
+
+
+def _iarr(vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+class MultiScaleLossFn(torch.autograd.Function):
+    """trainer.py:531-545 + 1126-1150,1241-1265,1298-1309 as one node.
+
+    Inputs: gt [N,1,H,W], K [N,4,4], then per scale (disp_s [N,1,h,w], color_s [N,3,h,w]).
+    Outputs: vals [1+3S] = (loss, then per scale loss/s, supervised_depth_loss/s, normals_loss/s)
+    and the S full-resolution depth maps (non-differentiable by-products, ("depth",0,s)).
+    """
+
+    @staticmethod
+    def forward(ctx, cfg, gt, K, *disp_color):
+        S = len(cfg.scales)
+        disps = [d.contiguous() for d in disp_color[:S]]
+        colors = [c.contiguous() for c in disp_color[S:]]
+        gt = gt.contiguous().float()
+        K = K.contiguous().float()
+        dev = gt.device
+        N, _, H, W = gt.shape
+        st = stream_ptr()
+        stride = 2048
+        sup_part, sm_part = _f32(dev, S, stride, 3), _f32(dev, S, stride, 2)
+        sup_rows, sm_rows, dims = [], [], []
+        depths, means = [], []
+        with_n = 1
+        for i, s in enumerate(cfg.scales):
+            d = disps[i]
+            hs, ws = d.shape[2], d.shape[3]
+            depth = _f32(dev, N, 1, H, W)
+            check(lib.pd_disp_to_depth(ptr(d), ptr(depth), None, N, hs, ws, H, W, cfg.min_depth, cfg.max_depth, st),
+                  "pd_disp_to_depth")
+            check(lib.pd_sup_loss_fwd(ptr(depth), ptr(gt), ptr(K), ptr(sup_part[i]), N, H, W, cfg.min_depth,
+                                      cfg.max_depth, with_n, st), "pd_sup_loss_fwd")
+            mean = _f32(dev, N)
+            check(lib.pd_smooth_fwd(ptr(d), ptr(colors[i]), ptr(mean), ptr(sm_part[i]), N, hs, ws, st), "pd_smooth_fwd")
+            sup_rows.append(lib.pd_loss_rows(N * H * W)); sm_rows.append(lib.pd_loss_rows(N * hs * ws))
+            dims += [N, hs, ws]
+            depths.append(depth); means.append(mean)
+        sums = torch.empty(S * 5, dtype=torch.float64, device=dev)
+        vals = _f32(dev, 1 + 3 * S)
+        check(lib.pd_loss_finalize(ptr(sup_part), _iarr(sup_rows), ptr(sm_part), _iarr(sm_rows), _iarr(dims),
+                                   _iarr(cfg.scales), S, stride, cfg.w_normals, cfg.w_smooth, ptr(sums), ptr(vals), st),
+              "pd_loss_finalize")
+        ctx.cfg, ctx.S = cfg, S
+        ctx.save_for_backward(gt, K, sums, *disps, *colors, *depths, *means)
+        ctx.mark_non_differentiable(*depths)
+        return (vals, *depths)
+
+    @staticmethod
+    def backward(ctx, gvals, *_unused):
+        cfg, S = ctx.cfg, ctx.S
+        saved = ctx.saved_tensors
+        gt, K, sums = saved[:3]
+        disps, colors = saved[3:3 + S], saved[3 + S:3 + 2 * S]
+        depths, means = saved[3 + 2 * S:3 + 3 * S], saved[3 + 3 * S:3 + 4 * S]
+        dev = gt.device
+        N, _, H, W = gt.shape
+        st = stream_ptr()
+        gvals = gvals.contiguous().float()
+        wts = _f32(dev, 3 * S)
+        check(lib.pd_loss_weights(ptr(gvals), _iarr(cfg.scales), S, cfg.w_normals, cfg.w_smooth, ptr(wts), st),
+              "pd_loss_weights")
+        ab = _f32(dev, N, H, W, 6)
+        gup = _f32(dev, N, H, W)
+        grads = []
+        for i in range(S):
+            d = disps[i]
+            hs, ws = d.shape[2], d.shape[3]
+            check(lib.pd_sup_loss_bwd(ptr(depths[i]), ptr(gt), ptr(K), ptr(wts[3 * i:]), ptr(sums[5 * i:]), ptr(ab),
+                                      ptr(gup), N, H, W, cfg.min_depth, cfg.max_depth, 1, 1, st), "pd_sup_loss_bwd")
+            gd = torch.empty_like(d)
+            check(lib.pd_up_gather_bwd(ptr(gup), ptr(gd), N, hs, ws, H, W, 0, st), "pd_up_gather_bwd")
+            gws = _f32(dev, N, hs, ws)
+            gacc = torch.empty(N, dtype=torch.float64, device=dev)
+            check(lib.pd_smooth_bwd(ptr(d), ptr(colors[i]), ptr(means[i]), ptr(wts[3 * i:]), ptr(gws), ptr(gacc),
+                                    ptr(gd), N, hs, ws, 1, st), "pd_smooth_bwd")
+            grads.append(gd)
+        return (None, None, None, *grads, *([None] * S))
+
+
+def multiscale_loss(cfg, gt, K, disps, colors):
+    out = MultiScaleLossFn.apply(cfg, gt, K, *disps, *colors)
+    return out[0], list(out[1:])

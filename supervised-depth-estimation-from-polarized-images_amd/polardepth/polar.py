@@ -96,3 +96,19 @@ def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=No
                                ptr(out.get("normals")), ptr(out.get("ints")), ptr(tables), tables.numel(),
                                B, H, W, mode, stream_ptr()), "pd_polar_fwd")
     return out
+
+
+def normals_from_xolp(xolp, n=1.5):
+    """ShallowNormalsEncoder.get_normals on the GPU: fp32 [B,2,H,W] (DoLP, AoLP) -> fp32 [B,9,H,W]."""
+    if not (isinstance(xolp, torch.Tensor) and xolp.is_cuda):
+        raise RuntimeError("normals_from_xolp needs a CUDA(HIP) tensor; there is no CPU fallback")
+    if xolp.dim() != 4 or xolp.shape[1] != 2:
+        raise ValueError(f"xolp must be [B,2,H,W], got {tuple(xolp.shape)}")
+    xolp = xolp.float().contiguous()
+    B, _, H, W = xolp.shape
+    tables = _device_tables(float(n), xolp.device.index)
+    out = torch.empty((B, 9, H, W), dtype=torch.float32, device=xolp.device)
+    with torch.cuda.device(xolp.device):
+        check(lib.pd_polar_normals_from_xolp(ptr(xolp), ptr(out), ptr(tables), tables.numel(), B, H, W,
+                                             stream_ptr()), "pd_polar_normals_from_xolp")
+    return out

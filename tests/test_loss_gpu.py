@@ -1,0 +1,71 @@
+"""K5 multi-scale loss kernels vs the fixture produced by the reference's Trainer.compute_losses (G5)
+and vs the CPU oracle on a second geometry.  Tolerance: 1e-4 relative (north_star), usually ~1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from polardepth import functional as PF
+
+pytestmark = pytest.mark.gpu
+G5 = np.load(os.path.join(GOLDEN, "g5_loss.npz"))
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def _close(a, b, tol, what=""):
+    a, b = torch.as_tensor(a).detach().cpu().float(), torch.as_tensor(b).float()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("tag,lam", [("lam0", 0.0), ("lam035", 0.35)])
+def test_loss_matches_reference_trainer(tag, lam):
+    cfg = PF.LossCfg([0, 1, 2, 3], 0.1, 2.0, lam, 1e-3, 64, 96)
+    gt, K = T(G5["in.depth"]).cuda(), T(G5["in.K_0"]).cuda()
+    disps = [T(G5[f"disp.{s}"]).cuda().requires_grad_(True) for s in range(4)]
+    colors = [T(G5[f"in.color_0_{s}"]).cuda() for s in range(4)]
+    vals, depths = PF.multiscale_loss(cfg, gt, K, disps, colors)
+    vals[0].backward()
+    v = vals.detach().cpu()
+    _close(v[0], T(G5[f"{tag}.loss"]), 1e-5, "loss")
+    for s in range(4):
+        _close(v[1 + 3 * s], T(G5[f"{tag}.loss/{s}"]), 1e-5, f"loss/{s}")
+        _close(v[2 + 3 * s], T(G5[f"{tag}.supervised_depth_loss/{s}"]), 1e-5, f"sup/{s}")
+        _close(depths[s], T(G5[f"{tag}.depth.{s}"]), 1e-6, f"depth{s}")
+        _close(disps[s].grad, T(G5[f"{tag}.ddisp.{s}"]), 1e-4, f"ddisp{s}")
+
+
+def test_loss_vs_oracle_other_geometry_and_partial_scales():
+    from oracle import losses as ol
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 3, 96, 160
+    scales = [0, 2]
+    # smooth GT surface + mild noise: white-noise depth makes the normals term so ill-conditioned that
+    # the fp32 CPU oracle itself is 6e-2 (relative) away from its fp64 evaluation
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    gt = (1.0 + 0.5 * torch.sin(xx / 23.0) * torch.cos(yy / 17.0))[None, None].repeat(N, 1, 1, 1)
+    gt = gt + 0.02 * torch.rand(N, 1, H, W, generator=g)
+    gt[torch.rand(N, 1, H, W, generator=g) < 0.15] = 0
+    K = torch.eye(4)[None].repeat(N, 1, 1)
+    K[:, 0, 0] = 100.0; K[:, 1, 1] = 110.0; K[:, 0, 2] = 75.0; K[:, 1, 2] = 50.0
+    disps = {s: torch.sigmoid(torch.randn(N, 1, H >> s, W >> s, generator=g)) for s in scales}
+    colors = {s: torch.rand(N, 3, H >> s, W >> s, generator=g) for s in scales}
+    dl = {("disp", s): disps[s].clone().requires_grad_(True) for s in scales}
+    outputs = dict(dl)
+    for s in scales:
+        outputs[("depth", 0, s)] = ol.upsample_disp_to_depth(dl[("disp", s)], H, W, 0.1, 2.0)
+    inputs = {("color", 0, s): colors[s] for s in scales}
+    inputs["depth"] = gt; inputs[("K", 0)] = K
+    L = ol.compute_losses(inputs, outputs, scales=scales, normals_loss_weight=0.35)
+    L["loss"].backward()
+    cfg = PF.LossCfg(scales, 0.1, 2.0, 0.35, 1e-3, H, W)
+    dd = [disps[s].cuda().requires_grad_(True) for s in scales]
+    vals, depths = PF.multiscale_loss(cfg, gt.cuda(), K.cuda(), dd, [colors[s].cuda() for s in scales])
+    vals[0].backward()
+    _close(vals[0], L["loss"], 1e-5, "loss")
+    for i, s in enumerate(scales):
+        _close(vals[3 + 3 * i], L[f"normals_loss/{s}"], 1e-5, "normals")
+        _close(dd[i].grad, dl[("disp", s)].grad, 2e-4, f"ddisp{s}")
