@@ -1,0 +1,87 @@
+"""Evaluation (reference manydepth/evaluation.py:23-311): inference with the five trained modules
+and per-material depth metrics, on the HIP forward path.  Settings mirror evaluation.py:25-48."""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from manydepth import datasets, networks
+from manydepth.layers import compute_depth_errors_numpy
+from manydepth.utils import readlines
+from polardepth import polar as pdpolar
+from polardepth._lib import lib, check, ptr, stream_ptr
+
+_MATERIAL_GREY = {"box": 20, "bottle": 40, "can": 60, "cup": 80, "remote": 100, "teapot": 120, "cutlery": 140,
+                  "glass": 160, "table": 180, "wall": 200}
+
+
+class Evaluation:
+    def __init__(self, load_weights_folder=None, data_path=None, height=320, width=480, batch_size=12,
+                 augment_xolp=True, augment_normals=True, num_workers=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("Evaluation needs the MI355X: there is no CPU fallback")
+        self.height, self.width, self.batch_size = height, width, batch_size
+        self.min_depth, self.max_depth, self.scales = 0.1, 2.0, [0, 1, 2, 3]
+        self.augment_xolp, self.augment_normals = augment_xolp, augment_normals
+        self.load_weights_folder = load_weights_folder
+        self.device = torch.device("cuda")
+        self.models = {"rgb_encoder": networks.ShallowResnetEncoder(18, False)}
+        if augment_normals:
+            self.models["normals_encoder"] = networks.ShallowNormalsEncoder(9, 0.0)
+        if augment_xolp:
+            self.models["xolp_encoder"] = networks.ShallowEncoder('XOLP', 2, 0.0)
+        self.models["joint_encoder"] = networks.JointEncoder(0.0, augment_normals, augment_xolp)
+        self.models["mono_depth"] = networks.DepthDecoder(self.models["rgb_encoder"].num_ch_enc, self.scales)
+        for m in self.models.values():
+            m.to(self.device).eval()
+        split = os.path.join("splits", "HAMMER_unseen", "test_files.txt")
+        files = readlines(split) if os.path.exists(split) else []
+        ds = datasets.HAMMER_Dataset(data_path, files, height, width, [0], 4, is_train=False)
+        self.test_loader = DataLoader(ds, batch_size, False, num_workers=num_workers, drop_last=True)
+
+    def load_mono_model(self):
+        if self.load_weights_folder is None:
+            return
+        for n, m in self.models.items():
+            path = os.path.join(self.load_weights_folder, f"{n}.pth")
+            sd = torch.load(path, map_location="cpu")
+            m.load_state_dict({k: v for k, v in sd.items() if k in m.state_dict()})
+
+    @torch.no_grad()
+    def predict(self, inputs):
+        normals = None
+        if ("pol", 0, 0) in inputs:
+            out = pdpolar.polar_forward(inputs[("pol", 0, 0)], want=("xolp", "normals") if self.augment_normals else ("xolp",))
+            inputs[("xolp", 0, 0)] = out["xolp"]; normals = out.get("normals")
+        feats = self.models["rgb_encoder"](inputs["color_aug", 0, 0].float())
+        xf = self.models["xolp_encoder"](inputs["xolp", 0, 0].float()) if self.augment_xolp else None
+        nf = self.models["normals_encoder"](inputs["xolp", 0, 0].float(), normals=normals) if self.augment_normals else None
+        feats = list(feats) + self.models["joint_encoder"](feats[-1], xf, nf)
+        disp = self.models["mono_depth"](feats)[("disp", 0)].contiguous()
+        N = disp.shape[0]
+        depth = torch.empty((N, 1, self.height, self.width), device=disp.device)
+        check(lib.pd_disp_to_depth(ptr(disp), ptr(depth), None, N, disp.shape[2], disp.shape[3], self.height, self.width,
+                                   self.min_depth, self.max_depth, stream_ptr()), "pd_disp_to_depth")
+        return depth.clamp(self.min_depth, self.max_depth)
+
+    def test(self):
+        gts, preds, masks = [], [], []
+        for inputs in self.test_loader:
+            inputs = {k: v.to(self.device) for k, v in inputs.items()}
+            preds.append(self.predict(inputs).cpu()); gts.append(inputs["depth_gt"].cpu()); masks.append(inputs[("mask", 0, 0)].cpu())
+        results = {}
+        for obj in ["all"] + list(_MATERIAL_GREY):
+            errs = []
+            for g, p, m in zip(gts, preds, masks):
+                for b in range(g.shape[0]):
+                    gt, pr = g[b, 0].numpy(), p[b, 0].numpy()
+                    mask = (gt > self.min_depth) & (gt < self.max_depth)
+                    if obj != "all":
+                        mask &= m[b, 0].numpy() == _MATERIAL_GREY[obj]
+                    if mask.any():
+                        errs.append(compute_depth_errors_numpy(gt[mask], pr[mask]))
+            if errs:
+                results[obj] = np.array(errs).mean(0)
+                print(obj, ("&{: 8.5f}  " * 7).format(*results[obj].tolist()))
+        return results

@@ -1,0 +1,421 @@
+"""manydepth.trainer.Trainer -- the reference's supervised training loop (manydepth/trainer.py:73)
+on the MI355X-native engine.
+
+Kept from the reference: constructor contract (options Namespace), attributes (models,
+model_optimizer, model_lr_scheduler, opt, device, epoch, step), method names and return values of
+train / run_epoch / process_batch / compute_losses / compute_supervised_normals_losses / val / test /
+set_train / set_eval / save_opts / save_model / load_model / load_mono_model / log / log_time, the
+per-model ``<name>.pth`` + ``adam.pth`` checkpoint layout and the loss dictionary keys.
+
+Implemented scope: the supervised single-frame branch (``--depth_supervision_only``,
+``--depth_supervision``) -- trainer.py:192-216, 469-477, 497-513, 531-545, 567, 1126-1150, 1241-1265,
+1298-1309.  Pose / matching / reprojection / DPT / stereo branches raise NotImplementedError.
+
+What runs where: every tensor operation of a training step is a hand-written HIP kernel from
+libpolardepth.so (polar preprocessing K1, implicit-GEMM convolutions K2, fused BN/ReLU/pool chains
+K3, decoder glue K4, multi-scale loss K5, Adam); torch supplies memory, streams, the autograd tape
+and torch.distributed (RCCL).  There is no CPU fallback: ``--no_cuda`` is rejected.
+"""
+import json
+import logging
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from .utils import readlines, sec_to_hm_str
+from .layers import SSIM, compute_depth_errors, compute_depth_errors_numpy
+from manydepth import datasets, networks
+from polardepth import functional as PF
+from polardepth import polar as pdpolar
+from polardepth.engine import ParamStore, FusedAdam, GradReducer
+from polardepth._lib import lib, check, ptr, stream_ptr
+
+try:
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:                                   # tensorboard is optional: keep the interface
+    class SummaryWriter:
+        def __init__(self, *a, **k): pass
+        def add_scalar(self, *a, **k): pass
+        def add_image(self, *a, **k): pass
+        def close(self): pass
+
+_MATERIAL_GREY = {"box": 20, "bottle": 40, "can": 60, "cup": 80, "remote": 100, "teapot": 120, "cutlery": 140,
+                  "glass": 160, "table": 180, "wall": 200}     # instance-mask grey values, trainer.py:1388-1407
+
+
+def _unused_resnet_param(model_name, param_name):
+    """ShallowResnetEncoder builds a full resnet18 but never runs layer3/layer4/fc (resnet_encoder.py:819-820)."""
+    return model_name == "rgb_encoder" and param_name.split(".")[1] in ("layer3", "layer4", "fc")
+
+
+class Trainer:
+    def __init__(self, options):
+        self.opt = options
+        if self.opt.no_cuda:
+            raise RuntimeError("--no_cuda: this build has no CPU path (the CPU restatement lives in oracle/ and "
+                               "is test infrastructure only)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no MI355X visible: the HIP hot path cannot run and there is no CPU fallback")
+        for flag in ("train_stereo_only", "train_dpt", "train_student", "use_stereo", "res_pose", "supervise_pose"):
+            if getattr(self.opt, flag, False):
+                raise NotImplementedError(f"--{flag}: outside the supervised hot path of this build")
+        if not (self.opt.depth_supervision_only and self.opt.depth_supervision):
+            raise NotImplementedError("only --depth_supervision_only True --depth_supervision True is implemented "
+                                      "(the path of train_supervised_GT.sh)")
+        local_rank = int(os.environ.get("LOCAL_RANK", 0))
+        self.device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(self.device)
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.rank = torch.distributed.get_rank() if self.distributed else 0
+
+        timestamp = datetime.now()
+        self.data_path, self.data_path_val, self.log_dir = self.opt.data_path, self.opt.data_path_val, self.opt.log_dir
+        self.log_path = os.path.join(self.opt.log_dir, self.opt.model_name + '_' + timestamp.strftime("%m-%d_%H-%M-%S"))
+        self.log_args(timestamp)
+
+        assert self.opt.height % 32 == 0, "'height' must be a multiple of 32"
+        assert self.opt.width % 32 == 0, "'width' must be a multiple of 32"
+
+        self.models = {}
+        self.parameters_to_train = []
+        self.num_scales = len(self.opt.scales)
+        self.train_teacher_and_pose = not self.opt.freeze_teacher_and_pose
+
+        # MODEL SETUP (trainer.py:192-216)
+        self.models["rgb_encoder"] = networks.ShallowResnetEncoder(18, self.opt.weights_init == "pretrained")
+        if self.opt.augment_normals:
+            self.models["normals_encoder"] = networks.ShallowNormalsEncoder(in_channels=9,
+                                                                            dropout_rate=self.opt.dropout_rate)
+        if self.opt.augment_xolp:
+            self.models["xolp_encoder"] = networks.ShallowEncoder(mode='XOLP', in_channels=2,
+                                                                  dropout_rate=self.opt.dropout_rate)
+        self.models["joint_encoder"] = networks.JointEncoder(dropout_rate=self.opt.dropout_rate,
+                                                             include_normals=self.opt.augment_normals,
+                                                             include_xolp=self.opt.augment_xolp)
+        self.models["mono_depth"] = networks.DepthDecoder(self.models["rgb_encoder"].num_ch_enc, self.opt.scales)
+        for m in self.models.values():
+            m.to(self.device)
+        if self.distributed:                    # identical replicas: broadcast rank 0's initialisation
+            for m in self.models.values():
+                for t in list(m.parameters()) + list(m.buffers()):
+                    torch.distributed.broadcast(t.data, 0)
+
+        order = [n for n in ("rgb_encoder", "xolp_encoder", "normals_encoder", "joint_encoder", "mono_depth")
+                 if n in self.models]
+        self.store = ParamStore(self.models, order=order, unused=_unused_resnet_param, device=self.device)
+        for n in order:
+            self.parameters_to_train += list(self.models[n].parameters())
+        self.reducer = GradReducer(self.store) if self.distributed else None
+        self.model_optimizer = FusedAdam(self.store, self.opt.learning_rate, reducer=self.reducer)
+        if self.distributed:
+            self.model_optimizer.grad_scale = 1.0 / torch.distributed.get_world_size()
+        self.model_lr_scheduler = torch.optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
+
+        if self.opt.load_weights_folder is not None:
+            self.load_model()
+        if self.opt.mono_weights_folder is not None:
+            self.load_mono_model()
+
+        # DATA (trainer.py:254-303)
+        if self.opt.dataset != "HAMMER":
+            raise NotImplementedError("only --dataset HAMMER is on the hot path")
+        self.dataset = datasets.HAMMER_Dataset
+
+        def _split(split, which):
+            path = os.path.join("splits", split, f"{which}_files.txt")
+            return readlines(path) if os.path.exists(path) else []
+        train_files = [self.opt.overfit_scene] if self.opt.overfit else _split(self.opt.split, "train")
+        val_files = [self.opt.overfit_scene] if self.opt.overfit else _split(self.opt.split, "val")
+        test_files = _split(self.opt.eval_split, "test")
+        mk = lambda path, files, tr: self.dataset(path, files, self.opt.height, self.opt.width, [0], 4, is_train=tr,
+                                                  img_ext='.png', offset=self.opt.offset, modality=self.opt.modality,
+                                                  supervised_depth=True, supervised_depth_only=True,
+                                                  depth_modality=self.opt.depth_modality)
+        train_dataset, val_dataset, test_dataset = mk(self.data_path, train_files, True), \
+            mk(self.data_path, val_files, False), mk(self.data_path_val, test_files, False)
+        sampler = torch.utils.data.distributed.DistributedSampler(train_dataset) if self.distributed else None
+        self.train_loader = DataLoader(train_dataset, self.opt.batch_size, sampler is None, sampler=sampler,
+                                       num_workers=self.opt.num_workers, pin_memory=True, drop_last=True)
+        self.val_loader = DataLoader(val_dataset, self.opt.batch_size, False, num_workers=self.opt.num_workers,
+                                     pin_memory=True, drop_last=True)
+        self.val_iter = iter(self.val_loader)
+        self.test_loader = DataLoader(test_dataset, self.opt.batch_size, False, num_workers=self.opt.num_workers,
+                                      pin_memory=True, drop_last=True)
+        self.num_total_steps = len(train_dataset) // self.opt.batch_size * self.opt.num_epochs
+
+        self.writers = {}
+        modes = ["train", "val", "val_mono", "test", "test_mono"] + ["test_mono_" + m for m in
+                                                                     ("glass", "cutlery", "can", "bottle", "cup", "teapot",
+                                                                      "remote", "box", "table", "wall")]
+        for mode in modes:
+            self.writers[mode] = SummaryWriter(os.path.join(self.log_path, mode)) if self.rank == 0 else SummaryWriter()
+        if not self.opt.no_ssim:
+            self.ssim = SSIM()
+        self.depth_metric_names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
+        self.depth_metric_names_mono = [n.replace("/", "_mono/", 1) for n in self.depth_metric_names]
+        self.loss_cfg = PF.LossCfg(self.opt.scales, self.opt.min_depth, self.opt.max_depth, self.opt.normals_loss_weight,
+                                   self.opt.disparity_smoothness, self.opt.height, self.opt.width)
+        self.epoch, self.step = 0, 0
+        self.start_time = time.time()
+        if self.rank == 0:
+            print("There are {:d} training items and {:d} validation items and {:d} test items\n".format(
+                len(train_dataset), len(val_dataset), len(test_dataset)))
+            self.save_opts()
+
+    # ------------------------------------------------------------------ bookkeeping
+    def log_args(self, timestamp):
+        if int(os.environ.get("RANK", 0)) != 0:
+            return
+        os.makedirs(self.log_path, exist_ok=True)
+        logging.basicConfig(filename=os.path.join(self.log_path, 'args.log'), level=logging.INFO, format='%(message)s')
+        logging.info('Run started at: %s', str(timestamp))
+        for arg, value in sorted(vars(self.opt).items()):
+            logging.info("%s: %r", arg, value)
+
+    def set_train(self):
+        for m in self.models.values():
+            m.train()
+
+    def set_eval(self):
+        for m in self.models.values():
+            m.eval()
+
+    # ------------------------------------------------------------------ training loop (trainer.py:379-467)
+    def train(self):
+        self.epoch, self.step = 0, 0
+        self.test()
+        self.start_time = time.time()
+        for self.epoch in range(self.opt.num_epochs):
+            self.run_epoch()
+            if (self.epoch + 1) % self.opt.save_frequency == 0:
+                self.save_model()
+                self.test()
+
+    def run_epoch(self):
+        self.set_train()
+        if self.distributed and hasattr(self.train_loader.sampler, "set_epoch"):
+            self.train_loader.sampler.set_epoch(self.epoch)
+        for batch_idx, inputs in enumerate(self.train_loader):
+            before_op_time = time.time()
+            self.model_optimizer.zero_grad()
+            outputs, losses, mono_outputs = self.process_batch(inputs, is_train=True)
+            losses["loss"].backward()
+            self.model_optimizer.step()
+            early_phase = batch_idx % self.opt.log_frequency == 0 and self.step < 2000
+            late_phase = self.step % 2000 == 0
+            if early_phase or late_phase:
+                duration = time.time() - before_op_time
+                self.log_time(batch_idx, duration, losses["loss"].cpu().data)    # the only host sync of the loop
+                if "depth_gt" in inputs:
+                    self.compute_depth_losses(inputs, outputs, losses)
+                self.log("train", inputs, outputs, losses)
+                self.val()
+                if self.rank == 0:
+                    self.save_model()
+            self.step += 1
+        self.model_lr_scheduler.step()
+
+    # ------------------------------------------------------------------ forward (trainer.py:469-648)
+    def _polar_inputs(self, inputs):
+        """On-device XOLP / normals from the raw planes when the loader hands them over (K1)."""
+        normals = None
+        if ("pol", 0, 0) in inputs and (self.opt.augment_xolp or self.opt.augment_normals):
+            want = ["xolp"] + (["normals"] if self.opt.augment_normals else [])
+            out = pdpolar.polar_forward(inputs[("pol", 0, 0)], want=tuple(want))
+            inputs[("xolp", 0, 0)] = out["xolp"]
+            normals = out.get("normals")
+        return normals
+
+    def _forward_models(self, inputs):
+        normals = self._polar_inputs(inputs)
+        feats = self.models["rgb_encoder"](inputs["color_aug", 0, 0].float())
+        xolp_feats = normals_feats = None
+        if self.opt.augment_xolp:
+            xolp_feats = self.models["xolp_encoder"](inputs["xolp", 0, 0].float())
+        if self.opt.augment_normals:
+            normals_feats = self.models["normals_encoder"](inputs["xolp", 0, 0].float(), normals=normals)
+        enc_feats = self.models["joint_encoder"](feats[-1], xolp_feats, normals_feats)
+        feats = list(feats) + enc_feats
+        return dict(self.models['mono_depth'](feats))
+
+    def process_batch(self, inputs, is_train=False):
+        for key, ipt in inputs.items():
+            inputs[key] = ipt.to(self.device, non_blocking=True)
+        if self.train_teacher_and_pose:
+            mono_outputs = self._forward_models(inputs)
+        else:
+            with torch.no_grad():
+                mono_outputs = self._forward_models(inputs)
+        for scale in self.opt.scales:
+            mono_outputs[("disp", 0, scale)] = mono_outputs[("disp", scale)]
+        losses = self.compute_losses(inputs, mono_outputs, is_multi=False)
+        return mono_outputs, losses, mono_outputs
+
+    def compute_losses(self, inputs, outputs, is_multi=False):
+        """Supervised branch of trainer.py:1126-1296; also fills ("depth",0,s) / ("mono_depth",0,s)
+        (trainer.py:538-545) because K5 produces the full-resolution depth maps on the way."""
+        scales = list(self.opt.scales)
+        disps = [outputs[("disp", s)] for s in scales]
+        colors = [inputs[("color", 0, s)] for s in scales]
+        vals, depths = PF.multiscale_loss(self.loss_cfg, inputs["depth"], inputs[("K", 0)], disps, colors)
+        losses = {"loss": vals[0]}
+        for i, s in enumerate(scales):
+            losses[f"loss/{s}"] = vals[1 + 3 * i]
+            losses[f"supervised_depth_loss/{s}"] = vals[2 + 3 * i]
+            losses[f"supervised_normals_loss/{s}"] = vals[3 + 3 * i]
+            outputs[("depth", 0, s)] = depths[i]
+            outputs[("mono_depth", 0, s)] = depths[i]
+        return losses
+
+    def compute_supervised_normals_losses(self, depth_gt, depth_pred, intrinsics, mask=None):
+        """trainer.py:1298-1309 (value only): sum((2 - cos) * mask) / sum(mask) with the depth-range mask."""
+        N, _, H, W = depth_gt.shape
+        K = torch.eye(4, device=depth_gt.device)[None].repeat(N, 1, 1)
+        K[:, :3, :3] = intrinsics[:, :3, :3]
+        rows = lib.pd_loss_rows(N * H * W)
+        part = torch.empty((rows, 3), dtype=torch.float32, device=depth_gt.device)
+        check(lib.pd_sup_loss_fwd(ptr(depth_pred.contiguous().float()), ptr(depth_gt.contiguous().float()),
+                                  ptr(K.contiguous()), ptr(part), N, H, W, self.opt.min_depth, self.opt.max_depth, 1,
+                                  stream_ptr()), "pd_sup_loss_fwd")
+        s = part.double().sum(0)
+        return (s[1] / s[2]).float()
+
+    # ------------------------------------------------------------------ validation / test
+    def _next_val(self):
+        try:
+            return next(self.val_iter)
+        except StopIteration:
+            self.val_iter = iter(self.val_loader)
+            return next(self.val_iter)
+
+    def val(self):
+        self.set_eval()
+        inputs = self._next_val()
+        with torch.no_grad():
+            outputs, losses, _ = self.process_batch(inputs)
+            losses = {}
+            if "depth_gt" in inputs:
+                self.compute_depth_losses(inputs, outputs, losses, mono=True)
+            self.log("val_mono", inputs, outputs, losses, log_images=False, log_essential_images=True)
+        self.set_train()
+
+    def test(self):
+        if self.rank == 0:
+            print("Running full test set at Epoch: ", self.epoch)
+        self.set_eval()
+        gts, preds_mono, masks = [], [], []
+        with torch.no_grad():
+            for inputs in self.test_loader:
+                for key, ipt in inputs.items():
+                    inputs[key] = ipt.to(self.device)
+                outputs = self._forward_models(inputs)
+                depth = torch.empty_like(inputs["depth_gt"])
+                N, _, H, W = depth.shape
+                d0 = outputs[("disp", 0)].contiguous()
+                check(lib.pd_disp_to_depth(ptr(d0), ptr(depth), None, N, d0.shape[2], d0.shape[3], H, W,
+                                           self.opt.min_depth, self.opt.max_depth, stream_ptr()), "pd_disp_to_depth")
+                gts.append(inputs["depth_gt"].cpu())
+                masks.append(inputs[("mask", 0, 0)].cpu())
+                preds_mono.append(depth.clamp(self.opt.min_depth, self.opt.max_depth).cpu())
+        if preds_mono and self.rank == 0:
+            for obj in ["all"] + list(_MATERIAL_GREY):
+                losses = {}
+                self.compute_depth_losses_from_list(gts, preds_mono, losses, masks, obj)
+                self.log("test_mono" if obj == "all" else "test_mono_" + obj, None, None, losses, log_images=False)
+        self.set_train()
+
+    def compute_depth_losses(self, inputs, outputs, losses, mono=False):
+        """trainer.py:1311-1355."""
+        depth_pred = outputs[("depth", 0, 0)].detach().clamp(self.opt.min_depth, self.opt.max_depth)
+        depth_gt = inputs["depth_gt"]
+        mask = (depth_gt > self.opt.min_depth) * (depth_gt < self.opt.max_depth)
+        errs = compute_depth_errors(depth_gt[mask], depth_pred[mask])
+        for i, metric in enumerate(self.depth_metric_names):
+            losses[metric] = np.array(errs[i].cpu())
+
+    def compute_depth_losses_from_list(self, gts, preds, losses, masks, object="all"):
+        """trainer.py:1357-1434: per-image metrics, optionally restricted to one material class."""
+        errors = []
+        lo, hi = self.opt.min_depth, self.opt.max_depth
+        for k in range(len(preds)):
+            pred_b = preds[k].clamp(lo, hi)[:, 0].numpy()
+            gt_b = gts[k][:, 0].numpy()
+            m_b = masks[k][:, 0].numpy()
+            for b in range(pred_b.shape[0]):
+                mask = np.logical_and(gt_b[b] > lo, gt_b[b] < hi)
+                if object != "all":
+                    mask = np.logical_and(mask, m_b[b] == _MATERIAL_GREY[object])
+                if not mask.any():
+                    continue
+                errors.append(compute_depth_errors_numpy(gt_b[b][mask], np.clip(pred_b[b][mask], lo, hi)))
+        if not errors:
+            return
+        mean_errors = np.array(errors).mean(0)
+        print("\n  " + ("{:>8} | " * 7).format("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"))
+        print(("&{: 8.5f}  " * 7).format(*mean_errors.tolist()) + "\\\\")
+        for i, metric in enumerate(self.depth_metric_names):
+            losses[metric] = np.array(mean_errors[i])
+
+    # ------------------------------------------------------------------ logging
+    def log_time(self, batch_idx, duration, loss):
+        samples_per_sec = self.opt.batch_size / duration
+        time_sofar = time.time() - self.start_time
+        left = (self.num_total_steps / self.step - 1.0) * time_sofar if self.step > 0 else 0
+        if self.rank == 0:
+            print("epoch {:>3} | batch {:>6} | examples/s: {:5.1f} | loss: {:.5f} | time elapsed: {} | time left: {}".format(
+                self.epoch, batch_idx, samples_per_sec, float(loss), sec_to_hm_str(time_sofar), sec_to_hm_str(left)))
+
+    def log(self, mode, inputs, outputs, losses, log_images=True, log_essential_images=False, mono_depth=False):
+        writer = self.writers[mode]
+        for l, v in losses.items():
+            try:
+                writer.add_scalar("{}".format(l), float(v), self.step)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ checkpoints (trainer.py:1586-1691)
+    def save_opts(self):
+        models_dir = os.path.join(self.log_path, "models")
+        os.makedirs(models_dir, exist_ok=True)
+        with open(os.path.join(models_dir, 'opt.json'), 'w') as f:
+            json.dump(self.opt.__dict__.copy(), f, indent=2)
+
+    def save_model(self):
+        save_folder = os.path.join(self.log_path, "models", "weights_{}".format(self.epoch))
+        os.makedirs(save_folder, exist_ok=True)
+        for model_name, model in self.models.items():
+            sd = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
+            torch.save(sd, os.path.join(save_folder, "{}.pth".format(model_name)))
+        torch.save(self.model_optimizer.state_dict(), os.path.join(save_folder, "adam.pth"))
+
+    def _load_into(self, name, path, strict=False):
+        model_dict = self.models[name].state_dict()
+        pretrained = torch.load(path, map_location="cpu")
+        pretrained = {k: v for k, v in pretrained.items() if k in model_dict}
+        model_dict.update(pretrained)
+        self.models[name].load_state_dict(model_dict, strict=strict)     # copies in place: flat-buffer views stay valid
+
+    def load_mono_model(self):
+        for n in ['rgb_encoder', 'mono_depth', 'normals_encoder', 'xolp_encoder', 'joint_encoder']:
+            path = os.path.join(self.opt.mono_weights_folder, "{}.pth".format(n))
+            if n in self.models and os.path.isfile(path):
+                self._load_into(n, path, strict=True)
+
+    def load_model(self):
+        folder = os.path.expanduser(self.opt.load_weights_folder)
+        assert os.path.isdir(folder), "Cannot find folder {}".format(folder)
+        names = [n for n in self.opt.models_to_load if n in self.models] or list(self.models)
+        for n in names:
+            path = os.path.join(folder, "{}.pth".format(n))
+            if os.path.isfile(path):
+                self._load_into(n, path)
+        opt_path = os.path.join(folder, "adam.pth")
+        if os.path.isfile(opt_path):
+            try:
+                self.model_optimizer.load_state_dict(torch.load(opt_path, map_location=self.device))
+            except (ValueError, KeyError):
+                print("Can't load Adam - using random")

@@ -1,0 +1,197 @@
+"""Parameter store, fused Adam and the data-parallel gradient reducer.
+
+* ``ParamStore`` flattens every parameter of the model dict into one fp32 buffer (and one gradient
+  buffer of the same layout), laid out in *backward completion order* so that contiguous buckets
+  become ready progressively.  Parameters become views (channels_last strides are kept), so
+  ``state_dict`` / ``load_state_dict`` / checkpoints work unchanged.
+* ``FusedAdam`` = torch.optim.Adam semantics (trainer.py:238) as one kernel over the flat buffer.
+* ``GradReducer`` = one process per GPU; bucketed RCCL all-reduce of the flat gradient over xGMI on a
+  side stream, launched as soon as the kernels have written the last gradient of a bucket, overlapped
+  with the rest of backward; the 1/world_size scaling is folded into the Adam kernel.
+  The reference has no distributed code: this component is new.
+"""
+import torch
+import torch.distributed as dist
+
+from ._lib import lib, check, ptr, stream_ptr
+
+
+class ParamStore:
+    def __init__(self, models, order=None, unused=lambda model_name, param_name: False, device=None):
+        names = list(order) if order is not None else list(models.keys())
+        fwd, tail = [], []
+        for mn in names:
+            for pn, p in models[mn].named_parameters():
+                (tail if unused(mn, pn) else fwd).append((f"{mn}.{pn}", p))
+        used = list(reversed(fwd))             # backward completion order
+        self.entries = used + tail
+        self.n_used_params = len(used)
+        device = device or self.entries[0][1].device
+        align = 4                              # keep every parameter 16-byte aligned
+        offs, total = [], 0
+        for _, p in self.entries:
+            offs.append(total)
+            total += (p.numel() + align - 1) // align * align
+        self.numel = total
+        self.n_used = offs[self.n_used_params] if self.n_used_params < len(offs) else total
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.offsets = {}
+        for (name, p), off in zip(self.entries, offs):
+            self.offsets[name] = (off, p.numel())
+            self._adopt(p, off)
+
+    def _view(self, buf, p, off):
+        flat = buf[off:off + p.numel()]
+        if p.dim() == 4 and p.data.is_contiguous(memory_format=torch.channels_last) and not p.data.is_contiguous():
+            co, ci, kh, kw = p.shape
+            return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat.view(p.shape)
+
+    def _adopt(self, p, off):
+        src = p.data
+        if p.dim() == 4:
+            src = src.contiguous(memory_format=torch.channels_last)
+            pv = self.flat[off:off + p.numel()].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+            gv = self.grad[off:off + p.numel()].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+        else:
+            pv = self.flat[off:off + p.numel()].view(p.shape)
+            gv = self.grad[off:off + p.numel()].view(p.shape)
+        pv.copy_(src.to(self.flat.device))
+        p.data = pv
+        p.grad = gv
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def used_params(self):
+        return [p for _, p in self.entries[:self.n_used_params]]
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr) semantics over a ParamStore, one kernel per step."""
+
+    def __init__(self, store, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, reducer=None):
+        self.store = store
+        self.reducer = reducer
+        params = [p for _, p in store.entries]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.exp_avg = torch.zeros_like(store.flat)
+        self.exp_avg_sq = torch.zeros_like(store.flat)
+        self.step_count = 0
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=False):
+        self.store.zero_grad()
+        if self.reducer is not None:
+            self.reducer.reset()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self.reducer is not None:
+            self.reducer.finish()
+        g = self.param_groups[0]
+        self.step_count += 1
+        n = self.store.n_used
+        b1, b2 = g["betas"]
+        check(lib.pd_adam_step(ptr(self.store.flat), ptr(self.store.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n,
+                               float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
+                               self.step_count, float(self.grad_scale), stream_ptr()), "pd_adam_step")
+
+    # ---- checkpoint interop with torch.optim.Adam ("adam.pth", trainer.py:1614-1617)
+    def state_dict(self):
+        state, ids = {}, []
+        for i, (name, p) in enumerate(self.store.entries):
+            ids.append(i)
+            if i < self.store.n_used_params and self.step_count > 0:
+                off, n = self.store.offsets[name]
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.store._view(self.exp_avg, p, off).clone(),
+                            "exp_avg_sq": self.store._view(self.exp_avg_sq, p, off).clone()}
+        g = dict(self.param_groups[0]); g["params"] = ids
+        return {"state": state, "param_groups": [g], "pd_order": [n for n, _ in self.store.entries]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            if k in g:
+                self.param_groups[0][k] = g[k]
+        names = sd.get("pd_order", [n for n, _ in self.store.entries])
+        steps = []
+        for i, st in sd["state"].items():
+            name = names[int(i)]
+            if name not in self.store.offsets:
+                continue
+            off, n = self.store.offsets[name]
+            p = dict(self.store.entries)[name]
+            self.store._view(self.exp_avg, p, off).copy_(st["exp_avg"])
+            self.store._view(self.exp_avg_sq, p, off).copy_(st["exp_avg_sq"])
+            steps.append(int(float(st["step"])))
+        self.step_count = max(steps) if steps else 0
+
+
+class GradReducer:
+    """Bucketed, overlapped all-reduce (sum) of ``store.grad[:n_used]``; scale is applied by Adam."""
+
+    def __init__(self, store, bucket_bytes=16 << 20, process_group=None):
+        self.store = store
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = []            # (start, end)
+        self.bucket_of = {}
+        cap = max(bucket_bytes // 4, 1)
+        start, cur = 0, 0
+        idx = 0
+        for name, p in store.entries[:store.n_used_params]:
+            off, n = store.offsets[name]
+            if off + n - start > cap and off > start:
+                self.buckets.append((start, off)); start = off; idx += 1
+            self.bucket_of[id(p)] = idx
+            cur = off + n
+            p._pd_grad_ready = (lambda pp=p: self.mark_ready(pp))
+        self.buckets.append((start, store.n_used))
+        self.counts = [0] * len(self.buckets)
+        for name, p in store.entries[:store.n_used_params]:
+            self.counts[self.bucket_of[id(p)]] += 1
+        self.cuda = store.grad.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=store.grad.device) if self.cuda and self.world > 1 else None
+        self.reset()
+
+    def reset(self):
+        self.pending = list(self.counts)
+        self.seen = set()
+        self.launched = [False] * len(self.buckets)
+        self.works = []
+
+    def mark_ready(self, p):
+        if self.world == 1 or id(p) in self.seen:
+            return
+        self.seen.add(id(p))
+        b = self.bucket_of[id(p)]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self.launched[b]:
+            return
+        self.launched[b] = True
+        s, e = self.buckets[b]
+        view = self.store.grad[s:e]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        if self.world == 1:
+            return
+        for b in range(len(self.buckets)):       # buckets holding a parameter that got no gradient this step
+            self._launch(b)
+        for w in self.works:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.works = []

@@ -1,0 +1,136 @@
+"""One full training step (K1 -> 3 encoders -> joint -> decoder -> K5 loss -> backward -> fused Adam)
+through the Trainer façade vs the CPU oracle with identical weights and batch (dropout 0, BN in
+training mode).  Tolerance: loss 1e-4 relative (north_star); gradients 2e-3 of each tensor's scale."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+sys.path.insert(0, GOLDEN)
+from synth_weights import fill_state_dict  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _opts(tmp, extra=()):
+    from manydepth.options import MonodepthOptions
+    return MonodepthOptions().parse([
+        "--png", "--batch_size", "2", "--height", "64", "--width", "96", "--dataset", "HAMMER", "--split", "HAMMER",
+        "--eval_split", "HAMMER_unseen", "--min_depth", "0.1", "--max_depth", "2.0", "--depth_supervision_only", "True",
+        "--depth_supervision", "True", "--normals_loss_weight", "0.35", "--augment_xolp", "--augment_normals",
+        "--log_dir", str(tmp), "--data_path", "synthetic", "--data_path_val", "synthetic", "--num_workers", "0",
+        "--weights_init", "scratch", "--learning_rate", "1e-4", *extra])
+
+
+def test_one_training_step_matches_oracle(tmp_path):
+    from manydepth.trainer import Trainer
+    from polardepth import synthetic
+    from oracle import nets as onets, losses as ol, polar as opolar
+    tr = Trainer(_opts(tmp_path, ["--dropout_rate", "0.0"]))
+    ref = onets.build_models(True, True, 0.0)
+    for name, m in ref.items():
+        fill_state_dict(m, 0, prefix=name + ".")
+        tr.models[name].load_state_dict(m.state_dict())
+        m.train()
+    tr.set_train()
+    batch = synthetic.make_batch(2, 64, 96, frame_w=92, device="cuda", seed=5)
+    cpu = {k: v.cpu() for k, v in batch.items()}
+
+    tr.model_optimizer.zero_grad()
+    outputs, losses, _ = tr.process_batch(dict(batch), is_train=True)
+    losses["loss"].backward()
+    gpu_grads = {n: p.grad.detach().cpu().clone() for mn in tr.models for n, p in
+                 ((f"{mn}.{k}", v) for k, v in tr.models[mn].named_parameters())}
+    before = tr.store.flat.clone()
+    tr.model_optimizer.step()
+    torch.cuda.synchronize()
+
+    # ---- oracle
+    xolp, _, _, _ = opolar.polar_forward(cpu[("pol", 0, 0)].numpy())
+    assert torch.equal(batch[("xolp", 0, 0)].cpu() if ("xolp", 0, 0) in batch else xolp, xolp)
+    outs = onets.forward_models(ref, cpu[("color_aug", 0, 0)], xolp)
+    ro = dict(outs)
+    for s in range(4):
+        ro[("depth", 0, s)] = ol.upsample_disp_to_depth(outs[("disp", s)], 64, 96, 0.1, 2.0)
+    L = ol.compute_losses(cpu, ro, normals_loss_weight=0.35)
+    L["loss"].backward()
+
+    for s in range(4):
+        d = outputs[("disp", s)].detach().cpu()
+        assert (d - outs[("disp", s)].detach()).abs().max().item() < 2e-5, f"disp {s}"
+    rel = abs(losses["loss"].item() - L["loss"].item()) / abs(L["loss"].item())
+    assert rel < 1e-4, (losses["loss"].item(), L["loss"].item())
+    for k in ("loss/0", "loss/3", "supervised_depth_loss/1"):
+        assert abs(losses[k].item() - L[k].item()) <= 1e-4 * abs(L[k].item())
+    checked = 0
+    for mn, m in ref.items():
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            g = gpu_grads[f"{mn}.{k}"]
+            if k.endswith("conv.bias") and mn != "mono_depth":
+                continue                     # bias in front of BatchNorm: exact 0 here, rounding noise in torch
+            scale = p.grad.abs().max().item() + 1e-12
+            assert (g - p.grad).abs().max().item() <= 2e-3 * scale, f"{mn}.{k}"
+            checked += 1
+    assert checked > 150
+    # unused resnet parameters keep a zero gradient and are not touched by Adam
+    assert gpu_grads["rgb_encoder.encoder.layer4.1.conv2.weight"].abs().max().item() == 0
+    off, n = tr.store.offsets["rgb_encoder.encoder.fc.weight"]
+    assert torch.equal(tr.store.flat[off:off + n], before[off:off + n])
+    # Adam first step: every used parameter with a non-negligible gradient moves by ~lr against its sign
+    off, n = tr.store.offsets["mono_depth.decoder.0.conv.conv.weight"]
+    delta = (tr.store.flat[off:off + n] - before[off:off + n]).cpu()
+    g = tr.store.grad[off:off + n].cpu()
+    big = g.abs() > 1e-6
+    assert torch.allclose(delta[big], -1e-4 * torch.sign(g[big]), atol=2e-6)
+
+
+def test_checkpoint_roundtrip_and_eval_mode(tmp_path):
+    from manydepth.trainer import Trainer
+    from polardepth import synthetic
+    tr = Trainer(_opts(tmp_path))
+    batch = synthetic.make_batch(2, 64, 96, frame_w=92, device="cuda", seed=6)
+    tr.set_train()
+    tr.model_optimizer.zero_grad()
+    _, losses, _ = tr.process_batch(dict(batch), is_train=True)
+    losses["loss"].backward()
+    tr.model_optimizer.step()
+    tr.save_model()
+    folder = os.path.join(tr.log_path, "models", "weights_0")
+    assert sorted(os.listdir(folder)) == ["adam.pth", "joint_encoder.pth", "mono_depth.pth", "normals_encoder.pth",
+                                          "rgb_encoder.pth", "xolp_encoder.pth"]
+    sd = torch.load(os.path.join(folder, "rgb_encoder.pth"))
+    assert "encoder.layer4.1.bn2.running_var" in sd and sd["encoder.conv1.weight"].is_contiguous()
+    tr.set_eval()
+    with torch.no_grad():
+        out1, l1, _ = tr.process_batch(dict(batch))
+    opts2 = _opts(tmp_path, ["--load_weights_folder", folder, "--models_to_load", "rgb_encoder", "xolp_encoder",
+                             "normals_encoder", "joint_encoder", "mono_depth"])
+    tr2 = Trainer(opts2)
+    tr2.set_eval()
+    with torch.no_grad():
+        out2, l2, _ = tr2.process_batch(dict(batch))
+    assert torch.equal(out1[("disp", 0)], out2[("disp", 0)]) and torch.equal(l1["loss"], l2["loss"])
+    assert tr2.model_optimizer.step_count == 1
+    assert torch.equal(tr2.model_optimizer.exp_avg, tr.model_optimizer.exp_avg)
+
+
+def test_dropout_is_deterministic_per_seed_and_matches_backward(tmp_path):
+    from polardepth import functional as PF
+    from manydepth.networks.pre_encoders import ConvBlock
+    torch.manual_seed(0)
+    blk = ConvBlock(64, 64, 3, 'none', 1, 0.3).cuda().train()
+    x = torch.randn(2, 64, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    PF.DropoutState.manual_seed(123)
+    y1 = blk(x)
+    PF.DropoutState.manual_seed(123)
+    y2 = blk(x)
+    assert torch.equal(y1, y2)
+    frac = (y1 == 0).float().mean().item()
+    assert 0.55 < frac < 0.75          # relu zeros (~50%) + 30% dropout of the rest
+    y1.sum().backward()
+    assert torch.isfinite(x.grad).all()
