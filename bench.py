@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: training images/s of the 3-encoder polarimetric depth network.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = zero_grad + K1 polar preprocessing + 3 encoders + joint encoder + decoder + multi-scale
+loss + backward + fused Adam on one synthetic HAMMER-shaped batch that is already resident in HBM.
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): full 3-encoder net
+(augment_xolp + augment_normals), scales [0,1,2,3], batch 16 per GPU, 512x612 frames -- the polar
+kernel runs on the true 512x612 planes, network and loss on 512x640 (28 zero-padded, mask-invalid
+columns; the reference itself cannot run W=612, trainer.py:107-108); images/s counts frames.
+Weak scaling: every rank processes its own batch of 16; gradients are all-reduced with RCCL.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (fp32-MFMA implicit-GEMM conv), algorithmic FLOPs / HIP-event time
+                  of its launches in instrumented steps of the same workload, vs the 157.3 TFLOP/s fp32
+                  matrix peak (MI355X_MICROARCH.md);
+  cpu_baseline -- the CPU oracle (oracle/: plain PyTorch-CPU restatement of the reference) timed on
+                  this box's host cores on a bounded sample (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "supervised-depth-estimation-from-polarized-images_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H, W, FRAME_W, BATCH = 512, 640, 612, 16
+FP32_MFMA_PEAK_TF = 157.3
+
+
+def build_trainer(batch, height, width, log_dir):
+    from manydepth.options import MonodepthOptions
+    from manydepth.trainer import Trainer
+    opts = MonodepthOptions().parse([
+        "--png", "--batch_size", str(batch), "--height", str(height), "--width", str(width), "--dataset", "HAMMER",
+        "--split", "HAMMER", "--eval_split", "HAMMER_unseen", "--min_depth", "0.1", "--max_depth", "2.0",
+        "--disparity_smoothness", "1e-3", "--depth_supervision_only", "True", "--depth_supervision", "True",
+        "--normals_loss_weight", "0.35", "--augment_xolp", "--augment_normals", "--learning_rate", "1e-4",
+        "--weights_init", "scratch", "--num_workers", "0", "--log_dir", log_dir, "--data_path", "synthetic",
+        "--data_path_val", "synthetic", "--model_name", "bench"])
+    return Trainer(opts)
+
+
+def train_step(tr, batch):
+    tr.model_optimizer.zero_grad()
+    _, losses, _ = tr.process_batch(dict(batch), is_train=True)
+    losses["loss"].backward()
+    tr.model_optimizer.step()
+    return losses["loss"]
+
+
+def cpu_baseline(sample_batch=2, steps=1):
+    """Oracle train step (fwd + loss + bwd + Adam) on the host cores; bounded sample of the same workload."""
+    import numpy as np
+    from oracle import nets as onets, losses as ol, polar as opolar
+    torch.manual_seed(0)
+    models = onets.build_models(True, True, 0.1)
+    params = [p for m in models.values() for p in m.parameters()]
+    opt = torch.optim.Adam(params, 1e-4)
+    for m in models.values():
+        m.train()
+    rng = np.random.default_rng(0)
+    pol = rng.integers(0, 256, (sample_batch, 4, H, FRAME_W), dtype=np.uint8)
+    color = torch.rand(sample_batch, 3, H, W)
+    inputs = {("color", 0, 0): color}
+    for s in range(1, 4):
+        inputs[("color", 0, s)] = torch.nn.functional.avg_pool2d(inputs[("color", 0, s - 1)], 2)
+    gt = 0.3 + 1.5 * torch.rand(sample_batch, 1, H, W)
+    gt[..., FRAME_W:] = 0
+    K = torch.eye(4)[None].repeat(sample_batch, 1, 1)
+    K[:, 0, 0] = K[:, 1, 1] = 0.65 * W; K[:, 0, 2] = W / 2; K[:, 1, 2] = H / 2
+    inputs["depth"] = gt; inputs[("K", 0)] = K
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        opt.zero_grad()
+        xolp, _, _, _ = opolar.polar_forward(pol)                       # DataLoader-side XOLP of the reference
+        xolp = torch.nn.functional.pad(xolp, (0, W - FRAME_W))
+        outs = dict(onets.forward_models(models, color, xolp))          # includes the scipy normals bounce
+        for s in range(4):
+            outs[("depth", 0, s)] = ol.upsample_disp_to_depth(outs[("disp", s)], H, W, 0.1, 2.0)
+        L = ol.compute_losses(inputs, outs, normals_loss_weight=0.35)
+        L["loss"].backward()
+        opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_batch * steps / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} step(s) of the same 3-encoder 512x640 train step at batch {sample_batch} "
+                      f"(oracle/: PyTorch-CPU + NumPy restatement, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")         # RCCL
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from polardepth import synthetic, ops
+    from polardepth import functional as PF
+    log_dir = tempfile.mkdtemp(prefix="pd_bench_")
+    tr = build_trainer(args.batch, H, W, log_dir)
+    tr.set_train()
+    PF.DropoutState.manual_seed(1234 + rank)
+    batch = synthetic.make_batch(args.batch, H, W, frame_w=FRAME_W, device=f"cuda:{local_rank}", seed=rank)
+    batch[("pol", 0, 0)] = batch[("pol", 0, 0)][..., :FRAME_W].contiguous()      # true 512x612 planes for K1
+    batch.pop("depth_gt"); batch.pop(("mask", 0, 0))
+
+    for _ in range(args.warmup):
+        train_step(tr, batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(tr, batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_val = float(loss)
+
+    # ---- roofline of the dominant kernel: instrumented steps of the same workload (HIP events on the
+    # launch stream around every implicit-GEMM conv launch), outside the timed region
+    ops.PROFILE = []
+    for _ in range(2):
+        train_step(tr, batch)
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    by_kernel = {}
+    for name, flops, e0, e1 in prof:
+        k = by_kernel.setdefault(name, [0.0, 0.0, 0])
+        k[0] += flops; k[1] += e0.elapsed_time(e1) * 1e-3; k[2] += 1
+    dom = max(by_kernel.items(), key=lambda kv: kv[1][1])
+    dname, (dflops, dtime, dcount) = dom
+    achieved = dflops / dtime / 1e12
+    step_conv_time = sum(v[1] for v in by_kernel.values()) / 2
+    roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "launches_per_step": dcount // 2, "avg_launch_ms": round(dtime / dcount * 1e3, 4),
+                "all_conv_kernels_ms_per_step": round(step_conv_time * 1e3, 2),
+                "all_conv_kernels_TFLOPs": round(sum(v[0] for v in by_kernel.values()) / 2 /
+                                                 max(step_conv_time, 1e-9) / 1e12, 2)}
+
+    result = {
+        "metric": "train images/sec (512x612, 3-encoder)", "value": round(args.batch * world * args.steps / dt, 3),
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: full 3-encoder (augment_xolp+augment_normals), multi-scale loss "
+                               "scales=[0,1,2,3], batch 16 per GPU, 512x612 frames (network/loss on 512x640 padded), "
+                               "dropout 0.1, Adam lr 1e-4, fp32",
+                   "global_batch": args.batch * world, "height": H, "width": W, "frame_width": FRAME_W,
+                   "parallelism": f"dp{world}"},
+        "final_loss": round(loss_val, 6), "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,11 +72,14 @@ int pd_polar_tables_build(double n, void* host_blob, size_t blob_bytes, size_t* 
  * normals    [B,9,H,W] fp32 or NULL   cat(N_diff, N_spec1, N_spec2)   == get_normals(xolp).float()
  * ints       [B,5,H,W] int32 or NULL  exact by-products: d1, d2, idx_diffuse, idx_spec1, idx_spec2
  * tables     device copy of the blob
- * H*W must be a multiple of 4; all pointers 16-byte aligned.
+ * Wout    row pitch (in pixels) of every OUTPUT plane, Wout >= W (0 means W).  Wout > W writes the
+ *         W real columns and zero-fills the Wout-W padding columns: the 512x612 HAMMER planes land
+ *         directly in the 512x640 tensors the network needs (multiples of 32, trainer.py:107-108).
+ * H*W must be a multiple of 4 (W and Wout multiples of 4 when they differ); pointers 16-byte aligned.
  */
 int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, void* normals,
                  void* ints, const void* tables, size_t tables_bytes,
-                 int B, int H, int W, int mode, void* stream);
+                 int B, int H, int W, int Wout, int mode, void* stream);
 
 /* get_normals() on an existing fp32 XOLP tensor (pre_encoders.py:99-113, the path taken when a
  * data loader already produced inputs[("xolp",0,0)]): xolp [B,2,H,W] -> normals [B,9,H,W]. */

@@ -260,7 +260,7 @@ template <int MODE, bool NORMALS>
 __global__ __launch_bounds__(kThreads) void polar_kernel(
     const uint8_t* __restrict__ pol, const uint8_t* __restrict__ mask, float* __restrict__ xolp,
     float* __restrict__ xolp_std, float* __restrict__ normals, int* __restrict__ ints,
-    const char* __restrict__ blob, long P, long quads_per_img, long total_quads) {
+    const char* __restrict__ blob, long P, long Pout, int wq_in, int wq_out, long quads_per_img, long total_quads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
     const float* lut = reinterpret_cast<const float*>(blob + h->off_lut);
@@ -271,7 +271,21 @@ __global__ __launch_bounds__(kThreads) void polar_kernel(
 
     for (long q = blockIdx.x * (long)kThreads + threadIdx.x; q < total_quads; q += (long)gridDim.x * kThreads) {
         const long b = q / quads_per_img;
-        const long p4 = (q - b * quads_per_img) * 4;  // first pixel of the quad inside its plane
+        const long ro = q - b * quads_per_img;          // quad index inside the (pitched) output plane
+        const long row = ro / wq_out;
+        const int cq = (int)(ro - row * wq_out);
+        const long po = ro * 4;                          // first output pixel of the quad
+        if (cq >= wq_in) {                               // right padding columns of a pitched output: zeros
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xolp) { *reinterpret_cast<float4*>(xolp + (b * 2) * Pout + po) = z; *reinterpret_cast<float4*>(xolp + (b * 2 + 1) * Pout + po) = z; }
+            if (xolp_std) { *reinterpret_cast<float4*>(xolp_std + (b * 2) * Pout + po) = z; *reinterpret_cast<float4*>(xolp_std + (b * 2 + 1) * Pout + po) = z; }
+            if (NORMALS && normals)
+                for (int c = 0; c < 9; ++c) *reinterpret_cast<float4*>(normals + (b * 9 + c) * Pout + po) = z;
+            if (ints)
+                for (int c = 0; c < (NORMALS ? 5 : 2); ++c) *reinterpret_cast<int4*>(ints + (b * 5 + c) * Pout + po) = make_int4(0, 0, 0, 0);
+            continue;
+        }
+        const long p4 = (row * wq_in + cq) * 4;          // first input pixel of the quad inside its plane
         const uint8_t* pb = pol + (b * 4) * P + p4;
         const uint32_t w0 = *reinterpret_cast<const uint32_t*>(pb);
         const uint32_t w45 = *reinterpret_cast<const uint32_t*>(pb + P);
@@ -304,29 +318,29 @@ __global__ __launch_bounds__(kThreads) void polar_kernel(
             }
         }
         if (xolp) {
-            float* o = xolp + (b * 2) * P + p4;
+            float* o = xolp + (b * 2) * Pout + po;
             *reinterpret_cast<float4*>(o) = make_float4(o_rho[0], o_rho[1], o_rho[2], o_rho[3]);
-            *reinterpret_cast<float4*>(o + P) = make_float4(o_phi[0], o_phi[1], o_phi[2], o_phi[3]);
+            *reinterpret_cast<float4*>(o + Pout) = make_float4(o_phi[0], o_phi[1], o_phi[2], o_phi[3]);
         }
         if (xolp_std) {
-            float* o = xolp_std + (b * 2) * P + p4;
+            float* o = xolp_std + (b * 2) * Pout + po;
             *reinterpret_cast<float4*>(o) = make_float4((o_rho[0] - kMean) / kStd, (o_rho[1] - kMean) / kStd,
                                                         (o_rho[2] - kMean) / kStd, (o_rho[3] - kMean) / kStd);
-            *reinterpret_cast<float4*>(o + P) = make_float4((o_phi[0] - kMean) / kStd, (o_phi[1] - kMean) / kStd,
+            *reinterpret_cast<float4*>(o + Pout) = make_float4((o_phi[0] - kMean) / kStd, (o_phi[1] - kMean) / kStd,
                                                             (o_phi[2] - kMean) / kStd, (o_phi[3] - kMean) / kStd);
         }
         if (NORMALS && normals) {
-            float* o = normals + (b * 9) * P + p4;
+            float* o = normals + (b * 9) * Pout + po;
 #pragma unroll
             for (int c = 0; c < 9; ++c)
-                *reinterpret_cast<float4*>(o + c * P) = make_float4(o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
+                *reinterpret_cast<float4*>(o + c * Pout) = make_float4(o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
         }
         if (ints) {
-            int* o = ints + (b * 5) * P + p4;
+            int* o = ints + (b * 5) * Pout + po;
             const int nch = NORMALS ? 5 : 2;
 #pragma unroll
             for (int c = 0; c < 5; ++c)
-                if (c < nch) *reinterpret_cast<int4*>(o + c * P) = make_int4(o_i[c][0], o_i[c][1], o_i[c][2], o_i[c][3]);
+                if (c < nch) *reinterpret_cast<int4*>(o + c * Pout) = make_int4(o_i[c][0], o_i[c][1], o_i[c][2], o_i[c][3]);
         }
     }
 }
@@ -382,20 +396,25 @@ extern "C" int pd_polar_normals_from_xolp(const void* xolp, void* normals, const
 }
 
 extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, void* normals,
-                            void* ints, const void* tables, size_t tables_bytes, int B, int H, int W, int mode,
-                            void* stream) {
+                            void* ints, const void* tables, size_t tables_bytes, int B, int H, int W, int Wout,
+                            int mode, void* stream) {
     PD_REQUIRE(B >= 0 && H > 0 && W > 0, "pd_polar_fwd: bad shape B=%d H=%d W=%d", B, H, W);
-    if (B == 0 && (long)H * W % 4 == 0) return PD_OK;  // empty batch: nothing to do (pointers may be null)
+    if (B == 0) return PD_OK;  // empty batch: nothing to do (pointers may be null)
     PD_REQUIRE(pol && tables, "pd_polar_fwd: pol and tables must not be null");
     PD_REQUIRE(mode == PD_POLAR_LS || mode == PD_POLAR_STOKES, "pd_polar_fwd: unknown mode %d", mode);
     const long P = (long)H * W;
-    PD_REQUIRE(P % 4 == 0, "pd_polar_fwd: H*W=%ld must be a multiple of 4", P);
+    if (Wout <= 0) Wout = W;
+    PD_REQUIRE(Wout >= W, "pd_polar_fwd: output pitch %d < W %d", Wout, W);
+    PD_REQUIRE(Wout == W ? P % 4 == 0 : (W % 4 == 0 && Wout % 4 == 0),
+               "pd_polar_fwd: H*W (or W and the output pitch, when they differ) must be multiples of 4");
     PD_REQUIRE(tables_bytes >= sizeof(PolarHeader), "pd_polar_fwd: tables blob too small");
     PD_REQUIRE(pd::aligned16(pol) && pd::aligned16(xolp) && pd::aligned16(xolp_std) && pd::aligned16(normals) &&
                    pd::aligned16(ints) && pd::aligned16(tables) && (!mask || pd::aligned16(mask)),
                "pd_polar_fwd: pointers must be 16-byte aligned");
     PD_REQUIRE(xolp || xolp_std || normals || ints, "pd_polar_fwd: no output requested");
-    const long qpi = P / 4, total = qpi * B;
+    const long Pout = (long)H * Wout;
+    const int wq_in = Wout == W ? (int)(P / 4) : W / 4, wq_out = Wout == W ? (int)(P / 4) : Wout / 4;
+    const long qpi = Pout / 4, total = qpi * B;
     const bool need_normals = normals != nullptr || ints != nullptr;
     // LDS image size is fixed by the table node counts; validated against the blob size on the
     // host by the caller's pd_polar_tables_bytes(); the default tables need 56,000 bytes.
@@ -409,7 +428,7 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, st,
                            static_cast<const uint8_t*>(pol), static_cast<const uint8_t*>(mask),
                            static_cast<float*>(xolp), static_cast<float*>(xolp_std), static_cast<float*>(normals),
-                           static_cast<int*>(ints), static_cast<const char*>(tables), P, qpi, total);
+                           static_cast<int*>(ints), static_cast<const char*>(tables), P, Pout, wq_in, wq_out, qpi, total);
     };
     if (mode == PD_POLAR_LS) {
         if (need_normals) args(polar_kernel<PD_POLAR_LS, true>); else args(polar_kernel<PD_POLAR_LS, false>);

@@ -225,7 +225,10 @@ class Trainer:
         normals = None
         if ("pol", 0, 0) in inputs and (self.opt.augment_xolp or self.opt.augment_normals):
             want = ["xolp"] + (["normals"] if self.opt.augment_normals else [])
-            out = pdpolar.polar_forward(inputs[("pol", 0, 0)], want=tuple(want))
+            pol = inputs[("pol", 0, 0)]
+            # planes narrower than the network width (512x612 frames -> 512x640): K1 pads on the fly
+            out = pdpolar.polar_forward(pol, want=tuple(want),
+                                        out_width=self.opt.width if pol.shape[3] < self.opt.width else None)
             inputs[("xolp", 0, 0)] = out["xolp"]
             normals = out.get("normals")
         return normals

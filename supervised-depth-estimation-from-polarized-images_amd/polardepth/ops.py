@@ -11,6 +11,24 @@ from ._lib import lib, check, ptr, stream_ptr
 MODE_ZERO, MODE_REFLECT, MODE_TRANSPOSED = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 CL = torch.channels_last
+PROFILE = None      # bench.py sets this to a list: (kernel label, algorithmic flops, start event, end event)
+
+
+def _profiled(label, flops, fn):
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE.append((label, flops, e0, e1))
+    return r
+
+
+def _igemm_label(M, Co, vec, kind):
+    bm = lib.pd_conv2d_tile_m(M, Co)
+    bn = 64 if Co > 32 else 32
+    return f"conv_igemm_kernel<{bm},{bn},{'vec' if vec else 'scalar'}>"
 
 
 def _require_cuda(*ts):
@@ -67,9 +85,11 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
         stats = torch.empty((rows, Co, 2), dtype=torch.float32, device=x.device)
     sub, div = (affine if affine is not None else (0.0, 1.0))
     sN, sC, sH, sW = x.stride()
-    check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
-                        Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub, div, ldy,
-                        stream_ptr()), "pd_conv2d")
+    vec = C % 4 == 0 and sC == 1 and affine is None
+    _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd"), 2.0 * N * Ho * Wo * Co * C * KH * KW,
+              lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
+                                          Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub,
+                                          div, ldy, stream_ptr()), "pd_conv2d"))
     return (out, stats) if want_stats else out
 
 
@@ -94,9 +114,11 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None):
         wt = weight_transposed(w)
     dx = empty_nhwc(N, Ci, H, W, dy.device)
     sN, sC, sH, sW = dy.stride()
-    check(lib.pd_conv2d(ptr(dy), ptr(wt), None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,
-                        H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci,
-                        stream_ptr()), "pd_conv2d(dgrad)")
+    # algorithmic flops of the data gradient = those of the forward conv it differentiates
+    _profiled(_igemm_label(N * H * W, Ci, True, "dgrad"), 2.0 * N * Hy * Wy * Co * Ci * KH * KW,
+              lambda: check(lib.pd_conv2d(ptr(dy), ptr(wt), None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,
+                                          H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci,
+                                          stream_ptr()), "pd_conv2d(dgrad)"))
     return dx
 
 
@@ -132,8 +154,9 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
     ws = _workspace(nbytes, x.device)
     sub, div = (affine if affine is not None else (0.0, 1.0))
     sN, sC, sH, sW = x.stride()
-    check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), N, H, W, C,
-                              sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride, pad, mode,
-                              int(affine is not None), sub, div, dy.stride(3), int(accumulate), stream_ptr()),
-          "pd_conv2d_wgrad")
+    _profiled("conv_wgrad_kernel", 2.0 * M * Co * K,
+              lambda: check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), N, H, W, C,
+                                                sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride, pad, mode,
+                                                int(affine is not None), sub, div, dy.stride(3), int(accumulate),
+                                                stream_ptr()), "pd_conv2d_wgrad"))
     return (dw, dbias) if (want_bias or dbias is not None) else dw

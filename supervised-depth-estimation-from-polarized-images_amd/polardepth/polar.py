@@ -65,11 +65,12 @@ def _device_tables(n, device_index):
     return blob.to(torch.device("cuda", device_index))
 
 
-def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=None):
+def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=None, out_width=None):
     """Run K1 on ``pol`` [B,4,H,W] uint8 (planes 0/45/90/135 deg) on the GPU.
 
     want: any of "xolp", "xolp_std", "normals", "ints".  Returns a dict of fp32 NCHW tensors
-    ([B,2,H,W], [B,2,H,W], [B,9,H,W]) and the int32 [B,5,H,W] by-products.
+    ([B,2,H,W], [B,2,H,W], [B,9,H,W]) and the int32 [B,5,H,W] by-products.  out_width > W makes every
+    output [.., H, out_width] with the extra right columns zero (612 -> 640 padding for the network).
     """
     if not (isinstance(pol, torch.Tensor) and pol.is_cuda):
         raise RuntimeError("polar_forward needs a CUDA(HIP) uint8 tensor; there is no CPU fallback")
@@ -80,7 +81,8 @@ def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=No
     if tables is None:
         tables = _device_tables(float(n), pol.device.index)
     out = {}
-    mk = lambda c, dt=torch.float32: torch.empty((B, c, H, W), dtype=dt, device=pol.device)
+    Wout = W if out_width is None else int(out_width)
+    mk = lambda c, dt=torch.float32: torch.empty((B, c, H, Wout), dtype=dt, device=pol.device)
     if "xolp" in want:
         out["xolp"] = mk(2)
     if "xolp_std" in want:
@@ -94,7 +96,7 @@ def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=No
     with torch.cuda.device(pol.device):
         check(lib.pd_polar_fwd(ptr(pol), ptr(mask), ptr(out.get("xolp")), ptr(out.get("xolp_std")),
                                ptr(out.get("normals")), ptr(out.get("ints")), ptr(tables), tables.numel(),
-                               B, H, W, mode, stream_ptr()), "pd_polar_fwd")
+                               B, H, W, Wout, mode, stream_ptr()), "pd_polar_fwd")
     return out
 
 

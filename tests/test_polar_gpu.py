@@ -140,3 +140,15 @@ def test_full_size_properties():
     xolp, _, normals, _ = opolar.polar_forward(stripe)
     assert torch.equal(full["xolp"][3, :, 100:164], xolp[0])
     np.testing.assert_allclose(full["normals"][3, :, 100:164].numpy(), normals[0].numpy(), rtol=0, atol=NORMALS_ATOL)
+
+
+def test_pitched_output_zero_pads_right_columns():
+    """512x612-style planes written straight into a wider (multiple-of-32) tensor."""
+    rng = np.random.default_rng(8)
+    pol = rng.integers(0, 256, (2, 4, 16, 36), dtype=np.uint8)
+    ref = _run(pol, want=("xolp", "normals", "xolp_std"))
+    got = pdpolar.polar_forward(torch.from_numpy(pol).cuda(), want=("xolp", "normals", "xolp_std"), out_width=64)
+    for k in ("xolp", "normals", "xolp_std"):
+        g = got[k].cpu()
+        assert g.shape[-1] == 64
+        assert torch.equal(g[..., :36], ref[k]) and g[..., 36:].abs().max().item() == 0
