@@ -85,7 +85,7 @@ def test_random_uint8_and_degenerate():
 def test_empty_batch_and_bad_shapes():
     out = pdpolar.polar_forward(torch.zeros((0, 4, 8, 8), dtype=torch.uint8, device="cuda"), want=("xolp",))
     assert out["xolp"].shape == (0, 2, 8, 8)
-    with pytest.raises(Exception, match="multiple of 4"):
+    with pytest.raises(Exception, match="multiples of 4"):
         pdpolar.polar_forward(torch.zeros((1, 4, 3, 3), dtype=torch.uint8, device="cuda"))
     with pytest.raises(ValueError):
         pdpolar.polar_forward(torch.zeros((1, 3, 4, 4), dtype=torch.uint8, device="cuda"))
