@@ -284,7 +284,42 @@ def make_loss():
     print("loss goldens written:", len(out), "arrays")
 
 
-GROUPS = {"polar": make_polar, "nets": make_nets, "loss": make_loss}
+# ------------------------------------------------------------------ group: options
+SCRIPT_FLAGS = ["--png", "--num_depth_bins", "96", "--num_workers", "8", "--batch_size", "12",
+                "--data_path", "/data/HAMMER/train/", "--data_path_val", "/data/HAMMER/test_unseen/",
+                "--log_dir", "/tmp/exp", "--num_epochs", "50", "--scheduler_step_size", "15",
+                "--freeze_teacher_epoch", "50", "--learning_rate", "1e-4", "--width", "480", "--height", "320",
+                "--dataset", "HAMMER", "--split", "HAMMER", "--eval_split", "HAMMER_unseen", "--min_depth", "0.1",
+                "--max_depth", "2.0", "--disparity_smoothness", "1e-3", "--offset", "10",
+                "--no_matching_augmentation", "--depth_supervision_only", "True", "--depth_supervision", "True",
+                "--modality", "polarization", "--depth_modality", "_gt", "--normals_loss_weight", "0.35",
+                "--model_name", "ABLATIONS_rgb_xolp_normals", "--augment_xolp", "--augment_normals"]
+
+
+def make_options():
+    """Defaults and the train_supervised_GT.sh command line through the reference's own argparse."""
+    import json
+    _ref_imports()
+    spec = importlib.util.spec_from_file_location("ref_options", os.path.join(REF, "manydepth", "options.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = sys.argv
+    try:
+        sys.argv = ["x"]
+        defaults = vars(mod.MonodepthOptions().parse())
+        sys.argv = ["x"] + SCRIPT_FLAGS
+        script = vars(mod.MonodepthOptions().parse())
+        sys.argv = ["x", "--depth_supervision_only", "False"]
+        quirk = vars(mod.MonodepthOptions().parse())["depth_supervision_only"]
+    finally:
+        sys.argv = old
+    with open(os.path.join(OUT, "g6_options.json"), "w") as f:
+        json.dump({"defaults": defaults, "script_flags": SCRIPT_FLAGS, "script": script,
+                   "bool_quirk_False_string": quirk}, f, indent=1, sort_keys=True)
+    print("options golden written:", len(defaults), "flags")
+
+
+GROUPS = {"polar": make_polar, "nets": make_nets, "loss": make_loss, "options": make_options}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

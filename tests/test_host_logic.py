@@ -1,0 +1,101 @@
+"""Host-side logic that needs no GPU: CLI contract vs the reference's own argparse (fixture),
+parameter store layout, checkpoint key names, façade import surface."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def test_options_match_reference_argparse():
+    from manydepth.options import MonodepthOptions
+    g = json.load(open(os.path.join(GOLDEN, "g6_options.json")))
+    mine = vars(MonodepthOptions().parse([]))
+    assert mine == g["defaults"]
+    script = vars(MonodepthOptions().parse(g["script_flags"]))
+    assert script == g["script"]
+    # the reference's type=bool quirk: any non-empty string is True (options.py:33-86)
+    assert MonodepthOptions().parse(["--depth_supervision_only", "False"]).depth_supervision_only is True
+    assert g["bool_quirk_False_string"] is True
+
+
+def test_facade_import_surface():
+    import manydepth.networks as nw
+    for name in ("ShallowResnetEncoder", "ShallowEncoder", "ShallowNormalsEncoder", "JointEncoder", "DepthDecoder",
+                 "ResnetEncoder", "ResnetEncoderMatching", "PoseDecoder", "PoseCNN"):
+        assert hasattr(nw, name)
+    with pytest.raises(NotImplementedError):
+        nw.PoseCNN(2)
+    import manydepth.layers as L
+    for name in ("disp_to_depth", "ConvBlock", "Conv3x3", "upsample", "get_smooth_loss", "SSIM",
+                 "compute_depth_errors", "compute_depth_errors_numpy"):
+        assert hasattr(L, name)
+    import manydepth.normals_vec as nv
+    assert all(hasattr(nv, n) for n in ("rho_diffuse", "rho_spec", "calc_normals"))
+    from polarisation.xolp import Iun_and_xolp  # noqa: F401
+    from manydepth.trainer import Trainer
+    for m in ("train", "run_epoch", "process_batch", "compute_losses", "compute_supervised_normals_losses", "val",
+              "test", "set_train", "set_eval", "save_opts", "save_model", "load_model", "load_mono_model", "log",
+              "log_time"):
+        assert callable(getattr(Trainer, m))
+
+
+def test_state_dict_keys_match_oracle_modules():
+    """Checkpoint key compatibility: façade modules vs the oracle restatement (itself pinned on the
+    reference's modules by tests/test_oracle_nets.py via load_state_dict of shared synthetic weights)."""
+    from manydepth import networks
+    from oracle import nets as onets
+    pairs = [(networks.ShallowEncoder('XOLP', 2, 0.1), onets.ShallowEncoder('XOLP', 2, 0.1)),
+             (networks.ShallowNormalsEncoder(9, 0.1), onets.ShallowNormalsEncoder(9, 0.1)),
+             (networks.JointEncoder(0.1, True, True), onets.JointEncoder(0.1, True, True)),
+             (networks.ShallowResnetEncoder(18, False), onets.ShallowResnetEncoder(18, False)),
+             (networks.DepthDecoder(np.array([64, 64, 128, 256, 512]), range(4)),
+              onets.DepthDecoder(np.array([64, 64, 128, 256, 512]), range(4)))]
+    for a, b in pairs:
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert all(sa[k].shape == sb[k].shape for k in sa)
+
+
+def test_param_store_views_and_order():
+    from manydepth import networks
+    from polardepth.engine import ParamStore
+    models = {"rgb_encoder": networks.ShallowResnetEncoder(18, False),
+              "mono_depth": networks.DepthDecoder(np.array([64, 64, 128, 256, 512]), range(4))}
+    ref_w = models["mono_depth"].decoder[0].conv.conv.weight.detach().clone()
+    unused = lambda m, p: m == "rgb_encoder" and p.split(".")[1] in ("layer3", "layer4", "fc")
+    st = ParamStore(models, order=["rgb_encoder", "mono_depth"], unused=unused, device=torch.device("cpu"))
+    w = models["mono_depth"].decoder[0].conv.conv.weight
+    assert torch.equal(w.detach(), ref_w) and w.is_contiguous(memory_format=torch.channels_last)
+    assert w.grad is not None and w.grad.stride() == w.stride()
+    assert w.data.untyped_storage().data_ptr() == st.flat.untyped_storage().data_ptr()
+    # backward-completion order: the decoder's parameters come first, unused resnet tail last
+    first = st.entries[0][0]
+    assert first.startswith("mono_depth.")
+    assert all(n.split(".")[2] in ("layer3", "layer4", "fc") for n, _ in st.entries[st.n_used_params:])
+    used_numel = sum(p.numel() for _, p in st.entries[:st.n_used_params])
+    assert used_numel <= st.n_used <= used_numel + 4 * st.n_used_params
+    # writing through the flat buffer is visible in the module, load_state_dict keeps the views
+    st.flat.zero_()
+    assert w.abs().sum().item() == 0
+    models["mono_depth"].load_state_dict({k: torch.ones_like(v) for k, v in models["mono_depth"].state_dict().items()})
+    off, n = st.offsets["mono_depth.decoder.0.conv.conv.weight"]
+    assert st.flat[off:off + n].sum().item() == n
+    w.grad.fill_(2.0)
+    assert st.grad[off:off + n].sum().item() == 2 * n
+    st.zero_grad()
+    assert w.grad.abs().sum().item() == 0
+
+
+def test_no_cpu_fallback_anywhere():
+    from manydepth.options import MonodepthOptions
+    from manydepth.trainer import Trainer
+    from polardepth import ops
+    opts = MonodepthOptions().parse(["--no_cuda", "--depth_supervision_only", "True", "--depth_supervision", "True"])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Trainer(opts)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv2d_fwd(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 3, 3))
