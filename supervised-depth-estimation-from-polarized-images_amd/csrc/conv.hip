@@ -24,10 +24,12 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;        // contraction chunk
 constexpr int LDT = BK + 4;   // padded LDS row (floats): 144 B, conflict-free for b128
 constexpr int NT = 256;       // threads per workgroup (4 waves)
+constexpr unsigned OOB = 0x80000000u;   // byte offset beyond every buffer extent (< 2 GiB, checked on the host)
 
 enum { MODE_ZERO = 0, MODE_REFLECT = 1, MODE_TRANSPOSED = 2 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
@@ -49,35 +51,44 @@ struct ConvArgs {
     long M;
     long ldy;                // row stride of y in elements
     int mtiles, ntiles;
+    int sshift;              // log2(stride) (transposed mode: stride is a power of two)
+    unsigned w_bytes;
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// Decode the input coordinate of tap (kh,kw) for output pixel (oh,ow). Returns false for a zero tap.
-__device__ __forceinline__ bool tap_coord(const ConvArgs& a, int oh, int ow, int kh, int kw, int& ih, int& iw) {
-    if (a.mode == MODE_TRANSPOSED) {
-        int th = oh + a.pad - kh, tw = ow + a.pad - kw;
-        if (th < 0 || tw < 0) return false;
-        if (a.stride > 1) {
-            if ((th % a.stride) | (tw % a.stride)) return false;
-            th /= a.stride; tw /= a.stride;
-        }
-        ih = th; iw = tw;
-        return th < a.H && tw < a.W;
-    }
-    ih = oh * a.stride - a.pad + kh;
-    iw = ow * a.stride - a.pad + kw;
-    if (a.mode == MODE_REFLECT) {
-        if (ih < 0) ih = -ih;
-        if (ih >= a.H) ih = 2 * a.H - 2 - ih;
-        if (iw < 0) iw = -iw;
-        if (iw >= a.W) iw = 2 * a.W - 2 - iw;
-        return true;
-    }
-    return ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+// Hardware-bounds-checked loads: an offset >= the descriptor's extent returns 0 without a branch.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+// Input coordinate of tap (kh,kw) for a row whose (rh,rw) were prepared for MODE:
+//   zero / reflect: rh = oh*stride - pad        -> ih = rh + kh
+//   transposed    : rh = oh + pad               -> ih = (rh - kh) / stride when divisible
+template <int MODE>
+__device__ __forceinline__ bool tap_in(int rh, int rw, int kh, int kw, int H, int W, int sshift, int& ih, int& iw) {
+    if (MODE == MODE_TRANSPOSED) {
+        const int th = rh - kh, tw = rw - kw;
+        const int smask = (1 << sshift) - 1;
+        ih = th >> sshift; iw = tw >> sshift;
+        return ((th | tw) >= 0) & (((th | tw) & smask) == 0) & (ih < H) & (iw < W);
+    }
+    ih = rh + kh; iw = rw + kw;
+    if (MODE == MODE_REFLECT) {
+        ih = ih < 0 ? -ih : ih; ih = ih >= H ? 2 * H - 2 - ih : ih;
+        iw = iw < 0 ? -iw : iw; iw = iw >= W ? 2 * W - 2 - iw : iw;
+        return true;
+    }
+    return ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+}
+
+template <int BM, int BN, int WM, int WN, bool VEC, int MODE>
 __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;     // 32x32 MFMA tiles per wave
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
 
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDT];
-    __shared__ int rowinfo[BM][3];                // n (or -1), oh, ow
+    __shared__ int rowinfo[VEC ? 1 : BM][3];      // scalar path: element offset of the image (or -1), rh, rw
     __shared__ float red[4][WN][2];
 
     // XCD-aware mapping: consecutive logical tiles (which share input halos / the A tile) land
@@ -105,71 +116,87 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int hw = a.Ho * a.Wo;
 
-    for (int r = tid; r < BM; r += NT) {
-        long m = m0 + r;
+    // Buffer descriptors.  The activation descriptor starts at the first image this tile touches, so
+    // that 32-bit byte offsets stay small whatever the batch size.
+    const int img0 = (int)(m0 / hw);
+    const long rest = ((long)a.N - img0) * a.sN * 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
+    const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, a.w_bytes);
+
+    auto row_coords = [&](long m, int& rb, int& rh, int& rw) {
         if (m < a.M) {
-            int hw = a.Ho * a.Wo;
-            int n = (int)(m / hw);
-            int rem = (int)(m - (long)n * hw);
-            int oh = rem / a.Wo;
-            rowinfo[r][0] = n; rowinfo[r][1] = oh; rowinfo[r][2] = rem - oh * a.Wo;
+            const int n = (int)(m / hw);
+            const int rem = (int)(m - (long)n * hw);
+            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+            rb = (int)((n - img0) * a.sN);
+            if (MODE == MODE_TRANSPOSED) { rh = oh + a.pad; rw = ow + a.pad; }
+            else { rh = oh * a.stride - a.pad; rw = ow * a.stride - a.pad; }
         } else {
-            rowinfo[r][0] = -1; rowinfo[r][1] = 0; rowinfo[r][2] = 0;
+            rb = -1; rh = 0; rw = 0;
         }
+    };
+
+    // ---- per-thread gather state
+    int rb[VEC ? A_VEC_ITERS : 1], rh[VEC ? A_VEC_ITERS : 1], rwc[VEC ? A_VEC_ITERS : 1];
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < A_VEC_ITERS; ++i) row_coords(m0 + (tid >> 3) + 32 * i, rb[i], rh[i], rwc[i]);
+    } else {
+        for (int r = tid; r < BM; r += NT) row_coords(m0 + r, rowinfo[r][0], rowinfo[r][1], rowinfo[r][2]);
+        __syncthreads();
     }
-    __syncthreads();
+    // tap of this thread's k column, advanced by BK per chunk (no divisions in the loop)
+    int tk = VEC ? 4 * (tid & 7) : (tid & 31);
+    int tkh, tkw, tc;
+    {
+        const int tap = tk / a.C;
+        tc = tk - tap * a.C; tkh = tap / a.KW; tkw = tap - tkh * a.KW;
+    }
+    auto advance_tap = [&]() {
+        tk += BK; tc += BK;
+        while (tc >= a.C) { tc -= a.C; if (++tkw == a.KW) { tkw = 0; ++tkh; } }
+    };
 
     const int nchunks = (a.K + BK - 1) / BK;
     float4 pa[VEC ? A_VEC_ITERS : 1], pb[VEC ? B_VEC_ITERS : 1];
     float sa[VEC ? 1 : A_SC_ITERS], sb[VEC ? 1 : B_SC_ITERS];
 
-    auto load_chunk = [&](int q) {
+    auto load_chunk = [&]() {   // loads the chunk the tap state points at, then advances it
+        const bool kv = tk < a.K;
         if (VEC) {
-            const int pc = tid & 7;
-            const int k = q * BK + 4 * pc;
-            const bool kv = k < a.K;
-            const int tap = k / a.C, c = k - tap * a.C;
-            const int kh = tap / a.KW, kw = tap - kh * a.KW;
 #pragma unroll
             for (int i = 0; i < A_VEC_ITERS; ++i) {
-                const int r = (tid >> 3) + 32 * i;
-                const int n = rowinfo[r][0];
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 int ih, iw;
-                if (kv && n >= 0 && tap_coord(a, rowinfo[r][1], rowinfo[r][2], kh, kw, ih, iw))
-                    v = ldg4(a.x + (long)n * a.sN + (long)ih * a.sH + (long)iw * a.sW + c);
-                pa[i] = v;
+                const bool ok = tap_in<MODE>(rh[i], rwc[i], tkh, tkw, a.H, a.W, a.sshift, ih, iw) & kv & (rb[i] >= 0);
+                const unsigned off = (unsigned)(rb[i] + ih * (int)a.sH + iw * (int)a.sW + tc) * 4u;
+                pa[i] = buf_ld4(rx, ok ? off : OOB);
             }
 #pragma unroll
             for (int i = 0; i < B_VEC_ITERS; ++i) {
                 const int nr = n0 + (tid >> 3) + 32 * i;
-                pb[i] = (kv && nr < a.Co) ? ldg4(a.w + (long)nr * a.K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pb[i] = buf_ld4(rw_, (kv & (nr < a.Co)) ? (unsigned)(nr * a.K + tk) * 4u : OOB);
             }
         } else {
-            const int kc = tid & 31;
-            const int k = q * BK + kc;
-            const bool kv = k < a.K;
-            const int tap = k / a.C, c = k - tap * a.C;
-            const int kh = tap / a.KW, kw = tap - kh * a.KW;
 #pragma unroll
             for (int i = 0; i < A_SC_ITERS; ++i) {
                 const int r = (tid >> 5) + 8 * i;
-                const int n = rowinfo[r][0];
-                float v = 0.f;
+                const int rbv = rowinfo[r][0];
                 int ih, iw;
-                if (kv && n >= 0 && tap_coord(a, rowinfo[r][1], rowinfo[r][2], kh, kw, ih, iw)) {
-                    v = a.x[(long)n * a.sN + (long)ih * a.sH + (long)iw * a.sW + (long)c * a.sC];
-                    if (a.affine) v = (v - a.sub) / a.div;
-                }
+                const bool ok = tap_in<MODE>(rowinfo[r][1], rowinfo[r][2], tkh, tkw, a.H, a.W, a.sshift, ih, iw) & kv & (rbv >= 0);
+                const unsigned off = (unsigned)(rbv + ih * (int)a.sH + iw * (int)a.sW + tc * (int)a.sC) * 4u;
+                float v = buf_ld1(rx, ok ? off : OOB);
+                if (a.affine) v = ok ? (v - a.sub) / a.div : 0.f;
                 sa[i] = v;
             }
 #pragma unroll
             for (int i = 0; i < B_SC_ITERS; ++i) {
                 const int nr = n0 + (tid >> 5) + 8 * i;
-                sb[i] = (kv && nr < a.Co) ? a.w[(long)nr * a.K + k] : 0.f;
+                sb[i] = buf_ld1(rw_, (kv & (nr < a.Co)) ? (unsigned)(nr * a.K + tk) * 4u : OOB);
             }
         }
+        advance_tap();
     };
     auto store_chunk = [&](int buf) {
         if (VEC) {
@@ -197,13 +224,13 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_chunk(0);
+    load_chunk();
     store_chunk(0);
     __syncthreads();
     const int frow = lane & 31, fk = 4 * (lane >> 5);
     for (int q = 0; q < nchunks; ++q) {
         const int buf = q & 1;
-        if (q + 1 < nchunks) load_chunk(q + 1);
+        if (q + 1 < nchunks) load_chunk();
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             float4 fa[TM], fb[TN];
@@ -282,9 +309,18 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
     a.mtiles = (int)((a.M + BM - 1) / BM);
     a.ntiles = (a.Co + BN - 1) / BN;
     const long nblk = (long)a.mtiles * a.ntiles;
-    const unsigned grid = (unsigned)((nblk + 7) / 8 * 8);
-    if (vec) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3(grid), dim3(NT), 0, st, a);
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
+#define PD_LAUNCH(V, MD) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, V, MD>), grid, block, 0, st, a)
+    if (vec) {
+        if (a.mode == MODE_ZERO) PD_LAUNCH(true, MODE_ZERO);
+        else if (a.mode == MODE_REFLECT) PD_LAUNCH(true, MODE_REFLECT);
+        else PD_LAUNCH(true, MODE_TRANSPOSED);
+    } else {
+        if (a.mode == MODE_ZERO) PD_LAUNCH(false, MODE_ZERO);
+        else if (a.mode == MODE_REFLECT) PD_LAUNCH(false, MODE_REFLECT);
+        else PD_LAUNCH(false, MODE_TRANSPOSED);
+    }
+#undef PD_LAUNCH
     return pd::check_launch("pd_conv2d");
 }
 
@@ -310,7 +346,10 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, void* y
     PD_REQUIRE(mode >= 0 && mode <= 2 && act >= 0 && act <= 3, "pd_conv2d: bad mode/act");
     PD_REQUIRE(mode != MODE_REFLECT || (pad < H && pad < W), "pd_conv2d: reflect pad must be < input size");
     PD_REQUIRE(ldy >= Co, "pd_conv2d: ldy < Cout");
+    int sshift = 0;
+    while ((1 << sshift) < stride) ++sshift;
     if (mode == MODE_TRANSPOSED) {
+        PD_REQUIRE((1 << sshift) == stride, "pd_conv2d: transposed mode needs a power-of-two stride");
         PD_REQUIRE(H == (Ho + 2 * pad - KH) / stride + 1 && W == (Wo + 2 * pad - KW) / stride + 1,
                    "pd_conv2d: transposed: x grid is not the forward output grid of a %dx%d input", Ho, Wo);
     } else {
@@ -323,7 +362,13 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, void* y
     a.N = N; a.H = H; a.W = W; a.C = C; a.sN = sN; a.sH = sH; a.sW = sW; a.sC = sC;
     a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.mode = mode; a.act = act; a.affine = affine; a.sub = sub; a.div = div;
-    a.K = KH * KW * C; a.M = (long)N * Ho * Wo; a.ldy = ldy;
+    a.K = KH * KW * C; a.M = (long)N * Ho * Wo; a.ldy = ldy; a.sshift = sshift;
+    const long wbytes = (long)Co * a.K * 4;
+    PD_REQUIRE(wbytes < 0x7fffffffL, "pd_conv2d: weight tensor too large for 32-bit offsets");
+    a.w_bytes = (unsigned)wbytes;
+    // 32-bit byte offsets are relative to the first image of a tile: a tile may span ceil(128/(Ho*Wo))+1 images
+    const long span = 128 / ((long)Ho * Wo) + 2;
+    PD_REQUIRE(span * sN * 4 < 0x7fffffffL, "pd_conv2d: image too large for 32-bit offsets (%ld bytes per image)", sN * 4);
     const bool vec = (C % 4 == 0) && sC == 1 && (sW % 4 == 0) && (sH % 4 == 0) && (sN % 4 == 0) && !affine &&
                      pd::aligned16(x) && pd::aligned16(w);
     hipStream_t st = (hipStream_t)stream;
@@ -334,15 +379,17 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, void* y
 
 // ===================================================================== weight gradient
 // dW[co][kh][kw][ci] = sum_m dY[m][co] * X[pix(m) + tap][ci]   ("TN" GEMM: contraction over pixels).
-// Workgroup = one 64(co) x 64(k) tile of dW for one slice of the pixel range; slices write
+// Workgroup = one TCO(co) x 128(k) tile of dW for one slice of the pixel range; slices write
 // partial tiles to a workspace that pd_reduce_rows() sums deterministically (no float atomics).
 // Both operands keep their natural [pixel][channel] layout in LDS; the MFMA fragment of a
 // 32-wide channel group at a fixed pixel is 32 consecutive floats (conflict-free ds_read_b32).
+// A thread's k columns never change, so its tap (kh,kw,ci) is decoded once; pixel rows advance
+// incrementally; all global reads are hardware-bounds-checked buffer loads (no branches).
 namespace {
 
-constexpr int WG_T = 64;          // tile edge (co and k)
+constexpr int WG_K = 128;         // k tile
 constexpr int WG_MC = 32;         // pixels per chunk
-constexpr int WG_LD = WG_T + 8;   // padded LDS row (floats)
+constexpr int WG_LDX = WG_K + 8;  // padded LDS rows (floats)
 
 struct WgradArgs {
     const float* x;
@@ -361,119 +408,139 @@ struct WgradArgs {
     int S, ktiles, ctiles;
 };
 
-template <bool VEC>
+template <int TCO, bool VEC, int MODE>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float Ds[2][WG_MC][WG_LD];
-    __shared__ __attribute__((aligned(16))) float Xs[2][WG_MC][WG_LD];
+    constexpr int LDD = TCO + 8;
+    constexpr int WAVES_CO = TCO / 32;            // 2 (TCO=64) or 1 (TCO=32)
+    constexpr int WAVES_K = 4 / WAVES_CO;         // 2 or 4
+    constexpr int TK = WG_K / WAVES_K / 32;       // MFMA tiles along k per wave: 2 or 1
+    constexpr int DY_ITERS = WG_MC * TCO / 4 / NT;   // 16-byte dY pieces per thread per chunk: 2 or 1
+    constexpr int DY_PPR = TCO / 4;                  // pieces per row
+    __shared__ __attribute__((aligned(16))) float Ds[2][WG_MC][LDD];
+    __shared__ __attribute__((aligned(16))) float Xs[2][WG_MC][WG_LDX];
+    __shared__ int ktab[VEC ? 1 : WG_K][3];
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_K, wn = wave - wm * WAVES_K;
     int b = blockIdx.x;
     const int kt = b % a.ktiles; b /= a.ktiles;
     const int ct = b % a.ctiles; b /= a.ctiles;
     const int s = b;
-    const int co0 = ct * WG_T, k0 = kt * WG_T;
+    const int co0 = ct * TCO, k0 = kt * WG_K;
     const long mbeg = (long)s * a.mper;
     const long mend = (mbeg + a.mper < a.M) ? mbeg + a.mper : a.M;
-    const int nchunks = mend > mbeg ? (int)((mend - mbeg + WG_MC - 1) / WG_MC) : 0;
+    const int nrows = (int)(mend - mbeg);
+    const int nchunks = nrows > 0 ? (nrows + WG_MC - 1) / WG_MC : 0;
+    const int hw = a.Ho * a.Wo;
 
-    // fixed per-thread assignment.  VEC: rows r0, r0+16; one 16-byte piece (4 co / 4 k) per row.
-    // scalar X path: row r = tid>>3, eight k columns (tid&7) + 8*i.
-    const int pc = tid & 15, r0 = tid >> 4;
-    int vkh = 0, vkw = 0, vc = 0; bool vkv = false;           // VEC: decode of k = k0 + 4*pc
+    const int img0 = (int)(mbeg / hw);
+    const long rest = ((long)a.N - img0) * a.sN * 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
+    const long dbytes = (long)nrows * a.ldd * 4;
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dy + mbeg * a.ldd, dbytes > 0 ? (unsigned)dbytes : 0u);
+
+    // ---- fixed k columns of this thread
+    // VEC: one 16-byte piece k = k0 + 4*(tid&31), rows (tid>>5) + 8*i, i < 4
+    // scalar: row tid>>3, sixteen columns (tid&7) + 8*j through the LDS tap table
+    int vkh = 0, vkw = 0, vc = 0; bool vkv = false;
     if (VEC) {
-        const int k = k0 + 4 * pc;
+        const int k = k0 + 4 * (tid & 31);
         vkv = k < a.K;
         const int tap = k / a.C;
         vc = k - tap * a.C; vkh = tap / a.KW; vkw = tap - vkh * a.KW;
-    }
-    __shared__ int ktab[WG_T][3];
-    if (!VEC) {
-        if (tid < WG_T) {
+    } else {
+        if (tid < WG_K) {
             const int k = k0 + tid;
             const int tap = k / a.C;
             const int kh = tap / a.KW;
-            ktab[tid][0] = k < a.K ? kh : -1; ktab[tid][1] = tap - kh * a.KW; ktab[tid][2] = k - tap * a.C;
+            ktab[tid][0] = k < a.K ? kh : -1; ktab[tid][1] = tap - kh * a.KW; ktab[tid][2] = (k - tap * a.C) * (int)a.sC;
         }
         __syncthreads();
     }
-    // pixel coordinates of this thread's rows, advanced by WG_MC per chunk
-    const int hw = a.Ho * a.Wo;
-    int rn[2], roh[2], row_[2];
-    const int nrows = VEC ? 2 : 1;
-    for (int i = 0; i < nrows; ++i) {
-        const long m = mbeg + (VEC ? r0 + 16 * i : (tid >> 3));
-        rn[i] = (int)(m / hw);
-        const int rem = (int)(m - (long)rn[i] * hw);
+    // ---- pixel rows of this thread, advanced by WG_MC per chunk
+    constexpr int XR = VEC ? 4 : 1;
+    int rb[XR], rloc[XR];                         // image offset (elements), row index inside the slice
+    int roh[XR], row_[XR];
+    for (int i = 0; i < XR; ++i) {
+        rloc[i] = VEC ? (tid >> 5) + 8 * i : (tid >> 3);
+        const int m = (int)(mbeg - (long)img0 * hw) + rloc[i];   // pixel index relative to image img0
+        const int n = m / hw;
+        const int rem = m - n * hw;
         roh[i] = rem / a.Wo; row_[i] = rem - roh[i] * a.Wo;
+        rb[i] = n * (int)a.sN;
     }
     auto advance = [&](int i) {
+        rloc[i] += WG_MC;
         row_[i] += WG_MC;
-        while (row_[i] >= a.Wo) { row_[i] -= a.Wo; if (++roh[i] == a.Ho) { roh[i] = 0; ++rn[i]; } }
+        while (row_[i] >= a.Wo) { row_[i] -= a.Wo; if (++roh[i] == a.Ho) { roh[i] = 0; rb[i] += (int)a.sN; } }
     };
 
-    float4 pd[2], px[2];
-    float sx[8];
-    // reuse the forward coordinate logic (zero / reflect padding)
-    ConvArgs ca;
-    ca.H = a.H; ca.W = a.W; ca.stride = a.stride; ca.pad = a.pad; ca.mode = a.mode;
+    float4 pd[DY_ITERS], px[VEC ? 4 : 1];
+    float sx[VEC ? 1 : 16];
 
     auto load_chunk = [&](int q) {
-        const long mb = mbeg + (long)q * WG_MC;
+        const int rbase = q * WG_MC;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const long m = mb + r0 + 16 * i;
-            const int co = co0 + 4 * pc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < mend) {
-                const float* p = a.dy + m * a.ldd + co;
-                if (co + 3 < a.Co) v = ldg4(p);
-                else { if (co < a.Co) v.x = p[0]; if (co + 1 < a.Co) v.y = p[1]; if (co + 2 < a.Co) v.z = p[2]; }
+        for (int i = 0; i < DY_ITERS; ++i) {
+            const int r = rbase + tid / DY_PPR + (NT / DY_PPR) * i;
+            const int co = co0 + 4 * (tid % DY_PPR);
+            const unsigned off = (unsigned)(r * (int)a.ldd + co) * 4u;
+            if ((a.Co & 3) == 0) {
+                pd[i] = buf_ld4(rd, (r < nrows && co < a.Co) ? off : OOB);
+            } else {   // ragged channel count (e.g. the 1-channel disparity heads): element-wise
+                float4 v;
+                v.x = buf_ld1(rd, (r < nrows && co < a.Co) ? off : OOB);
+                v.y = buf_ld1(rd, (r < nrows && co + 1 < a.Co) ? off + 4 : OOB);
+                v.z = buf_ld1(rd, (r < nrows && co + 2 < a.Co) ? off + 8 : OOB);
+                v.w = buf_ld1(rd, (r < nrows && co + 3 < a.Co) ? off + 12 : OOB);
+                pd[i] = v;
             }
-            pd[i] = v;
         }
         if (VEC) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const long m = mb + r0 + 16 * i;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 4; ++i) {
                 int ih, iw;
-                if (vkv && m < mend && tap_coord(ca, roh[i], row_[i], vkh, vkw, ih, iw))
-                    v = ldg4(a.x + (long)rn[i] * a.sN + (long)ih * a.sH + (long)iw * a.sW + vc);
-                px[i] = v;
+                const bool ok = tap_in<MODE>(roh[i] * a.stride - a.pad, row_[i] * a.stride - a.pad, vkh, vkw, a.H, a.W, 0, ih, iw) &
+                                vkv & (rloc[i] < nrows);
+                const unsigned off = (unsigned)(rb[i] + ih * (int)a.sH + iw * (int)a.sW + vc) * 4u;
+                px[i] = buf_ld4(rx, ok ? off : OOB);
                 advance(i);
             }
         } else {
-            const long m = mb + (tid >> 3);
+            const int rh0 = roh[0] * a.stride - a.pad, rw0 = row_[0] * a.stride - a.pad;
+            const bool rv = rloc[0] < nrows;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int kc = (tid & 7) + 8 * i;
-                float v = 0.f;
-                int ih, iw;
+            for (int j = 0; j < 16; ++j) {
+                const int kc = (tid & 7) + 8 * j;
                 const int kh = ktab[kc][0];
-                if (kh >= 0 && m < mend && tap_coord(ca, roh[0], row_[0], kh, ktab[kc][1], ih, iw)) {
-                    v = a.x[(long)rn[0] * a.sN + (long)ih * a.sH + (long)iw * a.sW + (long)ktab[kc][2] * a.sC];
-                    if (a.affine) v = (v - a.sub) / a.div;
-                }
-                sx[i] = v;
+                int ih, iw;
+                const bool ok = tap_in<MODE>(rh0, rw0, kh, ktab[kc][1], a.H, a.W, 0, ih, iw) & (kh >= 0) & rv;
+                const unsigned off = (unsigned)(rb[0] + ih * (int)a.sH + iw * (int)a.sW + ktab[kc][2]) * 4u;
+                float v = buf_ld1(rx, ok ? off : OOB);
+                if (a.affine) v = ok ? (v - a.sub) / a.div : 0.f;
+                sx[j] = v;
             }
             advance(0);
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Ds[buf][r0 + 16 * i][4 * pc]) = pd[i];
+        for (int i = 0; i < DY_ITERS; ++i)
+            *reinterpret_cast<float4*>(&Ds[buf][tid / DY_PPR + (NT / DY_PPR) * i][4 * (tid % DY_PPR)]) = pd[i];
         if (VEC) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Xs[buf][r0 + 16 * i][4 * pc]) = px[i];
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Xs[buf][(tid >> 5) + 8 * i][4 * (tid & 31)]) = px[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) Xs[buf][tid >> 3][(tid & 7) + 8 * i] = sx[i];
+            for (int j = 0; j < 16; ++j) Xs[buf][tid >> 3][(tid & 7) + 8 * j] = sx[j];
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[TK];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < TK; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
     const bool do_bias = a.bpart != nullptr && kt == 0;
 
@@ -486,10 +553,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int st = 0; st < WG_MC / 2; ++st) {
             const float av = Ds[buf][2 * st + fk][wm * 32 + fi];
-            const float bv = Xs[buf][2 * st + fk][wn * 32 + fi];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TK; ++t) {
+                const float bv = Xs[buf][2 * st + fk][(wn * TK + t) * 32 + fi];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
         }
-        if (do_bias && tid < WG_T) {
+        if (do_bias && tid < TCO) {
 #pragma unroll 8
             for (int r = 0; r < WG_MC; ++r) bsum += Ds[buf][r][tid];
         }
@@ -497,13 +567,16 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         __syncthreads();
     }
     // C/D layout: col = lane&31 -> k, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co
-    const int k = k0 + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc[r];
+    for (int t = 0; t < TK; ++t) {
+        const int k = k0 + (wn * TK + t) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc[t][r];
+        }
     }
-    if (do_bias && tid < WG_T && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = bsum;
+    if (do_bias && tid < TCO && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = bsum;
 }
 
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -528,8 +601,11 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     }
 }
 
+inline int wgrad_tco(int Co) { return Co > 32 ? 64 : 32; }
+
 void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
-    const long tiles = (long)((Co + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T);
+    const int tco = wgrad_tco(Co);
+    const long tiles = (long)((Co + tco - 1) / tco) * ((K + WG_K - 1) / WG_K);
     long s = (1536 + tiles - 1) / tiles;
     const long smax = (M + 511) / 512;
     if (s > smax) s = smax;
@@ -570,14 +646,24 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     PD_REQUIRE(ws_bytes >= need, "pd_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
     a.part = (float*)workspace;
     a.bpart = dbias ? a.part + (size_t)a.S * Co * a.K : nullptr;
-    a.ktiles = (a.K + WG_T - 1) / WG_T; a.ctiles = (Co + WG_T - 1) / WG_T;
+    const int tco = wgrad_tco(Co);
+    a.ktiles = (a.K + WG_K - 1) / WG_K; a.ctiles = (Co + tco - 1) / tco;
     const bool vec = (C % 4 == 0) && sC == 1 && (sW % 4 == 0) && (sH % 4 == 0) && (sN % 4 == 0) && !affine &&
                      pd::aligned16(x);
     PD_REQUIRE(pd::aligned16(dy) && (ldd % 4 == 0 || Co < 4), "pd_conv2d_wgrad: dy must be 16-byte aligned rows");
+    PD_REQUIRE(a.mper * ldd * 4 < 0x7fffffffL, "pd_conv2d_wgrad: slice too large for 32-bit offsets");
+    PD_REQUIRE((a.mper / ((long)Ho * Wo) + 2) * sN * 4 < 0x7fffffffL, "pd_conv2d_wgrad: image too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((long)a.ktiles * a.ctiles * a.S);
-    if (vec) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(grid), dim3(NT), 0, st, a);
+    const dim3 grid((unsigned)((long)a.ktiles * a.ctiles * a.S)), block(NT);
+#define PD_WG(T, V, MD) hipLaunchKernelGGL((conv_wgrad_kernel<T, V, MD>), grid, block, 0, st, a)
+    if (tco == 64) {
+        if (vec) { if (mode == MODE_ZERO) PD_WG(64, true, MODE_ZERO); else PD_WG(64, true, MODE_REFLECT); }
+        else { if (mode == MODE_ZERO) PD_WG(64, false, MODE_ZERO); else PD_WG(64, false, MODE_REFLECT); }
+    } else {
+        if (vec) { if (mode == MODE_ZERO) PD_WG(32, true, MODE_ZERO); else PD_WG(32, true, MODE_REFLECT); }
+        else { if (mode == MODE_ZERO) PD_WG(32, false, MODE_ZERO); else PD_WG(32, false, MODE_REFLECT); }
+    }
+#undef PD_WG
     int rc = pd::check_launch("pd_conv2d_wgrad");
     if (rc) return rc;
     const long nw = (long)Co * a.K;
