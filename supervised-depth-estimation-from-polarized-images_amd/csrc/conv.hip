@@ -27,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;        // contraction chunk
-constexpr int LDT = BK + 4;   // padded LDS row (floats): 144 B, conflict-free for b128
+constexpr int LDT = BK;       // LDS row = 128 B; 16-byte slots are XOR-swizzled: conflict-free b128 reads and writes
 constexpr int NT = 256;       // threads per workgroup (4 waves)
 constexpr unsigned OOB = 0x80000000u;   // byte offset beyond every buffer extent (< 2 GiB, checked on the host)
 
@@ -56,6 +56,11 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// float offset of 16-byte slot `slot` (0..7) in LDS row `row`: slot ^ ((row >> 1) & 7).  With 128-byte rows two
+// rows cover the 64 banks; the XOR makes the eight even (odd) rows of every ds_read_b128 lane group hit
+// eight different slots, and the eight slots of one row (a ds_write_b128 group) are always distinct.
+__device__ __forceinline__ int swz(int row, int slot) { return 4 * (slot ^ ((row >> 1) & 7)); }
 
 // Hardware-bounds-checked loads: an offset >= the descriptor's extent returns 0 without a branch.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDT];
     __shared__ int rowinfo[VEC ? 1 : BM][3];      // scalar path: element offset of the image (or -1), rh, rw
-    __shared__ float red[4][WN][2];
+    float (*red)[WN][2] = reinterpret_cast<float (*)[WN][2]>(&As[0][0][0]);   // epilogue scratch, aliases As
 
     // XCD-aware mapping: consecutive logical tiles (which share input halos / the A tile) land
     // on the same XCD and hence the same L2.  Grid is padded to a multiple of 8.
@@ -127,10 +132,11 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
 
     auto row_coords = [&](long m, int& rb, int& rh, int& rw) {
         if (m < a.M) {
-            const int n = (int)(m / hw);
-            const int rem = (int)(m - (long)n * hw);
+            const int mr = (int)(m - (long)img0 * hw);      // pixel index relative to the tile's first image
+            const int dn = mr / hw;
+            const int rem = mr - dn * hw;
             const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-            rb = (int)((n - img0) * a.sN);
+            rb = dn * (int)a.sN;
             if (MODE == MODE_TRANSPOSED) { rh = oh + a.pad; rw = ow + a.pad; }
             else { rh = oh * a.stride - a.pad; rw = ow * a.stride - a.pad; }
         } else {
@@ -203,16 +209,16 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
             const int pc = tid & 7;
 #pragma unroll
             for (int i = 0; i < A_VEC_ITERS; ++i)
-                *reinterpret_cast<float4*>(&As[buf][(tid >> 3) + 32 * i][4 * pc]) = pa[i];
+                *reinterpret_cast<float4*>(&As[buf][(tid >> 3) + 32 * i][swz((tid >> 3) + 32 * i, pc)]) = pa[i];
 #pragma unroll
             for (int i = 0; i < B_VEC_ITERS; ++i)
-                *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) + 32 * i][4 * pc]) = pb[i];
+                *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) + 32 * i][swz((tid >> 3) + 32 * i, pc)]) = pb[i];
         } else {
             const int kc = tid & 31;
 #pragma unroll
-            for (int i = 0; i < A_SC_ITERS; ++i) As[buf][(tid >> 5) + 8 * i][kc] = sa[i];
+            for (int i = 0; i < A_SC_ITERS; ++i) As[buf][(tid >> 5) + 8 * i][swz((tid >> 5) + 8 * i, kc >> 2) + (kc & 3)] = sa[i];
 #pragma unroll
-            for (int i = 0; i < B_SC_ITERS; ++i) Bs[buf][(tid >> 5) + 8 * i][kc] = sb[i];
+            for (int i = 0; i < B_SC_ITERS; ++i) Bs[buf][(tid >> 5) + 8 * i][swz((tid >> 5) + 8 * i, kc >> 2) + (kc & 3)] = sb[i];
         }
     };
 
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     load_chunk();
     store_chunk(0);
     __syncthreads();
-    const int frow = lane & 31, fk = 4 * (lane >> 5);
+    const int frow = lane & 31, fh = lane >> 5;
     for (int q = 0; q < nchunks; ++q) {
         const int buf = q & 1;
         if (q + 1 < nchunks) load_chunk();
@@ -236,10 +242,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
             float4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const float4*>(&As[buf][wm * WM + 32 * i + frow][8 * g + fk]);
+                fa[i] = *reinterpret_cast<const float4*>(&As[buf][wm * WM + 32 * i + frow][swz(wm * WM + 32 * i + frow, 2 * g + fh)]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * WN + 32 * j + frow][8 * g + fk]);
+                fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * WN + 32 * j + frow][swz(wn * WN + 32 * j + frow, 2 * g + fh)]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -606,7 +612,7 @@ inline int wgrad_tco(int Co) { return Co > 32 ? 64 : 32; }
 void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
     const int tco = wgrad_tco(Co);
     const long tiles = (long)((Co + tco - 1) / tco) * ((K + WG_K - 1) / WG_K);
-    long s = (1536 + tiles - 1) / tiles;
+    long s = 1536 / tiles;                    // <= two full rounds of 3 resident workgroups per CU (floor: no ragged tail)
     const long smax = (M + 511) / 512;
     if (s > smax) s = smax;
     if (s < 1) s = 1;

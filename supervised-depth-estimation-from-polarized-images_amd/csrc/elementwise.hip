@@ -447,14 +447,16 @@ __global__ __launch_bounds__(EW_T) void act_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------- reflection-pad fold
-// dxp [N,H+2,W+2,C] (gradient on the padded grid, pad 1) -> dx [N,H,W,C]
+// dxp [N,H+2,W+2,C] (gradient on the padded grid, pad 1) -> dx [N,H,W,C]; V = channels per thread (4 or 1)
+template <int V>
 __global__ __launch_bounds__(EW_T) void reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx,
                                                             int N, int H, int W, int C) {
-    const long total = (long)N * H * W * C;
+    const int cq = C / V;
+    const long total = (long)N * H * W * cq;
     const int Hp = H + 2, Wp = W + 2;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int c = (int)(i % C);
-        long pix = i / C;
+        const int c = (int)(i % cq) * V;
+        long pix = i / cq;
         const int w = (int)(pix % W); pix /= W;
         const int h = (int)(pix % H);
         const long n = pix / H;
@@ -462,10 +464,14 @@ __global__ __launch_bounds__(EW_T) void reflect_fold_kernel(const float* __restr
         int hs[3], ws[3], nh = 0, nw = 0;
         hs[nh++] = h + 1; if (h == 1) hs[nh++] = 0; if (h == H - 2) hs[nh++] = Hp - 1;
         ws[nw++] = w + 1; if (w == 1) ws[nw++] = 0; if (w == W - 2) ws[nw++] = Wp - 1;
-        float acc = 0.f;
+        float4 acc = f4(0.f);
         for (int a = 0; a < nh; ++a)
-            for (int b = 0; b < nw; ++b) acc += dxp[((n * Hp + hs[a]) * Wp + ws[b]) * C + c];
-        dx[i] = acc;
+            for (int b = 0; b < nw; ++b) {
+                const float* p = dxp + ((n * Hp + hs[a]) * Wp + ws[b]) * C + c;
+                if (V == 4) { const float4 v = ld4(p); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+                else acc.x += p[0];
+            }
+        if (V == 4) st4(dx + i * 4, acc); else dx[i] = acc.x;
     }
 }
 
@@ -683,8 +689,12 @@ extern "C" int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int a
 extern "C" int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, int C, void* stream) {
     PD_REQUIRE(dxp && dx && N >= 0 && H >= 2 && W >= 2 && C > 0, "pd_reflect_fold: bad arguments");
     if (N == 0) return PD_OK;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3(ew_grid((long)N * H * W * C)), dim3(EW_T), 0, (hipStream_t)stream,
-                       (const float*)dxp, (float*)dx, N, H, W, C);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(reflect_fold_kernel<4>, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(EW_T), 0,
+                           (hipStream_t)stream, (const float*)dxp, (float*)dx, N, H, W, C);
+    else
+        hipLaunchKernelGGL(reflect_fold_kernel<1>, dim3(ew_grid((long)N * H * W * C)), dim3(EW_T), 0,
+                           (hipStream_t)stream, (const float*)dxp, (float*)dx, N, H, W, C);
     return pd::check_launch("pd_reflect_fold");
 }
 

@@ -380,17 +380,37 @@ struct LossMeta {
     int sup_rows[8], sm_rows[8], N[8], h[8], w[8], scale_id[8];
 };
 
-__global__ void loss_finalize_kernel(const float* __restrict__ sup_part, const float* __restrict__ sm_part,
-                                     const LossMeta m, int part_stride, float w_normals, float w_smooth,
-                                     double* __restrict__ sums, float* __restrict__ vals) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ sup_part,
+                                                            const float* __restrict__ sm_part, const LossMeta m,
+                                                            int part_stride, float w_normals, float w_smooth,
+                                                            double* __restrict__ sums, float* __restrict__ vals) {
+    // one workgroup; thread t sums rows t, t+256, ... of every partial array in fp64, then a tree over LDS
+    __shared__ double red[256];
+    __shared__ double tot[8 * 5];
+    for (int s = 0; s < m.S; ++s) {
+        for (int j = 0; j < 5; ++j) {
+            double v = 0.0;
+            if (j < 3) {
+                const float* sp = sup_part + (long)s * part_stride * 3;
+                for (int r = threadIdx.x; r < m.sup_rows[s]; r += 256) v += sp[r * 3 + j];
+            } else {
+                const float* mp = sm_part + (long)s * part_stride * 2;
+                for (int r = threadIdx.x; r < m.sm_rows[s]; r += 256) v += mp[r * 2 + (j - 3)];
+            }
+            red[threadIdx.x] = v;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) tot[s * 5 + j] = red[0];
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x != 0) return;
     double total = 0.0;
     for (int s = 0; s < m.S; ++s) {
-        double a[5] = {0, 0, 0, 0, 0};
-        const float* sp = sup_part + (long)s * part_stride * 3;
-        for (int r = 0; r < m.sup_rows[s]; ++r) { a[0] += sp[r * 3]; a[1] += sp[r * 3 + 1]; a[2] += sp[r * 3 + 2]; }
-        const float* mp = sm_part + (long)s * part_stride * 2;
-        for (int r = 0; r < m.sm_rows[s]; ++r) { a[3] += mp[r * 2]; a[4] += mp[r * 2 + 1]; }
+        const double* a = tot + s * 5;
         for (int j = 0; j < 5; ++j) sums[s * 5 + j] = a[j];
         const int N = m.N[s], h = m.h[s], w = m.w[s];
         const double l1 = a[0] / a[2], ln = a[1] / a[2];
@@ -502,7 +522,7 @@ extern "C" int pd_loss_finalize(const void* sup_part, const int* sup_rows, const
         m.N[s] = dims[3 * s]; m.h[s] = dims[3 * s + 1]; m.w[s] = dims[3 * s + 2]; m.scale_id[s] = scale_ids[s];
         PD_REQUIRE(sup_rows[s] <= part_stride && sm_rows[s] <= part_stride, "pd_loss_finalize: rows exceed part_stride");
     }
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)sup_part,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)sup_part,
                        (const float*)sm_part, m, part_stride, w_normals, w_smooth, (double*)sums, (float*)vals);
     return pd::check_launch("pd_loss_finalize");
 }
