@@ -16,20 +16,29 @@
 //     [-255,255]^2; a 511x511 fp32 LUT built on the host in fp64 (L2-resident, 1 MB)
 //     gives the exactly-rounded value through integer indexing.
 //   * theta tables: searchsorted-left on fp32 keys floor32(x[i]) is exact for an fp32
-//     query; the per-bin (x_lo, y_lo, slope) triples are precomputed in fp64 with the
-//     same operations scipy performs, and live in LDS together with the keys.
+//     query.  The three tables are searched at once: ONE binary search over the merged,
+//     sorted key array gives p = #{merged keys < rho}; a rank table maps p to the three
+//     per-table counts (= the three searchsorted results).  The per-bin (x_lo, y_lo, slope)
+//     (x_lo, slope) pairs are precomputed in fp64 with the operations scipy performs, next to
+//     sin/cos(y_lo).  Keys, a sqrt(rho) bucket index, ranks and bins (90 KB) live in LDS.
 //   * normals: cos/sin(phi) in fp32 (torch CPU computes them on the fp32 tensor),
-//     promoted and multiplied with the fp64 sin/cos(theta), rounded to fp32.
+//     promoted and multiplied with the fp64 sin/cos(theta), rounded to fp32.  Inside the tables
+//     sin/cos(theta) = angle addition of the tabulated sin/cos(y_lo) with a Taylor series of the
+//     sub-step delta (|delta| <= 1.6e-3 rad); extrapolated rho uses a 3-term Cody-Waite reduction
+//     + fdlibm kernels (< 1 ulp for |theta| < 1.6e6; LS mode reaches 1.4e2, Stokes mode 2.5e4).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #include "pd_common.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace {
 
-constexpr uint32_t kMagic = 0x50444c54u;  // "PDLT"
+constexpr uint32_t kMagic = 0x50444c33u;  // "PDL3"
+constexpr int kBuckets = 1024;            // sqrt(rho) buckets of the guided search
 constexpr int kLutSide = 511;
 constexpr int kLutCount = kLutSide * kLutSide;
 
@@ -44,11 +53,19 @@ struct PolarHeader {   // 64 bytes, little endian
 };
 static_assert(sizeof(PolarHeader) == 64, "header size");
 
-// LDS image layout (all offsets relative to its start):
-//   float  keys[nk]                     nk = n_d + n_s1 + n_s2, padded to a multiple of 4
-//   double xlo[nk], ylo[nk], slope[nk]  entry i of a table describes bin idx == i (i >= 1)
+// LDS image layout (offsets relative to its start), nk = n_d + n_s1 + n_s2, nkp = nk rounded up to 4:
+//   float    mkeys[nkp]           all keys floor32(x) of the three tables, sorted ascending (+inf padding)
+//   uint16_t bstart[kBuckets + 4] bstart[b] = #{merged keys k : sqrt(k) < b * smax / kBuckets}; [kBuckets+1..] = nk
+//   float    bscale, pad          kBuckets / smax, smax = sqrt(largest finite key)   (8 bytes)
+//   uint16_t rank[nk + 1][4]      rank[p] = (#diffuse, #spec1, #spec2, 0) among the first p merged keys
+//   double   bins[nk][4]          per table (diffuse | spec1 | spec2), entry i describes bin idx == i:
+//                                 x_lo, slope, sin(y_lo), cos(y_lo)
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int keys_padded(int nk) { return (nk + 3) / 4 * 4; }
+inline size_t lds_off_bstart(int nk) { return size_t(keys_padded(nk)) * 4; }
+inline size_t lds_off_rank(int nk) { return lds_off_bstart(nk) + size_t(kBuckets + 4) * 2 + 8; }
+inline size_t lds_off_bins(int nk) { return round_up(lds_off_rank(nk) + size_t(nk + 1) * 8, 16); }
+inline size_t lds_image_bytes(int nk) { return round_up(lds_off_bins(nk) + size_t(nk) * 32, 16); }
 
 float floor32(double x) {  // largest fp32 <= x
     float f = static_cast<float>(x);
@@ -60,9 +77,7 @@ float floor32(double x) {  // largest fp32 <= x
 
 extern "C" size_t pd_polar_tables_bytes(int n_d, int n_s1, int n_s2) {
     if (n_d < 2 || n_s1 < 2 || n_s2 < 2) return 0;
-    int nk = n_d + n_s1 + n_s2;
-    size_t lds = round_up(size_t(keys_padded(nk)) * 4 + size_t(nk) * 24, 16);
-    return sizeof(PolarHeader) + round_up(size_t(kLutCount) * 4, 16) + lds;
+    return sizeof(PolarHeader) + round_up(size_t(kLutCount) * 4, 16) + lds_image_bytes(n_d + n_s1 + n_s2);
 }
 
 extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_d,
@@ -80,8 +95,9 @@ extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_
     h.magic = kMagic; h.n_d = n_d; h.n_s1 = n_s1; h.n_s2 = n_s2;
     h.off_lut = sizeof(PolarHeader);
     h.off_lds = h.off_lut + uint32_t(round_up(size_t(kLutCount) * 4, 16));
-    int nk = n_d + n_s1 + n_s2;
-    h.lds_bytes = uint32_t(round_up(size_t(keys_padded(nk)) * 4 + size_t(nk) * 24, 16));
+    const int nk = n_d + n_s1 + n_s2;
+    PD_REQUIRE(lds_image_bytes(nk) <= 160 * 1024, "pd_polar_tables_pack: tables exceed the 160 KB LDS of a CU");
+    h.lds_bytes = uint32_t(lds_image_bytes(nk));
     h.total_bytes = uint32_t(need);
     memcpy(base, &h, sizeof(h));
 
@@ -92,26 +108,54 @@ extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_
             lut[(d2 + 255) * kLutSide + (d1 + 255)] =
                 static_cast<float>(0.5 * atan2(d2 / 2.0, d1 / 2.0));
 
-    float* keys = reinterpret_cast<float*>(base + h.off_lds);
-    double* xlo = reinterpret_cast<double*>(base + h.off_lds + size_t(keys_padded(nk)) * 4);
-    double* ylo = xlo + nk;
-    double* slope = ylo + nk;
+    const int nkp = keys_padded(nk);
+    char* img = base + h.off_lds;
+    float* mkeys = reinterpret_cast<float*>(img);
+    uint16_t* bstart = reinterpret_cast<uint16_t*>(img + lds_off_bstart(nk));
+    float* bscale = reinterpret_cast<float*>(img + lds_off_bstart(nk) + size_t(kBuckets + 4) * 2);
+    uint16_t* rank = reinterpret_cast<uint16_t*>(img + lds_off_rank(nk));
+    double* bins = reinterpret_cast<double*>(img + lds_off_bins(nk));
     const double* xs[3] = {x_d, x_s1, x_s2};
     const double* ys[3] = {y_d, y_s1, y_s2};
     const int ns[3] = {n_d, n_s1, n_s2};
+    std::vector<std::pair<float, int>> merged;   // (key, table)
+    merged.reserve(nk);
     int o = 0;
     for (int t = 0; t < 3; ++t) {
         for (int i = 0; i < ns[t]; ++i) {
             PD_REQUIRE(i == 0 || xs[t][i] >= xs[t][i - 1], "pd_polar_tables_pack: x not ascending (table %d)", t);
-            keys[o + i] = floor32(xs[t][i]);
-            if (i >= 1) {  // scipy _call_linear: slope = (y_hi - y_lo) / (x_hi - x_lo)
-                xlo[o + i] = xs[t][i - 1];
-                ylo[o + i] = ys[t][i - 1];
-                slope[o + i] = (ys[t][i] - ys[t][i - 1]) / (xs[t][i] - xs[t][i - 1]);
+            PD_REQUIRE(xs[t][i] >= 0.0, "pd_polar_tables_pack: negative node (table %d)", t);
+            merged.emplace_back(floor32(xs[t][i]), t);
+            if (i >= 1) {  // scipy _call_linear: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope*(x - x_lo) + y_lo
+                double* bin = bins + size_t(o + i) * 4;
+                bin[0] = xs[t][i - 1];
+                bin[1] = (ys[t][i] - ys[t][i - 1]) / (xs[t][i] - xs[t][i - 1]);
+                bin[2] = sin(ys[t][i - 1]);
+                bin[3] = cos(ys[t][i - 1]);
             }
         }
         o += ns[t];
     }
+    std::stable_sort(merged.begin(), merged.end(),
+                     [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+    uint16_t cnt[3] = {0, 0, 0};
+    for (int p = 0; p <= nk; ++p) {
+        rank[4 * p] = cnt[0]; rank[4 * p + 1] = cnt[1]; rank[4 * p + 2] = cnt[2]; rank[4 * p + 3] = 0;
+        if (p < nk) { mkeys[p] = merged[p].first; ++cnt[merged[p].second]; }
+    }
+    for (int p = nk; p < nkp; ++p) mkeys[p] = INFINITY;
+    // guided search: buckets uniform in sqrt(rho) (the tables are ~quadratic in theta at both ends)
+    const double smax = sqrt((double)merged[nk - 1].first);
+    PD_REQUIRE(smax > 0.0, "pd_polar_tables_pack: all nodes are zero");
+    int p = 0;
+    for (int bkt = 0; bkt <= kBuckets; ++bkt) {
+        const double edge = bkt * smax / kBuckets;
+        while (p < nk && sqrt((double)merged[p].first) < edge) ++p;
+        bstart[bkt] = (uint16_t)p;
+    }
+    for (int bkt = kBuckets + 1; bkt < kBuckets + 4; ++bkt) bstart[bkt] = (uint16_t)nk;
+    bscale[0] = (float)(kBuckets / smax);
+    bscale[1] = 0.f;
     return PD_OK;
 }
 
@@ -149,46 +193,125 @@ extern "C" int pd_polar_tables_build(double n, void* host_blob, size_t blob_byte
 // ------------------------------------------------------------------ device side
 namespace {
 
-struct Tab {  // LDS-resident view of one theta table
-    const float* keys;
-    const double* xlo;
-    const double* ylo;
-    const double* slope;
-    int n;
+struct Tabs {  // LDS-resident view of the interpolation tables
+    const float* mkeys;
+    const uint16_t* bstart;
+    const uint2* rank;          // ushort4 packed in 8 bytes
+    const double* bins;         // [nk][4]: x_lo, slope, sin(y_lo), cos(y_lo)
+    float bscale;
+    int nk, n_d, n_s1, n_s2;
 };
 
-// searchsorted(x, v, side='left').clip(1, n-1) on fp32 keys (exact for fp32 v).
-__device__ __forceinline__ int bin_index(const Tab& t, float v) {
-    int pos = 0;  // number of keys strictly less than v
-#pragma unroll
-    for (int step = 2048; step > 0; step >>= 1) {
-        int c = pos + step;
-        if (c <= t.n && t.keys[c - 1] < v) pos = c;
-    }
-    if (v != v) pos = t.n;  // NaN sorts last (numpy)
-    return min(max(pos, 1), t.n - 1);
+__device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char* smem, int nthreads, Tabs& t) {
+    const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
+    const uint4* src = reinterpret_cast<const uint4*>(blob + h->off_lds);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const int n16 = h->lds_bytes / 16;
+    for (int i = threadIdx.x; i < n16; i += nthreads) dst[i] = src[i];
+    t.n_d = h->n_d; t.n_s1 = h->n_s1; t.n_s2 = h->n_s2;
+    t.nk = t.n_d + t.n_s1 + t.n_s2;
+    const int nkp = (t.nk + 3) / 4 * 4;
+    const int off_rank = nkp * 4 + (kBuckets + 4) * 2 + 8;
+    t.mkeys = reinterpret_cast<const float*>(smem);
+    t.bstart = reinterpret_cast<const uint16_t*>(smem + nkp * 4);
+    t.rank = reinterpret_cast<const uint2*>(smem + off_rank);
+    t.bins = reinterpret_cast<const double*>(smem + (off_rank + (t.nk + 1) * 8 + 15) / 16 * 16);
+    __syncthreads();
+    t.bscale = *reinterpret_cast<const float*>(smem + nkp * 4 + (kBuckets + 4) * 2);
 }
 
-__device__ __forceinline__ double interp(const Tab& t, int idx, float v) {
-    // y_new = slope * (x_new - x_lo) + y_lo   (two roundings, -ffp-contract=off)
-    return t.slope[idx] * (static_cast<double>(v) - t.xlo[idx]) + t.ylo[idx];
+// fp64 sin/cos: Cody-Waite with pi/2 = C1 + C2 + C3 (33 + 33 + 53 bits, fdlibm constants) and the
+// fdlibm polynomial kernels on [-pi/4, pi/4]; FMAs are explicit (this file is built with -ffp-contract=off).
+__device__ __forceinline__ void sincos_f64(double x, double& s, double& c) {
+    // Valid (< 1 ulp) while j * C1 is exact, |x| < 1.6e6; uint8 inputs give |theta| <= 2.5e4 (Stokes mode,
+    // rho <= 361).  Beyond that precision degrades gradually; inf / NaN propagate as NaN like numpy.
+    const double j = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-j, 1.57079632673412561417e+00, x);
+    r = fma(-j, 6.07710050630396597660e-11, r);
+    r = fma(-j, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    // __kernel_sin
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    const double sn = fma(r * z, fma(z, ps, -1.66666666666666324348e-01), r);
+    // __kernel_cos
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cs = w + (((1.0 - w) - hz) + z * (z * pc));
+    const int q = static_cast<int>(j) & 3;
+    const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
+// fp32 sin/cos for |x| <= 4 (AoLP in [-pi/2, pi/2], AoLP + pi/2 in [0, pi]); ~1 ulp
+__device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
+    const float j = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-j, 1.5707962512969971f, x);       // pi/2 hi (24 bits)
+    r = fmaf(-j, 7.5497894158615964e-08f, r);         // pi/2 lo
+    const float z = r * r;
+    float ps = fmaf(z, 2.7183114939898219e-06f, -1.9839334836096632e-04f);
+    ps = fmaf(z, ps, 8.3333095718939529e-03f);
+    const float sn = fmaf(r * z, fmaf(z, ps, -1.6666665459843126e-01f), r);
+    float pc = fmaf(z, 2.4390448796277409e-05f, -1.3887316255677255e-03f);
+    pc = fmaf(z, pc, 4.1666645683222281e-02f);
+    const float cs = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    const int q = static_cast<int>(j) & 3;
+    const float a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
+// sin/cos of theta = y_lo + delta from the tabulated sin/cos(y_lo): delta = slope * (rho - x_lo) is at most
+// one table step (1.6e-3 rad) inside the tables, where a short Taylor series is exact to 1e-22; extrapolated
+// rho (beyond the table ends) takes the general reduction.  Equals sin/cos(fl64(theta)) to ~1e-16.
+__device__ __forceinline__ void sincos_bin(const double* __restrict__ bin, double x, double& s, double& c) {
+    const double d = bin[1] * (x - bin[0]);
+    double sd, cd;
+    if (fabs(d) < 4.0e-3) {
+        const double d2 = d * d;
+        sd = d * fma(d2, fma(d2, 8.33333333333333322e-03, -1.66666666666666657e-01), 1.0);
+        cd = fma(d2, fma(d2, fma(d2, -1.38888888888888894e-03, 4.16666666666666644e-02), -0.5), 1.0);
+    } else {
+        sincos_f64(d, sd, cd);
+    }
+    s = fma(bin[2], cd, bin[3] * sd);
+    c = fma(bin[3], cd, -(bin[2] * sd));
 }
 
 // theta lookups + the three physical normals of one pixel (normals_vec.py:11-60, pre_encoders.py:99-113)
-__device__ __forceinline__ void normals9(float rho, float phi, const Tab& td, const Tab& t1, const Tab& t2,
-                                         float (&v)[9], int (&bi)[3]) {
+__device__ __forceinline__ void normals9(float rho, float phi, const Tabs& t, float (&v)[9], int (&bi)[3]) {
     const float kHalfPi = static_cast<float>(1.5707963267948966);
-    bi[0] = bin_index(td, rho); bi[1] = bin_index(t1, rho); bi[2] = bin_index(t2, rho);
-    const double thd = interp(td, bi[0], rho);
-    const double th1 = interp(t1, bi[1], rho);
-    const double th2 = interp(t2, bi[2], rho);
+    // pos = number of merged keys strictly below rho (searchsorted-left on the merged key array).
+    // A sqrt(rho) bucket table narrows the range to a few keys (+-1 bucket of slack covers the rounding of
+    // the fp32 sqrt), then an exact binary search finishes.
+    const float u = sqrtf(fmaxf(rho, 0.f)) * t.bscale;
+    const int bk = (int)fminf(u, (float)kBuckets);
+    int lo = t.bstart[max(bk - 1, 0)], hi = t.bstart[bk + 2];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (t.mkeys[mid] < rho) lo = mid + 1; else hi = mid;
+    }
+    const uint2 rk = t.rank[lo];
+    const bool isnan_ = rho != rho;   // NaN sorts last (numpy)
+    bi[0] = isnan_ ? t.n_d - 1 : min(max((int)(rk.x & 0xffffu), 1), t.n_d - 1);
+    bi[1] = isnan_ ? t.n_s1 - 1 : min(max((int)(rk.x >> 16), 1), t.n_s1 - 1);
+    bi[2] = isnan_ ? t.n_s2 - 1 : min(max((int)(rk.y & 0xffffu), 1), t.n_s2 - 1);
+    const double x = static_cast<double>(rho);
     double sd, cd, s1, c1, s2, c2;
-    sincos(thd, &sd, &cd);
-    sincos(th1, &s1, &c1);
-    sincos(th2, &s2, &c2);
+    sincos_bin(t.bins + 4 * bi[0], x, sd, cd);
+    sincos_bin(t.bins + 4 * (t.n_d + bi[1]), x, s1, c1);
+    sincos_bin(t.bins + 4 * (t.n_d + t.n_s1 + bi[2]), x, s2, c2);
     float sp, cp, sq, cq;
-    sincosf(phi, &sp, &cp);             // torch.cos/sin on the fp32 AoLP
-    sincosf(phi + kHalfPi, &sq, &cq);   // phi + np.pi/2 evaluated in fp32 (pre_encoders.py:108-109)
+    sincos_f32(phi, sp, cp);             // torch.cos/sin on the fp32 AoLP
+    sincos_f32(phi + kHalfPi, sq, cq);   // phi + np.pi/2 evaluated in fp32 (pre_encoders.py:108-109)
     v[0] = static_cast<float>(static_cast<double>(cp) * sd);
     v[1] = static_cast<float>(static_cast<double>(sp) * sd);
     v[2] = static_cast<float>(cd);
@@ -198,27 +321,6 @@ __device__ __forceinline__ void normals9(float rho, float phi, const Tab& td, co
     v[6] = static_cast<float>(static_cast<double>(cq) * s2);
     v[7] = static_cast<float>(static_cast<double>(sq) * s2);
     v[8] = static_cast<float>(c2);
-}
-
-// stage keys + bins of the three tables into LDS (16-byte copies) and build the views
-__device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char* smem, int nthreads, Tab& td, Tab& t1,
-                                             Tab& t2) {
-    const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
-    const uint4* src = reinterpret_cast<const uint4*>(blob + h->off_lds);
-    uint4* dst = reinterpret_cast<uint4*>(smem);
-    const int n16 = h->lds_bytes / 16;
-    for (int i = threadIdx.x; i < n16; i += nthreads) dst[i] = src[i];
-    const int nk = h->n_d + h->n_s1 + h->n_s2;
-    const float* keys = reinterpret_cast<const float*>(smem);
-    const double* xlo = reinterpret_cast<const double*>(smem + ((nk + 3) / 4 * 4) * 4);
-    const double* ylo = xlo + nk;
-    const double* slope = ylo + nk;
-    td = Tab{keys, xlo, ylo, slope, h->n_d};
-    int o = h->n_d;
-    t1 = Tab{keys + o, xlo + o, ylo + o, slope + o, h->n_s1};
-    o += h->n_s1;
-    t2 = Tab{keys + o, xlo + o, ylo + o, slope + o, h->n_s2};
-    __syncthreads();
 }
 
 struct Px {
@@ -254,22 +356,25 @@ __device__ __forceinline__ Px xolp_pixel(int i0, int i45, int i90, int i135, con
     return p;
 }
 
-constexpr int kThreads = 512;
+constexpr int kThreads = 512;    // XOLP-only kernels: 64 VGPRs, 4 workgroups per CU
+constexpr int kThreadsN = 768;   // kernels with the fp64 normals: one 12-wave workgroup per CU (3 waves/SIMD, <= 168 VGPRs);
+                                 // its 90 KB LDS image of the tables is staged once per CU
 
 template <int MODE, bool NORMALS>
-__global__ __launch_bounds__(kThreads) void polar_kernel(
+__global__ __launch_bounds__(NORMALS ? kThreadsN : kThreads) void polar_kernel(
     const uint8_t* __restrict__ pol, const uint8_t* __restrict__ mask, float* __restrict__ xolp,
     float* __restrict__ xolp_std, float* __restrict__ normals, int* __restrict__ ints,
     const char* __restrict__ blob, long P, long Pout, int wq_in, int wq_out, long quads_per_img, long total_quads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
     const float* lut = reinterpret_cast<const float*>(blob + h->off_lut);
-    Tab td, t1, t2;
-    if (NORMALS) stage_tables(blob, smem, kThreads, td, t1, t2);
+    constexpr int NTH = NORMALS ? kThreadsN : kThreads;
+    Tabs tabs;
+    if (NORMALS) stage_tables(blob, smem, NTH, tabs);
     const float kMean = static_cast<float>(0.08693199701957657);
     const float kStd = static_cast<float>(0.44430732785457433);
 
-    for (long q = blockIdx.x * (long)kThreads + threadIdx.x; q < total_quads; q += (long)gridDim.x * kThreads) {
+    for (long q = blockIdx.x * (long)NTH + threadIdx.x; q < total_quads; q += (long)gridDim.x * NTH) {
         const long b = q / quads_per_img;
         const long ro = q - b * quads_per_img;          // quad index inside the (pitched) output plane
         const long row = ro / wq_out;
@@ -296,8 +401,11 @@ __global__ __launch_bounds__(kThreads) void polar_kernel(
 
         float o_rho[4], o_phi[4], o_n[9][4];
         int o_i[5][4];
+        // With the normals the four pixels are processed strictly one after the other (scheduling barrier
+        // between them): interleaving four fp64 trig chains quadruples the live registers.
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (NORMALS && (j & 1) == 0) __builtin_amdgcn_sched_barrier(0);   // pixels are interleaved in pairs
             const int sh = 8 * j;
             const bool on = ((wm >> sh) & 0xffu) != 0;
             int i0 = (w0 >> sh) & 0xff, i45 = (w45 >> sh) & 0xff, i90 = (w90 >> sh) & 0xff, i135 = (w135 >> sh) & 0xff;
@@ -311,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void polar_kernel(
             if (NORMALS) {
                 int bi[3];
                 float v[9];
-                normals9(p.rho, p.phi, td, t1, t2, v, bi);
+                normals9(p.rho, p.phi, tabs, v, bi);
                 o_i[2][j] = bi[0]; o_i[3][j] = bi[1]; o_i[4][j] = bi[2];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) o_n[c][j] = (MODE == PD_POLAR_STOKES && !on) ? 0.f : v[c];
@@ -346,14 +454,14 @@ __global__ __launch_bounds__(kThreads) void polar_kernel(
 }
 
 // get_normals() on an existing fp32 XOLP tensor (pre_encoders.py:99-113): [B,2,H,W] -> [B,9,H,W]
-__global__ __launch_bounds__(kThreads) void normals_from_xolp_kernel(const float* __restrict__ xolp,
+__global__ __launch_bounds__(kThreadsN) void normals_from_xolp_kernel(const float* __restrict__ xolp,
                                                                      float* __restrict__ normals,
                                                                      const char* __restrict__ blob, long P,
                                                                      long quads_per_img, long total_quads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Tab td, t1, t2;
-    stage_tables(blob, smem, kThreads, td, t1, t2);
-    for (long q = blockIdx.x * (long)kThreads + threadIdx.x; q < total_quads; q += (long)gridDim.x * kThreads) {
+    Tabs tabs;
+    stage_tables(blob, smem, kThreadsN, tabs);
+    for (long q = blockIdx.x * (long)kThreadsN + threadIdx.x; q < total_quads; q += (long)gridDim.x * kThreadsN) {
         const long b = q / quads_per_img;
         const long p4 = (q - b * quads_per_img) * 4;
         const float4 r4 = *reinterpret_cast<const float4*>(xolp + (b * 2) * P + p4);
@@ -362,8 +470,9 @@ __global__ __launch_bounds__(kThreads) void normals_from_xolp_kernel(const float
         float o_n[9][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
             float v[9]; int bi[3];
-            normals9(rr[j], ff[j], td, t1, t2, v, bi);
+            normals9(rr[j], ff[j], tabs, v, bi);
 #pragma unroll
             for (int c = 0; c < 9; ++c) o_n[c][j] = v[c];
         }
@@ -372,6 +481,18 @@ __global__ __launch_bounds__(kThreads) void normals_from_xolp_kernel(const float
         for (int c = 0; c < 9; ++c)
             *reinterpret_cast<float4*>(o + c * P) = make_float4(o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
     }
+}
+
+inline size_t lds_from_blob_bytes(size_t tables_bytes) {
+    return tables_bytes - (sizeof(PolarHeader) + ((size_t(kLutCount) * 4 + 15) / 16 * 16));
+}
+
+template <typename K>
+int set_lds_limit(K kernel, size_t lds) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return pd::fail(PD_ELAUNCH, "pd_polar: cannot reserve %zu bytes of LDS", lds);
+    return PD_OK;
 }
 
 }  // namespace
@@ -384,13 +505,17 @@ extern "C" int pd_polar_normals_from_xolp(const void* xolp, void* normals, const
     if (B == 0) return PD_OK;
     PD_REQUIRE(xolp && normals && tables, "pd_polar_normals_from_xolp: null pointer");
     PD_REQUIRE(pd::aligned16(xolp) && pd::aligned16(normals) && pd::aligned16(tables), "pd_polar_normals_from_xolp: unaligned");
-    PD_REQUIRE(tables_bytes >= sizeof(PolarHeader), "pd_polar_normals_from_xolp: tables blob too small");
-    const size_t lds = tables_bytes - (sizeof(PolarHeader) + ((size_t(kLutCount) * 4 + 15) / 16 * 16));
-    PD_REQUIRE(lds <= 64 * 1024, "pd_polar_normals_from_xolp: theta tables need %zu bytes of LDS", lds);
+    PD_REQUIRE(tables_bytes >= sizeof(PolarHeader) + size_t(kLutCount) * 4, "pd_polar_normals_from_xolp: tables blob too small");
+    const size_t lds = lds_from_blob_bytes(tables_bytes);
+    PD_REQUIRE(lds <= 160 * 1024, "pd_polar_normals_from_xolp: theta tables need %zu bytes of LDS", lds);
+    {
+        int rc = set_lds_limit(normals_from_xolp_kernel, lds);
+        if (rc) return rc;
+    }
     const long qpi = P / 4, total = qpi * B;
-    long blocks = (total + kThreads - 1) / kThreads;
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(normals_from_xolp_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream,
+    long blocks = (total + kThreadsN - 1) / kThreadsN;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(normals_from_xolp_kernel, dim3((unsigned)blocks), dim3(kThreadsN), lds, (hipStream_t)stream,
                        (const float*)xolp, (float*)normals, (const char*)tables, P, qpi, total);
     return pd::check_launch("pd_polar_normals_from_xolp");
 }
@@ -407,7 +532,7 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
     PD_REQUIRE(Wout >= W, "pd_polar_fwd: output pitch %d < W %d", Wout, W);
     PD_REQUIRE(Wout == W ? P % 4 == 0 : (W % 4 == 0 && Wout % 4 == 0),
                "pd_polar_fwd: H*W (or W and the output pitch, when they differ) must be multiples of 4");
-    PD_REQUIRE(tables_bytes >= sizeof(PolarHeader), "pd_polar_fwd: tables blob too small");
+    PD_REQUIRE(tables_bytes >= sizeof(PolarHeader) + size_t(kLutCount) * 4, "pd_polar_fwd: tables blob too small");
     PD_REQUIRE(pd::aligned16(pol) && pd::aligned16(xolp) && pd::aligned16(xolp_std) && pd::aligned16(normals) &&
                    pd::aligned16(ints) && pd::aligned16(tables) && (!mask || pd::aligned16(mask)),
                "pd_polar_fwd: pointers must be 16-byte aligned");
@@ -416,24 +541,26 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
     const int wq_in = Wout == W ? (int)(P / 4) : W / 4, wq_out = Wout == W ? (int)(P / 4) : Wout / 4;
     const long qpi = Pout / 4, total = qpi * B;
     const bool need_normals = normals != nullptr || ints != nullptr;
-    // LDS image size is fixed by the table node counts; validated against the blob size on the
-    // host by the caller's pd_polar_tables_bytes(); the default tables need 56,000 bytes.
-    const size_t lds = need_normals ? tables_bytes - (sizeof(PolarHeader) + ((size_t(kLutCount) * 4 + 15) / 16 * 16)) : 0;
-    PD_REQUIRE(lds <= 64 * 1024, "pd_polar_fwd: theta tables need %zu bytes of LDS (max 65536)", lds);
-    long blocks = (total + kThreads - 1) / kThreads;
-    const long cap = need_normals ? 256L * 2 : 256L * 4;  // persistent: 2 (normals) / 4 (xolp only) blocks per CU
+    // LDS image size is fixed by the table node counts (72,016 bytes for the default 1000/625/375 nodes)
+    const size_t lds = need_normals ? lds_from_blob_bytes(tables_bytes) : 0;
+    PD_REQUIRE(lds <= 160 * 1024, "pd_polar_fwd: theta tables need %zu bytes of LDS (max 163840)", lds);
+    const int nth = need_normals ? kThreadsN : kThreads;
+    long blocks = (total + nth - 1) / nth;
+    const long cap = need_normals ? 256L : 256L * 4;      // persistent: 1 (normals) / 4 (xolp only) workgroups per CU
     if (blocks > cap) blocks = cap;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    auto args = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, st,
+    auto go = [&](auto kern) -> int {
+        int rc = set_lds_limit(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nth), lds, st,
                            static_cast<const uint8_t*>(pol), static_cast<const uint8_t*>(mask),
                            static_cast<float*>(xolp), static_cast<float*>(xolp_std), static_cast<float*>(normals),
                            static_cast<int*>(ints), static_cast<const char*>(tables), P, Pout, wq_in, wq_out, qpi, total);
+        return PD_OK;
     };
-    if (mode == PD_POLAR_LS) {
-        if (need_normals) args(polar_kernel<PD_POLAR_LS, true>); else args(polar_kernel<PD_POLAR_LS, false>);
-    } else {
-        if (need_normals) args(polar_kernel<PD_POLAR_STOKES, true>); else args(polar_kernel<PD_POLAR_STOKES, false>);
-    }
+    int rc;
+    if (mode == PD_POLAR_LS) rc = need_normals ? go(polar_kernel<PD_POLAR_LS, true>) : go(polar_kernel<PD_POLAR_LS, false>);
+    else rc = need_normals ? go(polar_kernel<PD_POLAR_STOKES, true>) : go(polar_kernel<PD_POLAR_STOKES, false>);
+    if (rc) return rc;
     return pd::check_launch("pd_polar_fwd");
 }

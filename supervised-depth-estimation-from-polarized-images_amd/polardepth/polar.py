@@ -65,7 +65,7 @@ def _device_tables(n, device_index):
     return blob.to(torch.device("cuda", device_index))
 
 
-def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=None, out_width=None):
+def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=None, out_width=None, out=None):
     """Run K1 on ``pol`` [B,4,H,W] uint8 (planes 0/45/90/135 deg) on the GPU.
 
     want: any of "xolp", "xolp_std", "normals", "ints".  Returns a dict of fp32 NCHW tensors
@@ -80,17 +80,13 @@ def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=No
     B, _, H, W = pol.shape
     if tables is None:
         tables = _device_tables(float(n), pol.device.index)
-    out = {}
+    out = dict(out) if out is not None else {}      # pre-allocated outputs may be passed in
     Wout = W if out_width is None else int(out_width)
     mk = lambda c, dt=torch.float32: torch.empty((B, c, H, Wout), dtype=dt, device=pol.device)
-    if "xolp" in want:
-        out["xolp"] = mk(2)
-    if "xolp_std" in want:
-        out["xolp_std"] = mk(2)
-    if "normals" in want:
-        out["normals"] = mk(9)
-    if "ints" in want:
-        out["ints"] = mk(5, torch.int32)
+    for key, ch, dt in (("xolp", 2, torch.float32), ("xolp_std", 2, torch.float32), ("normals", 9, torch.float32),
+                        ("ints", 5, torch.int32)):
+        if key in want and key not in out:
+            out[key] = mk(ch, dt)
     if mask is not None:
         mask = mask.to(torch.uint8).contiguous()
     with torch.cuda.device(pol.device):

@@ -38,28 +38,52 @@ def test_table_blob_numpy_vs_oracle_tables():
         np.testing.assert_array_equal(y, t[k][1])
 
 
+def _blob_offsets(nk=2000, buckets=1024):
+    off_bstart = nk * 4
+    off_rank = off_bstart + (buckets + 4) * 2 + 8
+    off_bins = (off_rank + (nk + 1) * 8 + 15) // 16 * 16
+    return off_bstart, off_rank, off_bins
+
+
 def test_table_blob_layout_and_lut():
     blob = pdpolar.pack_tables(pdpolar.theta_tables_numpy(1.5)).numpy().tobytes()
     hdr = np.frombuffer(blob[:32], dtype=np.uint32)
-    assert hdr[0] == 0x50444c54 and tuple(hdr[1:4]) == (1000, 625, 375)
+    assert hdr[0] == 0x50444c33 and tuple(hdr[1:4]) == (1000, 625, 375)
     off_lut, off_lds, lds_bytes, total = (int(v) for v in hdr[4:8])
-    assert total == len(blob) and lds_bytes <= 64 * 1024
+    assert total == len(blob) and lds_bytes <= 160 * 1024
     lut = np.frombuffer(blob[off_lut:off_lut + 511 * 511 * 4], dtype=np.float32).reshape(511, 511)
     d = np.arange(-255, 256, dtype=np.float64)
     ref = (0.5 * np.arctan2(d[:, None] / 2, d[None, :] / 2)).astype(np.float32)   # xolp.py:30
     np.testing.assert_array_equal(lut, ref)
     assert lut[255, 0] == np.float32(np.pi / 2)            # canonical branch: x2 == 0, x1 < 0 -> +pi/2
-    # keys are floor32 of the fp64 nodes: searchsorted on them is exact for fp32 queries
+    # merged keys are floor32 of the fp64 nodes, sorted; rank[p] = per-table counts among the first p keys,
+    # so rank[searchsorted(merged, v)] reproduces the three per-table searchsorted results for fp32 v
     nk = 2000
-    keys = np.frombuffer(blob[off_lds:off_lds + nk * 4], dtype=np.float32)
-    x_all = np.concatenate([opolar.theta_tables(1.5)[k][0] for k in ("diffuse", "spec1", "spec2")])
-    assert np.all(keys.astype(np.float64) <= x_all)
-    assert np.all(np.nextafter(keys, np.float32(np.inf)).astype(np.float64) > x_all)
-    bins = np.frombuffer(blob[off_lds + nk * 4:off_lds + nk * 4 + nk * 24], dtype=np.float64).reshape(3, nk)
+    img = blob[off_lds:off_lds + lds_bytes]
+    off_bstart, off_rank, off_bins = _blob_offsets(nk)
+    mkeys = np.frombuffer(img[:nk * 4], dtype=np.float32)
+    assert np.all(np.diff(mkeys) >= 0)
+    rank = np.frombuffer(img[off_rank:off_rank + (nk + 1) * 8], dtype=np.uint16).reshape(nk + 1, 4)
+    assert tuple(rank[0][:3]) == (0, 0, 0) and tuple(rank[nk][:3]) == (1000, 625, 375)
+    tabs = [opolar.theta_tables(1.5)[k][0] for k in ("diffuse", "spec1", "spec2")]
+    rng = np.random.default_rng(0)
+    q = np.concatenate([rng.random(5000).astype(np.float32) * 1.2, mkeys[::7], np.float32([0, 1, 2, 0.38461538])])
+    pos = np.searchsorted(mkeys, q, side="left")
+    for t in range(3):
+        np.testing.assert_array_equal(rank[pos, t], np.searchsorted(tabs[t], q.astype(np.float64), side="left"))
+    # sqrt(rho) bucket index: the true position always lies in [bstart[b-1], bstart[b+2]] for the device's b
+    bstart = np.frombuffer(img[off_bstart:off_bstart + 1028 * 2], dtype=np.uint16).astype(int)
+    bscale = np.frombuffer(img[off_bstart + 1028 * 2:off_bstart + 1028 * 2 + 4], dtype=np.float32)[0]
+    assert np.all(np.diff(bstart) >= 0) and bstart[0] == 0 and bstart[1025] == nk
+    b = np.minimum(np.sqrt(np.maximum(q, 0)).astype(np.float32) * bscale, 1024).astype(int)
+    assert np.all(bstart[np.maximum(b - 1, 0)] <= pos) and np.all(pos <= bstart[b + 2])
+    assert (bstart[2:] - bstart[:-2]).max() <= 64          # the guided range stays small everywhere
+    bins = np.frombuffer(img[off_bins:off_bins + nk * 32], dtype=np.float64).reshape(nk, 4)
     x, y = opolar.theta_tables(1.5)["diffuse"]
-    np.testing.assert_array_equal(bins[0, 1:1000], x[:-1])
-    np.testing.assert_array_equal(bins[1, 1:1000], y[:-1])
-    np.testing.assert_array_equal(bins[2, 1:1000], (y[1:] - y[:-1]) / (x[1:] - x[:-1]))
+    np.testing.assert_array_equal(bins[1:1000, 0], x[:-1])
+    np.testing.assert_array_equal(bins[1:1000, 1], (y[1:] - y[:-1]) / (x[1:] - x[:-1]))
+    np.testing.assert_allclose(bins[1:1000, 2], np.sin(y[:-1]), rtol=0, atol=2e-16)
+    np.testing.assert_allclose(bins[1:1000, 3], np.cos(y[:-1]), rtol=0, atol=2e-16)
 
 
 def test_libm_tables_close_to_numpy_tables():
@@ -68,10 +92,11 @@ def test_libm_tables_close_to_numpy_tables():
     assert a.shape == b.shape
     off = 64 + (511 * 511 * 4 + 15) // 16 * 16
     np.testing.assert_array_equal(a[:off], b[:off])         # header + LUT identical
-    fa = np.frombuffer(a[off + 8000:].tobytes(), dtype=np.float64)
-    fb = np.frombuffer(b[off + 8000:].tobytes(), dtype=np.float64)
-    # x_lo / y_lo within a few ulp (libm vs NumPy sin/cos); slopes amplify that near the flat ends
-    np.testing.assert_allclose(fa[:4000], fb[:4000], rtol=1e-13, atol=1e-300)
+    _, _, off_bins = _blob_offsets()
+    fa = np.frombuffer(a[off + off_bins:off + off_bins + 2000 * 32].tobytes(), dtype=np.float64).reshape(2000, 4)
+    fb = np.frombuffer(b[off + off_bins:off + off_bins + 2000 * 32].tobytes(), dtype=np.float64).reshape(2000, 4)
+    # x_lo and sin/cos(y_lo) within a few ulp (libm vs NumPy sin/cos); slopes amplify that near the flat ends
+    np.testing.assert_allclose(fa[:, [0, 2, 3]], fb[:, [0, 2, 3]], rtol=1e-12, atol=1e-15)
 
 
 def test_bad_arguments_are_rejected():
