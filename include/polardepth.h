@@ -52,6 +52,10 @@ int pd_version(void);
  */
 #define PD_POLAR_LS 0
 #define PD_POLAR_STOKES 1
+/* flags: default (0) = fp64 sin/cos(theta) rounded once and cos/sin(fl32(phi+pi/2)) like the reference;
+ * PD_POLAR_FAST_NORMALS = fp32 angle addition on fp32 tables with residuals (|err| ~1e-7, cos/sin(phi+pi/2) by
+ * identity), ~8 % faster.  DoLP / AoLP / index maps are bit-exact in both. */
+#define PD_POLAR_FAST_NORMALS 1
 
 /* bytes needed for the table blob with n_d / n_s1 / n_s2 table nodes */
 size_t pd_polar_tables_bytes(int n_d, int n_s1, int n_s2);
@@ -79,12 +83,12 @@ int pd_polar_tables_build(double n, void* host_blob, size_t blob_bytes, size_t* 
  */
 int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, void* normals,
                  void* ints, const void* tables, size_t tables_bytes,
-                 int B, int H, int W, int Wout, int mode, void* stream);
+                 int B, int H, int W, int Wout, int mode, int flags, void* stream);
 
 /* get_normals() on an existing fp32 XOLP tensor (pre_encoders.py:99-113, the path taken when a
  * data loader already produced inputs[("xolp",0,0)]): xolp [B,2,H,W] -> normals [B,9,H,W]. */
 int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tables, size_t tables_bytes,
-                               int B, int H, int W, void* stream);
+                               int B, int H, int W, int flags, void* stream);
 
 /* ------------------------------------------------------------------------- K2
  * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).

@@ -49,7 +49,9 @@ struct PolarHeader {   // 64 bytes, little endian
     uint32_t off_lds;    // start of the LDS image (keys, then bins)
     uint32_t lds_bytes;  // size of the LDS image (multiple of 16)
     uint32_t total_bytes;
-    uint32_t pad[8];
+    uint32_t off_bins32; // float[nk][8] fp32 image of the bins (fast normals), absolute offset
+    uint32_t img_bins;   // offset of the fp64 bins inside the LDS image (= bytes of the common part)
+    uint32_t pad[6];
 };
 static_assert(sizeof(PolarHeader) == 64, "header size");
 
@@ -60,6 +62,9 @@ static_assert(sizeof(PolarHeader) == 64, "header size");
 //   uint16_t rank[nk + 1][4]      rank[p] = (#diffuse, #spec1, #spec2, 0) among the first p merged keys
 //   double   bins[nk][4]          per table (diffuse | spec1 | spec2), entry i describes bin idx == i:
 //                                 x_lo, slope, sin(y_lo), cos(y_lo)
+// After the image the blob carries the fp32 form of the bins used by the fast normals path, which replaces
+// bins[] in LDS:  float fbins[nk][8] = x_lo32 (= floor32 x_lo), (float)(x_lo - x_lo32), (float)slope,
+//                                      s = (float)sin, (float)(sin - s), c = (float)cos, (float)(cos - c), 0
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int keys_padded(int nk) { return (nk + 3) / 4 * 4; }
 inline size_t lds_off_bstart(int nk) { return size_t(keys_padded(nk)) * 4; }
@@ -77,7 +82,8 @@ float floor32(double x) {  // largest fp32 <= x
 
 extern "C" size_t pd_polar_tables_bytes(int n_d, int n_s1, int n_s2) {
     if (n_d < 2 || n_s1 < 2 || n_s2 < 2) return 0;
-    return sizeof(PolarHeader) + round_up(size_t(kLutCount) * 4, 16) + lds_image_bytes(n_d + n_s1 + n_s2);
+    return sizeof(PolarHeader) + round_up(size_t(kLutCount) * 4, 16) + lds_image_bytes(n_d + n_s1 + n_s2) +
+           size_t(n_d + n_s1 + n_s2) * 32;
 }
 
 extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_d,
@@ -98,6 +104,8 @@ extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_
     const int nk = n_d + n_s1 + n_s2;
     PD_REQUIRE(lds_image_bytes(nk) <= 160 * 1024, "pd_polar_tables_pack: tables exceed the 160 KB LDS of a CU");
     h.lds_bytes = uint32_t(lds_image_bytes(nk));
+    h.off_bins32 = h.off_lds + h.lds_bytes;
+    h.img_bins = uint32_t(lds_off_bins(nk));
     h.total_bytes = uint32_t(need);
     memcpy(base, &h, sizeof(h));
 
@@ -132,6 +140,10 @@ extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_
                 bin[1] = (ys[t][i] - ys[t][i - 1]) / (xs[t][i] - xs[t][i - 1]);
                 bin[2] = sin(ys[t][i - 1]);
                 bin[3] = cos(ys[t][i - 1]);
+                float* fb = reinterpret_cast<float*>(base + h.off_bins32) + size_t(o + i) * 8;
+                fb[0] = floor32(bin[0]); fb[1] = (float)(bin[0] - (double)fb[0]); fb[2] = (float)bin[1];
+                fb[3] = (float)bin[2]; fb[4] = (float)(bin[2] - (double)fb[3]);
+                fb[5] = (float)bin[3]; fb[6] = (float)(bin[3] - (double)fb[5]); fb[7] = 0.f;
             }
         }
         o += ns[t];
@@ -197,17 +209,21 @@ struct Tabs {  // LDS-resident view of the interpolation tables
     const float* mkeys;
     const uint16_t* bstart;
     const uint2* rank;          // ushort4 packed in 8 bytes
-    const double* bins;         // [nk][4]: x_lo, slope, sin(y_lo), cos(y_lo)
+    const double* bins;         // [nk][4]: x_lo, slope, sin(y_lo), cos(y_lo)  (LDS when PRECISE, else global)
+    const float* fbins;         // [nk][8] fp32 image (LDS, fast path only)
     float bscale;
     int nk, n_d, n_s1, n_s2;
 };
 
+template <bool PRECISE>
 __device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char* smem, int nthreads, Tabs& t) {
     const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
-    const uint4* src = reinterpret_cast<const uint4*>(blob + h->off_lds);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    const int n16 = h->lds_bytes / 16;
-    for (int i = threadIdx.x; i < n16; i += nthreads) dst[i] = src[i];
+    const uint4* src = reinterpret_cast<const uint4*>(blob + h->off_lds);
+    const int ncommon = h->img_bins / 16, n16 = h->lds_bytes / 16;
+    for (int i = threadIdx.x; i < ncommon; i += nthreads) dst[i] = src[i];
+    const uint4* bsrc = PRECISE ? src + ncommon : reinterpret_cast<const uint4*>(blob + h->off_bins32);
+    for (int i = threadIdx.x; i < n16 - ncommon; i += nthreads) dst[ncommon + i] = bsrc[i];
     t.n_d = h->n_d; t.n_s1 = h->n_s1; t.n_s2 = h->n_s2;
     t.nk = t.n_d + t.n_s1 + t.n_s2;
     const int nkp = (t.nk + 3) / 4 * 4;
@@ -215,7 +231,9 @@ __device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char
     t.mkeys = reinterpret_cast<const float*>(smem);
     t.bstart = reinterpret_cast<const uint16_t*>(smem + nkp * 4);
     t.rank = reinterpret_cast<const uint2*>(smem + off_rank);
-    t.bins = reinterpret_cast<const double*>(smem + (off_rank + (t.nk + 1) * 8 + 15) / 16 * 16);
+    t.fbins = reinterpret_cast<const float*>(smem + h->img_bins);
+    t.bins = PRECISE ? reinterpret_cast<const double*>(smem + h->img_bins)
+                     : reinterpret_cast<const double*>(blob + h->off_lds + h->img_bins);
     __syncthreads();
     t.bscale = *reinterpret_cast<const float*>(smem + nkp * 4 + (kBuckets + 4) * 2);
 }
@@ -286,7 +304,30 @@ __device__ __forceinline__ void sincos_bin(const double* __restrict__ bin, doubl
     c = fma(bin[3], cd, -(bin[2] * sd));
 }
 
+// fp32 form of the same angle addition for the fast path: (rho - x_lo32) is exact (neighbouring floats), the
+// residuals of x_lo / sin / cos restore the bits the fp32 table entries drop; error ~1e-7 absolute.
+// Extrapolated rho falls back to the fp64 routine (bins read from global memory).
+__device__ __forceinline__ void sincos_bin_fast(const float* __restrict__ fb, const double* __restrict__ gbin,
+                                                float rho, float& s, float& c) {
+    const float4 a = *reinterpret_cast<const float4*>(fb);       // x_lo32, dx, slope, sin
+    const float4 b = *reinterpret_cast<const float4*>(fb + 4);   // sin residual, cos, cos residual
+    const float d = a.z * ((rho - a.x) - a.y);
+    if (fabsf(d) < 4.0e-3f) {
+        const float d2 = d * d;
+        const float sd = d * fmaf(d2, fmaf(d2, 8.3333338e-03f, -1.6666667e-01f), 1.0f);
+        const float cd = fmaf(d2, fmaf(d2, 4.1666668e-02f, -0.5f), 1.0f);
+        s = fmaf(a.w, cd, fmaf(b.y, sd, b.x));
+        c = fmaf(b.y, cd, fmaf(-a.w, sd, b.z));
+    } else {
+        double sd, cd;
+        sincos_bin(gbin, static_cast<double>(rho), sd, cd);
+        s = static_cast<float>(sd);
+        c = static_cast<float>(cd);
+    }
+}
+
 // theta lookups + the three physical normals of one pixel (normals_vec.py:11-60, pre_encoders.py:99-113)
+template <bool PRECISE>
 __device__ __forceinline__ void normals9(float rho, float phi, const Tabs& t, float (&v)[9], int (&bi)[3]) {
     const float kHalfPi = static_cast<float>(1.5707963267948966);
     // pos = number of merged keys strictly below rho (searchsorted-left on the merged key array).
@@ -304,23 +345,37 @@ __device__ __forceinline__ void normals9(float rho, float phi, const Tabs& t, fl
     bi[0] = isnan_ ? t.n_d - 1 : min(max((int)(rk.x & 0xffffu), 1), t.n_d - 1);
     bi[1] = isnan_ ? t.n_s1 - 1 : min(max((int)(rk.x >> 16), 1), t.n_s1 - 1);
     bi[2] = isnan_ ? t.n_s2 - 1 : min(max((int)(rk.y & 0xffffu), 1), t.n_s2 - 1);
-    const double x = static_cast<double>(rho);
-    double sd, cd, s1, c1, s2, c2;
-    sincos_bin(t.bins + 4 * bi[0], x, sd, cd);
-    sincos_bin(t.bins + 4 * (t.n_d + bi[1]), x, s1, c1);
-    sincos_bin(t.bins + 4 * (t.n_d + t.n_s1 + bi[2]), x, s2, c2);
-    float sp, cp, sq, cq;
+    const int i0 = bi[0], i1 = t.n_d + bi[1], i2 = t.n_d + t.n_s1 + bi[2];
+    float sp, cp;
     sincos_f32(phi, sp, cp);             // torch.cos/sin on the fp32 AoLP
-    sincos_f32(phi + kHalfPi, sq, cq);   // phi + np.pi/2 evaluated in fp32 (pre_encoders.py:108-109)
-    v[0] = static_cast<float>(static_cast<double>(cp) * sd);
-    v[1] = static_cast<float>(static_cast<double>(sp) * sd);
-    v[2] = static_cast<float>(cd);
-    v[3] = static_cast<float>(static_cast<double>(cq) * s1);
-    v[4] = static_cast<float>(static_cast<double>(sq) * s1);
-    v[5] = static_cast<float>(c1);
-    v[6] = static_cast<float>(static_cast<double>(cq) * s2);
-    v[7] = static_cast<float>(static_cast<double>(sq) * s2);
-    v[8] = static_cast<float>(c2);
+    if (PRECISE) {
+        const double x = static_cast<double>(rho);
+        double sd, cd, s1, c1, s2, c2;
+        sincos_bin(t.bins + 4 * i0, x, sd, cd);
+        sincos_bin(t.bins + 4 * i1, x, s1, c1);
+        sincos_bin(t.bins + 4 * i2, x, s2, c2);
+        float sq, cq;
+        sincos_f32(phi + kHalfPi, sq, cq);   // phi + np.pi/2 evaluated in fp32 (pre_encoders.py:108-109)
+        v[0] = static_cast<float>(static_cast<double>(cp) * sd);
+        v[1] = static_cast<float>(static_cast<double>(sp) * sd);
+        v[2] = static_cast<float>(cd);
+        v[3] = static_cast<float>(static_cast<double>(cq) * s1);
+        v[4] = static_cast<float>(static_cast<double>(sq) * s1);
+        v[5] = static_cast<float>(c1);
+        v[6] = static_cast<float>(static_cast<double>(cq) * s2);
+        v[7] = static_cast<float>(static_cast<double>(sq) * s2);
+        v[8] = static_cast<float>(c2);
+    } else {
+        float sd, cd, s1, c1, s2, c2;
+        sincos_bin_fast(t.fbins + 8 * i0, t.bins + 4 * i0, rho, sd, cd);
+        sincos_bin_fast(t.fbins + 8 * i1, t.bins + 4 * i1, rho, s1, c1);
+        sincos_bin_fast(t.fbins + 8 * i2, t.bins + 4 * i2, rho, s2, c2);
+        // cos(phi + pi/2) = -sin(phi), sin(phi + pi/2) = cos(phi): within 2e-7 of the reference's fp32
+        // evaluation of cos/sin(fl32(phi + pi/2))
+        v[0] = cp * sd; v[1] = sp * sd; v[2] = cd;
+        v[3] = -sp * s1; v[4] = cp * s1; v[5] = c1;
+        v[6] = -sp * s2; v[7] = cp * s2; v[8] = c2;
+    }
 }
 
 struct Px {
@@ -360,17 +415,19 @@ constexpr int kThreads = 512;    // XOLP-only kernels: 64 VGPRs, 4 workgroups pe
 constexpr int kThreadsN = 768;   // kernels with the fp64 normals: one 12-wave workgroup per CU (3 waves/SIMD, <= 168 VGPRs);
                                  // its 90 KB LDS image of the tables is staged once per CU
 
-template <int MODE, bool NORMALS>
-__global__ __launch_bounds__(NORMALS ? kThreadsN : kThreads) void polar_kernel(
+constexpr int kThreadsF = 1024;  // fast (fp32) normals: 112 VGPRs -> one 16-wave workgroup per CU (4 waves/SIMD)
+
+template <int MODE, bool NORMALS, bool PRECISE>
+__global__ __launch_bounds__(NORMALS ? (PRECISE ? kThreadsN : kThreadsF) : kThreads) void polar_kernel(
     const uint8_t* __restrict__ pol, const uint8_t* __restrict__ mask, float* __restrict__ xolp,
     float* __restrict__ xolp_std, float* __restrict__ normals, int* __restrict__ ints,
     const char* __restrict__ blob, long P, long Pout, int wq_in, int wq_out, long quads_per_img, long total_quads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
     const float* lut = reinterpret_cast<const float*>(blob + h->off_lut);
-    constexpr int NTH = NORMALS ? kThreadsN : kThreads;
+    constexpr int NTH = NORMALS ? (PRECISE ? kThreadsN : kThreadsF) : kThreads;
     Tabs tabs;
-    if (NORMALS) stage_tables(blob, smem, NTH, tabs);
+    if (NORMALS) stage_tables<PRECISE>(blob, smem, NTH, tabs);
     const float kMean = static_cast<float>(0.08693199701957657);
     const float kStd = static_cast<float>(0.44430732785457433);
 
@@ -419,7 +476,7 @@ __global__ __launch_bounds__(NORMALS ? kThreadsN : kThreads) void polar_kernel(
             if (NORMALS) {
                 int bi[3];
                 float v[9];
-                normals9(p.rho, p.phi, tabs, v, bi);
+                normals9<PRECISE>(p.rho, p.phi, tabs, v, bi);
                 o_i[2][j] = bi[0]; o_i[3][j] = bi[1]; o_i[4][j] = bi[2];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) o_n[c][j] = (MODE == PD_POLAR_STOKES && !on) ? 0.f : v[c];
@@ -454,14 +511,16 @@ __global__ __launch_bounds__(NORMALS ? kThreadsN : kThreads) void polar_kernel(
 }
 
 // get_normals() on an existing fp32 XOLP tensor (pre_encoders.py:99-113): [B,2,H,W] -> [B,9,H,W]
-__global__ __launch_bounds__(kThreadsN) void normals_from_xolp_kernel(const float* __restrict__ xolp,
+template <bool PRECISE>
+__global__ __launch_bounds__(PRECISE ? kThreadsN : kThreadsF) void normals_from_xolp_kernel(const float* __restrict__ xolp,
                                                                      float* __restrict__ normals,
                                                                      const char* __restrict__ blob, long P,
                                                                      long quads_per_img, long total_quads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Tabs tabs;
-    stage_tables(blob, smem, kThreadsN, tabs);
-    for (long q = blockIdx.x * (long)kThreadsN + threadIdx.x; q < total_quads; q += (long)gridDim.x * kThreadsN) {
+    constexpr int NTH = PRECISE ? kThreadsN : kThreadsF;
+    stage_tables<PRECISE>(blob, smem, NTH, tabs);
+    for (long q = blockIdx.x * (long)NTH + threadIdx.x; q < total_quads; q += (long)gridDim.x * NTH) {
         const long b = q / quads_per_img;
         const long p4 = (q - b * quads_per_img) * 4;
         const float4 r4 = *reinterpret_cast<const float4*>(xolp + (b * 2) * P + p4);
@@ -472,7 +531,7 @@ __global__ __launch_bounds__(kThreadsN) void normals_from_xolp_kernel(const floa
         for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_sched_barrier(0);
             float v[9]; int bi[3];
-            normals9(rr[j], ff[j], tabs, v, bi);
+            normals9<PRECISE>(rr[j], ff[j], tabs, v, bi);
 #pragma unroll
             for (int c = 0; c < 9; ++c) o_n[c][j] = v[c];
         }
@@ -483,8 +542,12 @@ __global__ __launch_bounds__(kThreadsN) void normals_from_xolp_kernel(const floa
     }
 }
 
+// LDS image size implied by the blob size: blob = header + LUT + image(nk) + nk * 32 (monotone in nk)
 inline size_t lds_from_blob_bytes(size_t tables_bytes) {
-    return tables_bytes - (sizeof(PolarHeader) + ((size_t(kLutCount) * 4 + 15) / 16 * 16));
+    const size_t fixed = sizeof(PolarHeader) + round_up(size_t(kLutCount) * 4, 16);
+    for (int nk = 6; nk < 3 * 4096; ++nk)
+        if (fixed + lds_image_bytes(nk) + size_t(nk) * 32 == tables_bytes) return lds_image_bytes(nk);
+    return 0;
 }
 
 template <typename K>
@@ -498,7 +561,7 @@ int set_lds_limit(K kernel, size_t lds) {
 }  // namespace
 
 extern "C" int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tables, size_t tables_bytes,
-                                          int B, int H, int W, void* stream) {
+                                          int B, int H, int W, int flags, void* stream) {
     PD_REQUIRE(B >= 0 && H > 0 && W > 0, "pd_polar_normals_from_xolp: bad shape");
     const long P = (long)H * W;
     PD_REQUIRE(P % 4 == 0, "pd_polar_normals_from_xolp: H*W=%ld must be a multiple of 4", P);
@@ -507,22 +570,28 @@ extern "C" int pd_polar_normals_from_xolp(const void* xolp, void* normals, const
     PD_REQUIRE(pd::aligned16(xolp) && pd::aligned16(normals) && pd::aligned16(tables), "pd_polar_normals_from_xolp: unaligned");
     PD_REQUIRE(tables_bytes >= sizeof(PolarHeader) + size_t(kLutCount) * 4, "pd_polar_normals_from_xolp: tables blob too small");
     const size_t lds = lds_from_blob_bytes(tables_bytes);
-    PD_REQUIRE(lds <= 160 * 1024, "pd_polar_normals_from_xolp: theta tables need %zu bytes of LDS", lds);
+    PD_REQUIRE(lds > 0 && lds <= 160 * 1024, "pd_polar_normals_from_xolp: tables blob has an unexpected size");
+    const bool precise = (flags & PD_POLAR_FAST_NORMALS) == 0;
     {
-        int rc = set_lds_limit(normals_from_xolp_kernel, lds);
+        int rc = precise ? set_lds_limit(normals_from_xolp_kernel<true>, lds) : set_lds_limit(normals_from_xolp_kernel<false>, lds);
         if (rc) return rc;
     }
     const long qpi = P / 4, total = qpi * B;
-    long blocks = (total + kThreadsN - 1) / kThreadsN;
+    const int nth = precise ? kThreadsN : kThreadsF;
+    long blocks = (total + nth - 1) / nth;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(normals_from_xolp_kernel, dim3((unsigned)blocks), dim3(kThreadsN), lds, (hipStream_t)stream,
-                       (const float*)xolp, (float*)normals, (const char*)tables, P, qpi, total);
+    if (precise)
+        hipLaunchKernelGGL(normals_from_xolp_kernel<true>, dim3((unsigned)blocks), dim3(kThreadsN), lds, (hipStream_t)stream,
+                           (const float*)xolp, (float*)normals, (const char*)tables, P, qpi, total);
+    else
+        hipLaunchKernelGGL(normals_from_xolp_kernel<false>, dim3((unsigned)blocks), dim3(kThreadsF), lds, (hipStream_t)stream,
+                           (const float*)xolp, (float*)normals, (const char*)tables, P, qpi, total);
     return pd::check_launch("pd_polar_normals_from_xolp");
 }
 
 extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, void* normals,
                             void* ints, const void* tables, size_t tables_bytes, int B, int H, int W, int Wout,
-                            int mode, void* stream) {
+                            int mode, int flags, void* stream) {
     PD_REQUIRE(B >= 0 && H > 0 && W > 0, "pd_polar_fwd: bad shape B=%d H=%d W=%d", B, H, W);
     if (B == 0) return PD_OK;  // empty batch: nothing to do (pointers may be null)
     PD_REQUIRE(pol && tables, "pd_polar_fwd: pol and tables must not be null");
@@ -541,12 +610,15 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
     const int wq_in = Wout == W ? (int)(P / 4) : W / 4, wq_out = Wout == W ? (int)(P / 4) : Wout / 4;
     const long qpi = Pout / 4, total = qpi * B;
     const bool need_normals = normals != nullptr || ints != nullptr;
+    const bool precise = (flags & PD_POLAR_FAST_NORMALS) == 0;
     // LDS image size is fixed by the table node counts (72,016 bytes for the default 1000/625/375 nodes)
     const size_t lds = need_normals ? lds_from_blob_bytes(tables_bytes) : 0;
-    PD_REQUIRE(lds <= 160 * 1024, "pd_polar_fwd: theta tables need %zu bytes of LDS (max 163840)", lds);
-    const int nth = need_normals ? kThreadsN : kThreads;
+    PD_REQUIRE(!need_normals || (lds > 0 && lds <= 160 * 1024), "pd_polar_fwd: tables blob has an unexpected size");
+    const int nth = need_normals ? (precise ? kThreadsN : kThreadsF) : kThreads;
     long blocks = (total + nth - 1) / nth;
-    const long cap = need_normals ? 256L : 256L * 4;      // persistent: 1 (normals) / 4 (xolp only) workgroups per CU
+    // with normals: persistent, one workgroup per CU (the 90 KB table image is staged once per CU);
+    // XOLP only: no tables to amortise -> one quad per thread, hardware-scheduled (measured 1.4x faster)
+    const long cap = need_normals ? 256L : (1L << 30);
     if (blocks > cap) blocks = cap;
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto go = [&](auto kern) -> int {
@@ -559,8 +631,13 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
         return PD_OK;
     };
     int rc;
-    if (mode == PD_POLAR_LS) rc = need_normals ? go(polar_kernel<PD_POLAR_LS, true>) : go(polar_kernel<PD_POLAR_LS, false>);
-    else rc = need_normals ? go(polar_kernel<PD_POLAR_STOKES, true>) : go(polar_kernel<PD_POLAR_STOKES, false>);
+    if (mode == PD_POLAR_LS) {
+        if (!need_normals) rc = go(polar_kernel<PD_POLAR_LS, false, false>);
+        else rc = precise ? go(polar_kernel<PD_POLAR_LS, true, true>) : go(polar_kernel<PD_POLAR_LS, true, false>);
+    } else {
+        if (!need_normals) rc = go(polar_kernel<PD_POLAR_STOKES, false, false>);
+        else rc = precise ? go(polar_kernel<PD_POLAR_STOKES, true, true>) : go(polar_kernel<PD_POLAR_STOKES, true, false>);
+    }
     if (rc) return rc;
     return pd::check_launch("pd_polar_fwd");
 }

@@ -28,8 +28,8 @@ SIGNATURES = {
     "pd_polar_tables_bytes": (_sz, [_i, _i, _i]),
     "pd_polar_tables_pack": (_i, [_dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _i, _vp, _sz]),
     "pd_polar_tables_build": (_i, [_dbl, _vp, _sz, _c.POINTER(_sz)]),
-    "pd_polar_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
-    "pd_polar_normals_from_xolp": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "pd_polar_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
+    "pd_polar_normals_from_xolp": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     "pd_conv2d_tile_m": (_i, [_l, _i]),
     "pd_conv2d_stats_rows": (_l, [_l, _i]),
     "pd_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i,

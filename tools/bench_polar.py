@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "supervised-depth-estimation-from-polarize
 from polardepth import polar as pdpolar  # noqa: E402
 
 
-def time_variant(B, want, iters=20, H=512, W=612, realistic=True):
+def time_variant(B, want, iters=20, H=512, W=612, realistic=True, precise=False):
     g = torch.Generator(device="cuda").manual_seed(0)
     if realistic:
         yy, xx = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
@@ -22,26 +22,26 @@ def time_variant(B, want, iters=20, H=512, W=612, realistic=True):
         pol = (pol + 1.5 * torch.randn(pol.shape, device="cuda", generator=g)).round().clamp(0, 255).to(torch.uint8)
     else:
         pol = torch.randint(0, 256, (B, 4, H, W), dtype=torch.uint8, device="cuda", generator=g)
-    outs = pdpolar.polar_forward(pol, want=want)          # outputs are allocated once and reused
+    outs = pdpolar.polar_forward(pol, want=want, precise=precise)   # outputs are allocated once and reused
     for _ in range(3):
-        pdpolar.polar_forward(pol, want=want, out=outs)
+        pdpolar.polar_forward(pol, want=want, out=outs, precise=precise)
     torch.cuda.synchronize()
     # one event pair per launch (kernel-only time: host launch gaps are excluded)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for e0, e1 in evs:
         e0.record()
-        pdpolar.polar_forward(pol, want=want, out=outs)
+        pdpolar.polar_forward(pol, want=want, out=outs, precise=precise)
         e1.record()
     torch.cuda.synchronize()
     ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[iters // 2]
     bpp = 4 + (8 if "xolp" in want else 0) + (8 if "xolp_std" in want else 0) + (36 if "normals" in want else 0)
     gbs = B * H * W * bpp / (ms * 1e-3) / 1e9
-    return {"B": B, "want": list(want), "realistic": realistic, "ms": round(ms, 4), "bytes_px": bpp,
+    return {"B": B, "want": list(want), "realistic": realistic, "precise": precise, "ms": round(ms, 4), "bytes_px": bpp,
             "GBps": round(gbs, 1), "frac_8TBps": round(gbs / 8000, 3)}
 
 
 if __name__ == "__main__":
     for realistic in (True, False):
-        for want in (("xolp",), ("xolp", "normals"), ("xolp_std", "normals")):
+        for want, precise in ((("xolp",), False), (("xolp", "normals"), False), (("xolp", "normals"), True)):
             for B in (8, 16, 64, 128):
-                print(json.dumps(time_variant(B, want, realistic=realistic)), flush=True)
+                print(json.dumps(time_variant(B, want, realistic=realistic, precise=precise)), flush=True)
