@@ -114,9 +114,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path is HIP-only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("PD_DIST_TEST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")         # RCCL
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world)         # "nccl" is RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from polardepth import synthetic, ops
@@ -187,7 +188,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

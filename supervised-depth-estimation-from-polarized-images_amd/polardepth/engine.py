@@ -10,6 +10,8 @@
   with the rest of backward; the 1/world_size scaling is folded into the Adam kernel.
   The reference has no distributed code: this component is new.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -137,6 +139,8 @@ class GradReducer:
         self.store = store
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # PD_DIST_TEST=1 exercises the full bucket / side-stream / RCCL path even with a single rank
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("PD_DIST_TEST") == "1")
         self.buckets = []            # (start, end)
         self.bucket_of = {}
         cap = max(bucket_bytes // 4, 1)
@@ -154,7 +158,7 @@ class GradReducer:
         for name, p in store.entries[:store.n_used_params]:
             self.counts[self.bucket_of[id(p)]] += 1
         self.cuda = store.grad.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=store.grad.device) if self.cuda and self.world > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=store.grad.device) if self.cuda and self.active else None
         self.reset()
 
     def reset(self):
@@ -164,7 +168,7 @@ class GradReducer:
         self.works = []
 
     def mark_ready(self, p):
-        if self.world == 1 or id(p) in self.seen:
+        if not self.active or id(p) in self.seen:
             return
         self.seen.add(id(p))
         b = self.bucket_of[id(p)]
@@ -186,7 +190,7 @@ class GradReducer:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         for b in range(len(self.buckets)):       # buckets holding a parameter that got no gradient this step
             self._launch(b)
