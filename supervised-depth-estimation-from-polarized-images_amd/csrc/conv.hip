@@ -585,11 +585,28 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     if (do_bias && tid < TCO && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = bsum;
 }
 
+// out[i] (+)= sum_s part[s][i]: 64 columns x 4 slice lanes per workgroup; every lane keeps four independent
+// loads in flight; the lane partials are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int S, long n, int accumulate) {
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int j = 0; j < S; ++j) s += part[(long)j * n + i];
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = blockIdx.x * 64L + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int j = sl;
+        for (; j + 12 < S; j += 16) {
+            a0 += part[(long)j * n + i];
+            a1 += part[(long)(j + 4) * n + i];
+            a2 += part[(long)(j + 8) * n + i];
+            a3 += part[(long)(j + 12) * n + i];
+        }
+        for (; j < S; j += 4) a0 += part[(long)j * n + i];
+    }
+    red[sl][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        const float s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
         out[i] = accumulate ? out[i] + s : s;
     }
 }
@@ -673,10 +690,10 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     int rc = pd::check_launch("pd_conv2d_wgrad");
     if (rc) return rc;
     const long nw = (long)Co * a.K;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((nw + 255) / 256 > 2048 ? 2048 : (nw + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, st,
                        a.part, (float*)dw, a.S, nw, accumulate);
     if (dbias)
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((Co + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((Co + 63) / 64)), dim3(256), 0, st,
                            a.bpart, (float*)dbias, a.S, (long)Co, accumulate);
     return pd::check_launch("pd_conv2d_wgrad/reduce");
 }

@@ -84,12 +84,16 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = 1.0
 
     def zero_grad(self, set_to_none=False):
+        from . import functional as PF
+        PF.sync_wgrad_stream()
         self.store.zero_grad()
         if self.reducer is not None:
             self.reducer.reset()
 
     @torch.no_grad()
     def step(self, closure=None):
+        from . import functional as PF
+        PF.sync_wgrad_stream()                   # weight gradients are produced on a side stream
         if self.reducer is not None:
             self.reducer.finish()
         g = self.param_groups[0]
@@ -183,7 +187,9 @@ class GradReducer:
         s, e = self.buckets[b]
         view = self.store.grad[s:e]
         if self.comm_stream is not None:
+            from . import functional as PF
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            PF.sync_wgrad_stream(self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

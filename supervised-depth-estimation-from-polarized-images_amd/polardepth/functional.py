@@ -6,6 +6,7 @@ flat gradient buffer when a ParamStore owns the parameters) and the Functions re
 for them, so there is no per-parameter AccumulateGrad pass; ``zero_grad`` is one memset.
 """
 import ctypes
+import os
 
 import torch
 
@@ -30,6 +31,57 @@ class DropoutState:
     def next(cls):
         cls.offset += 1
         return cls.seed, cls.offset
+
+
+# ------------------------------------------------------------------ side stream for weight gradients
+# The weight gradient and the data gradient of a layer both read dz and are independent of each other:
+# wgrad kernels run on a side stream next to the dgrad / elementwise kernels of the main stream, which
+# fills the tails of the MFMA kernels.  Consumers of the parameter gradients (Adam, the RCCL reducer)
+# wait for the side stream through ``sync_wgrad_stream``.
+_WGRAD_STREAMS = {}
+USE_WGRAD_STREAM = os.environ.get("PD_WGRAD_STREAM", "1") == "1"
+
+
+def wgrad_stream(device):
+    st = _WGRAD_STREAMS.get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _WGRAD_STREAMS[device.index] = st
+    return st
+
+
+def sync_wgrad_stream(stream=None):
+    """Make `stream` (default: the current one) wait for all weight-gradient kernels issued so far."""
+    for st in _WGRAD_STREAMS.values():
+        (stream or torch.cuda.current_stream()).wait_stream(st)
+
+
+_join_queued = False
+
+
+def _join_after_backward():
+    """Autograd callback: when the backward pass ends, the main stream waits for the side stream, so that
+    anything enqueued afterwards (reads of .grad, the optimizer) sees complete weight gradients."""
+    global _join_queued
+    _join_queued = False
+    sync_wgrad_stream()
+
+
+def _wgrad_async(x, dz, fn):
+    """Run fn() (which launches wgrad kernels reading x and dz) on the side stream."""
+    global _join_queued
+    if not USE_WGRAD_STREAM:
+        fn()
+        return
+    if not _join_queued:
+        torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
+        _join_queued = True
+    side = wgrad_stream(dz.device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    x.record_stream(side)
+    dz.record_stream(side)
 
 
 # ------------------------------------------------------------------ helpers
@@ -155,8 +207,9 @@ class ConvBNChainFn(torch.autograd.Function):
             dres = dy                     # out = f(x) + res: the residual gradient is dy itself
         if weight.requires_grad:
             # the bias feeds a BatchNorm: its gradient is identically zero (mean subtraction)
-            ops.conv2d_wgrad(x, dz, weight.shape, cfg.stride, cfg.pad, affine=cfg.affine, dw=grad_buf(weight),
-                             accumulate=True)
+            gw = grad_buf(weight)
+            _wgrad_async(x, dz, lambda: ops.conv2d_wgrad(x, dz, weight.shape, cfg.stride, cfg.pad, affine=cfg.affine,
+                                                         dw=gw, accumulate=True))
             if bias is not None and bias.requires_grad:
                 grad_buf(bias)
         dx = None
@@ -201,8 +254,9 @@ class ReflectConvActFn(torch.autograd.Function):
             dz = dy
         if weight.requires_grad:
             db = grad_buf(bias) if bias is not None and bias.requires_grad else None
-            ops.conv2d_wgrad(x, dz, weight.shape, 1, 1, mode=ops.MODE_REFLECT, dw=grad_buf(weight), dbias=db,
-                             accumulate=True)
+            gw = grad_buf(weight)
+            _wgrad_async(x, dz, lambda: ops.conv2d_wgrad(x, dz, weight.shape, 1, 1, mode=ops.MODE_REFLECT, dw=gw,
+                                                         dbias=db, accumulate=True))
         dx = None
         if ctx.needs_input_grad[0]:
             Ci = x.shape[1]
