@@ -14,8 +14,9 @@ Weak scaling: every rank processes its own batch of 16; gradients are all-reduce
 
 The JSON line also carries
   roofline     -- the dominant kernel (fp32-MFMA implicit-GEMM conv), algorithmic FLOPs / HIP-event time
-                  of its launches in instrumented steps of the same workload, vs the 157.3 TFLOP/s fp32
-                  matrix peak (MI355X_MICROARCH.md);
+                  of its launches in instrumented steps of the same workload (run serially on one stream:
+                  in the timed steps weight-gradient kernels overlap data-gradient kernels, which would
+                  stretch per-kernel durations), vs the 157.3 TFLOP/s fp32 matrix peak (MI355X_MICROARCH.md);
   cpu_baseline -- the CPU oracle (oracle/: plain PyTorch-CPU restatement of the reference) timed on
                   this box's host cores on a bounded sample (rank 0, N == 1 only).
 """
@@ -152,11 +153,15 @@ def main():
 
     # ---- roofline of the dominant kernel: instrumented steps of the same workload (HIP events on the
     # launch stream around every implicit-GEMM conv launch), outside the timed region
+    # (weight-gradient kernels normally overlap the data-gradient kernels on a side stream; for per-kernel
+    # durations the instrumented steps run them serially on one stream)
+    overlap, PF.USE_WGRAD_STREAM = PF.USE_WGRAD_STREAM, False
     ops.PROFILE = []
     for _ in range(2):
         train_step(tr, batch)
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
+    PF.USE_WGRAD_STREAM = overlap
     by_kernel = {}
     for name, flops, e0, e1 in prof:
         k = by_kernel.setdefault(name, [0.0, 0.0, 0])
