@@ -211,6 +211,18 @@ int pd_loss_finalize(const void* sup_part, const int* sup_rows, const void* sm_p
 int pd_loss_weights(const void* gvals, const int* scale_ids, int S, float w_normals, float w_smooth, void* wts,
                     void* stream);
 
+/* SSIM map (mode 0, layers.py:468-499) or the photometric reprojection loss of trainer.py:1069-1081 (mode 1:
+ * out [N,1,H,W] = 0.85 * mean_c SSIM + 0.15 * mean_c |y - x|, or the L1 part alone when no_ssim).  x, y planar
+ * NCHW fp32.  Inactive under --depth_supervision_only; forward only. */
+int pd_ssim_fwd(const void* x, const void* y, void* out, int N, int C, int H, int W, int mode, int no_ssim,
+                void* stream);
+/* compute_depth_errors (layers.py:539-557) per image on the device: metrics [N][8] = abs_rel, sq_rel, rmse,
+ * rmse_log, a1, a2, a3, pixel count over min < gt < max (and mask == mask_value when mask != NULL, the
+ * per-material selection of trainer.py:1385-1411); pred is clamped to [min, max] (trainer.py:1422-1423).
+ * partial_ws: N * 64 * 8 floats. */
+int pd_depth_metrics(const void* gt, const void* pred, const void* mask, int mask_value, void* partial_ws,
+                     void* metrics, int N, long P, float min_depth, float max_depth, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -537,3 +537,117 @@ extern "C" int pd_loss_weights(const void* gvals, const int* scale_ids, int S, f
                        w_normals, w_smooth, (float*)wts);
     return pd::check_launch("pd_loss_weights");
 }
+
+// ============================================================================ SSIM + depth metrics
+// SSIM (layers.py:468-499: ReflectionPad2d(1), 3x3 average pools, C1 = 1e-4, C2 = 9e-4, clamp((1-n/d)/2, 0, 1))
+// and the photometric mix of trainer.py:1069-1081 (0.85 * mean_c SSIM + 0.15 * mean_c |target - pred|).
+// Constructed by the reference trainer but inactive under --depth_supervision_only; exposed because
+// north_star names it.  Planar NCHW fp32, one thread per pixel, all channels.
+namespace {
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// mode 0: out[N,C,H,W] = SSIM map;  mode 1: out[N,1,H,W] = reprojection loss (no_ssim -> plain L1 mean)
+__global__ __launch_bounds__(LT) void ssim_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                  float* __restrict__ out, int N, int C, int H, int W, int mode,
+                                                  int no_ssim) {
+    const long P = (long)H * W, total = N * P;
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const int px = (int)(i % W);
+        const long t = i / W;
+        const int py = (int)(t % H);
+        const long n = t / H;
+        float s_ssim = 0.f, s_l1 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* xp = x + (n * C + c) * P;
+            const float* yp = y + (n * C + c) * P;
+            float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = reflect1(py + dy, H);
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = reflect1(px + dx, W);
+                    const float a = xp[(long)yy * W + xx], b = yp[(long)yy * W + xx];
+                    sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+                }
+            }
+            const float k = 1.f / 9.f;
+            const float mu_x = sx * k, mu_y = sy * k;
+            const float sig_x = sxx * k - mu_x * mu_x, sig_y = syy * k - mu_y * mu_y, sig_xy = sxy * k - mu_x * mu_y;
+            const float nn = (2.f * mu_x * mu_y + 1e-4f) * (2.f * sig_xy + 9e-4f);
+            const float dd = (mu_x * mu_x + mu_y * mu_y + 1e-4f) * (sig_x + sig_y + 9e-4f);
+            const float v = fminf(fmaxf((1.f - nn / dd) * 0.5f, 0.f), 1.f);
+            if (mode == 0) out[(n * C + c) * P + (long)py * W + px] = v;
+            s_ssim += v;
+            s_l1 += fabsf(yp[(long)py * W + px] - xp[(long)py * W + px]);
+        }
+        if (mode == 1) {
+            const float l1 = s_l1 / C;
+            out[i] = no_ssim ? l1 : 0.85f * (s_ssim / C) + 0.15f * l1;
+        }
+    }
+}
+
+// compute_depth_errors (layers.py:539-557) over the pixels selected by lo < gt < hi [and mask == mask_value],
+// per image: partial[block][9] = (count, sum|d|/gt, sum d^2/gt, sum d^2, sum dlog^2, a1, a2, a3, 0); the
+// prediction is clamped to [lo, hi] first like trainer.py:1422-1423.  One image per blockIdx.y.
+__global__ __launch_bounds__(LT) void depth_metrics_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
+                                                           const int* __restrict__ mask, int mask_value,
+                                                           float* __restrict__ partial, long P, float lo, float hi) {
+    __shared__ float sm[4 * 8];
+    const long n = blockIdx.y;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < P; i += (long)gridDim.x * LT) {
+        const float g = gt[n * P + i];
+        if (!(g > lo && g < hi)) continue;
+        if (mask && mask[n * P + i] != mask_value) continue;
+        const float p = fminf(fmaxf(pred[n * P + i], lo), hi);
+        const float d = g - p, r = fmaxf(g / p, p / g), dl = logf(g) - logf(p);
+        acc[0] += 1.f; acc[1] += fabsf(d) / g; acc[2] += d * d / g; acc[3] += d * d; acc[4] += dl * dl;
+        acc[5] += r < 1.25f ? 1.f : 0.f; acc[6] += r < 1.5625f ? 1.f : 0.f; acc[7] += r < 1.953125f ? 1.f : 0.f;
+    }
+    block_sum<8>(acc, sm);
+    if (threadIdx.x == 0) {
+        float* o = partial + (n * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = acc[k];
+    }
+}
+
+// metrics[n][8] = (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, count) from the per-block partials
+__global__ void depth_metrics_finalize_kernel(const float* __restrict__ partial, float* __restrict__ metrics,
+                                              int blocks) {
+    const int n = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < blocks; ++b)
+        for (int k = 0; k < 8; ++k) a[k] += partial[((long)n * blocks + b) * 8 + k];
+    float* o = metrics + n * 8;
+    const double c = a[0];
+    o[0] = (float)(a[1] / c); o[1] = (float)(a[2] / c); o[2] = (float)sqrt(a[3] / c); o[3] = (float)sqrt(a[4] / c);
+    o[4] = (float)(a[5] / c); o[5] = (float)(a[6] / c); o[6] = (float)(a[7] / c); o[7] = (float)c;
+}
+
+}  // namespace
+
+extern "C" int pd_ssim_fwd(const void* x, const void* y, void* out, int N, int C, int H, int W, int mode, int no_ssim,
+                           void* stream) {
+    PD_REQUIRE(x && y && out && N >= 0 && C > 0 && H >= 2 && W >= 2 && (mode == 0 || mode == 1), "pd_ssim_fwd: bad arguments");
+    if (N == 0) return PD_OK;
+    hipLaunchKernelGGL(ssim_kernel, dim3(lgrid((long)N * H * W)), dim3(LT), 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)y, (float*)out, N, C, H, W, mode, no_ssim);
+    return pd::check_launch("pd_ssim_fwd");
+}
+
+extern "C" int pd_depth_metrics(const void* gt, const void* pred, const void* mask, int mask_value, void* partial_ws,
+                                void* metrics, int N, long P, float min_depth, float max_depth, void* stream) {
+    PD_REQUIRE(gt && pred && partial_ws && metrics && N > 0 && P > 0, "pd_depth_metrics: bad arguments");
+    const int blocks = 64;   // partial_ws: N * 64 * 8 floats
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(depth_metrics_kernel, dim3(blocks, N), dim3(LT), 0, st, (const float*)gt, (const float*)pred,
+                       (const int*)mask, mask_value, (float*)partial_ws, P, min_depth, max_depth);
+    hipLaunchKernelGGL(depth_metrics_finalize_kernel, dim3(N), dim3(64), 0, st, (const float*)partial_ws, (float*)metrics,
+                       blocks);
+    return pd::check_launch("pd_depth_metrics");
+}

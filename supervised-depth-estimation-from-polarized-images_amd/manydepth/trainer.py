@@ -31,6 +31,7 @@ from .layers import SSIM, compute_depth_errors, compute_depth_errors_numpy
 from manydepth import datasets, networks
 from polardepth import functional as PF
 from polardepth import polar as pdpolar
+from polardepth import ops
 from polardepth.engine import ParamStore, FusedAdam, GradReducer
 from polardepth._lib import lib, check, ptr, stream_ptr
 
@@ -307,10 +308,15 @@ class Trainer:
         self.set_train()
 
     def test(self):
+        """trainer.py:782-980: full test split, "all" + per-material metrics.  The per-image masked metrics
+        (compute_depth_losses_from_list, trainer.py:1357-1434) are reduced on the device by pd_depth_metrics;
+        only 11 x 7 numbers per batch leave the GPU."""
         if self.rank == 0:
             print("Running full test set at Epoch: ", self.epoch)
         self.set_eval()
-        gts, preds_mono, masks = [], [], []
+        objects = ["all"] + list(_MATERIAL_GREY)
+        sums = {o: torch.zeros(7, dtype=torch.float64, device=self.device) for o in objects}
+        counts = {o: torch.zeros((), dtype=torch.float64, device=self.device) for o in objects}
         with torch.no_grad():
             for inputs in self.test_loader:
                 for key, ipt in inputs.items():
@@ -321,14 +327,22 @@ class Trainer:
                 d0 = outputs[("disp", 0)].contiguous()
                 check(lib.pd_disp_to_depth(ptr(d0), ptr(depth), None, N, d0.shape[2], d0.shape[3], H, W,
                                            self.opt.min_depth, self.opt.max_depth, stream_ptr()), "pd_disp_to_depth")
-                gts.append(inputs["depth_gt"].cpu())
-                masks.append(inputs[("mask", 0, 0)].cpu())
-                preds_mono.append(depth.clamp(self.opt.min_depth, self.opt.max_depth).cpu())
-        if preds_mono and self.rank == 0:
-            for obj in ["all"] + list(_MATERIAL_GREY):
-                losses = {}
-                self.compute_depth_losses_from_list(gts, preds_mono, losses, masks, obj)
-                self.log("test_mono" if obj == "all" else "test_mono_" + obj, None, None, losses, log_images=False)
+                for o in objects:
+                    m = ops.depth_metrics(inputs["depth_gt"], depth, self.opt.min_depth, self.opt.max_depth,
+                                          mask=None if o == "all" else inputs[("mask", 0, 0)],
+                                          mask_value=_MATERIAL_GREY.get(o, 0))
+                    valid = m[:, 7] > 0
+                    sums[o] += (m[:, :7].double() * valid[:, None]).sum(0)
+                    counts[o] += valid.sum()
+        if self.rank == 0:
+            for o in objects:
+                if counts[o].item() == 0:
+                    continue
+                mean_errors = (sums[o] / counts[o]).cpu().numpy()
+                print("\n  " + o + "\n  " + ("{:>8} | " * 7).format("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3"))
+                print(("&{: 8.5f}  " * 7).format(*mean_errors.tolist()) + "\\\\")
+                losses = {metric: np.array(mean_errors[i]) for i, metric in enumerate(self.depth_metric_names)}
+                self.log("test_mono" if o == "all" else "test_mono_" + o, None, None, losses, log_images=False)
         self.set_train()
 
     def compute_depth_losses(self, inputs, outputs, losses, mono=False):

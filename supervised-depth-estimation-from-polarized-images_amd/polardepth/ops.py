@@ -160,3 +160,38 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
                                                 int(affine is not None), sub, div, dy.stride(3), int(accumulate),
                                                 stream_ptr()), "pd_conv2d_wgrad"))
     return (dw, dbias) if (want_bias or dbias is not None) else dw
+
+
+def ssim(x, y):
+    """layers.SSIM forward on the GPU: planar NCHW fp32 -> SSIM loss map of the same shape."""
+    _require_cuda(x, y)
+    x, y = x.float().contiguous(), y.float().contiguous()
+    N, C, H, W = x.shape
+    out = torch.empty_like(x)
+    check(lib.pd_ssim_fwd(ptr(x), ptr(y), ptr(out), N, C, H, W, 0, 0, stream_ptr()), "pd_ssim_fwd")
+    return out
+
+
+def reprojection_loss(pred, target, no_ssim=False):
+    """trainer.py:1069-1081: [N,1,H,W] = 0.85 * mean_c SSIM(pred, target) + 0.15 * mean_c |target - pred|."""
+    _require_cuda(pred, target)
+    pred, target = pred.float().contiguous(), target.float().contiguous()
+    N, C, H, W = pred.shape
+    out = torch.empty((N, 1, H, W), dtype=torch.float32, device=pred.device)
+    check(lib.pd_ssim_fwd(ptr(pred), ptr(target), ptr(out), N, C, H, W, 1, int(no_ssim), stream_ptr()), "pd_ssim_fwd")
+    return out
+
+
+def depth_metrics(gt, pred, min_depth, max_depth, mask=None, mask_value=0):
+    """Per-image depth metrics on the device: [N,8] = abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, count."""
+    _require_cuda(gt, pred, mask)
+    gt, pred = gt.float().contiguous(), pred.float().contiguous()
+    N = gt.shape[0]
+    P = gt.numel() // N
+    if mask is not None:
+        mask = mask.to(torch.int32).contiguous()
+    ws = torch.empty(N * 64 * 8, dtype=torch.float32, device=gt.device)
+    out = torch.empty((N, 8), dtype=torch.float32, device=gt.device)
+    check(lib.pd_depth_metrics(ptr(gt), ptr(pred), ptr(mask), int(mask_value), ptr(ws), ptr(out), N, P,
+                               float(min_depth), float(max_depth), stream_ptr()), "pd_depth_metrics")
+    return out

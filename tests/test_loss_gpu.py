@@ -84,3 +84,37 @@ def test_loss_vs_oracle_other_geometry_and_partial_scales():
         n_out_oracle = ((g32[i] - ref).abs() > 2e-4 * scale).sum().item()
         assert (err > 2e-4 * scale).sum().item() <= 2 * n_out_oracle + 2
         assert err.max().item() <= 3 * noise + 2e-4 * scale, (err.max().item(), noise, scale)
+
+
+def test_ssim_and_reprojection_loss_match_reference_fixture():
+    from polardepth import ops
+    x, y = T(G5["ssim.x"]).cuda(), T(G5["ssim.y"]).cuda()
+    got = ops.ssim(x, y)
+    _close(got, T(G5["ssim.out"]), 2e-5, "ssim")
+    rep = ops.reprojection_loss(x, y)
+    ref = 0.85 * T(G5["ssim.out"]).mean(1, True) + 0.15 * (T(G5["ssim.y"]) - T(G5["ssim.x"])).abs().mean(1, True)
+    _close(rep, ref, 2e-5, "reprojection")
+    _close(ops.reprojection_loss(x, y, no_ssim=True), (T(G5["ssim.y"]) - T(G5["ssim.x"])).abs().mean(1, True), 1e-6, "l1")
+    from manydepth.layers import SSIM
+    _close(SSIM()(x, y), T(G5["ssim.out"]), 2e-5, "layers.SSIM")
+
+
+def test_depth_metrics_match_reference_fixture():
+    from polardepth import ops
+    gt, pr = T(G5["err.gt"]), T(G5["err.pred"])          # 500 values in (0.2, 1.7): all inside (0.1, 2.0)
+    m = ops.depth_metrics(gt.cuda()[None], pr.cuda()[None], 0.1, 2.0)
+    _close(m[0, :7], T(G5["err.out"]), 1e-5, "metrics")
+    assert m[0, 7].item() == 500
+    # per-material selection + clamping + invalid pixels vs the numpy restatement
+    import numpy as np
+    from oracle import losses as ol
+    g = torch.Generator().manual_seed(2)
+    gt2 = 0.05 + 2.2 * torch.rand(3, 1, 32, 40, generator=g)
+    pr2 = 0.05 + 2.2 * torch.rand(3, 1, 32, 40, generator=g)
+    mask = (torch.randint(0, 11, (3, 1, 32, 40), generator=g) * 20).int()
+    got = ops.depth_metrics(gt2.cuda(), pr2.cuda(), 0.1, 2.0, mask=mask.cuda(), mask_value=160).cpu()
+    for n in range(3):
+        sel = (gt2[n] > 0.1) & (gt2[n] < 2.0) & (mask[n] == 160)
+        ref = torch.stack(ol.compute_depth_errors(gt2[n][sel], pr2[n][sel].clamp(0.1, 2.0)))
+        _close(got[n, :7], ref, 1e-5, f"img{n}")
+        assert got[n, 7].item() == sel.sum().item()

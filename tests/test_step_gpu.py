@@ -134,3 +134,12 @@ def test_dropout_is_deterministic_per_seed_and_matches_backward(tmp_path):
     assert 0.55 < frac < 0.75          # relu zeros (~50%) + 30% dropout of the rest
     y1.sum().backward()
     assert torch.isfinite(x.grad).all()
+
+
+def test_trainer_test_loop_runs_on_device_metrics(tmp_path, capsys):
+    """Trainer.test(): forward in eval mode + device-side per-material metrics (smoke: finite numbers printed)."""
+    from manydepth.trainer import Trainer
+    tr = Trainer(_opts(tmp_path))
+    tr.test()
+    out = capsys.readouterr().out
+    assert "abs_rel" in out and "glass" in out and "nan" not in out.lower()
