@@ -170,8 +170,19 @@ def main():
     dname, (dflops, dtime, dcount) = dom
     achieved = dflops / dtime / 1e12
     step_conv_time = sum(v[1] for v in by_kernel.values()) / 2
+    # HBM traffic per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, gfx950
+    # FETCH_SIZE x2 correction) cannot run inside this process -- the committed summary of those passes is quoted
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            dom_pmc = json.load(f).get("dominant", {})
+        if dom_pmc.get("kernel") == dname:
+            traffic, traffic_src = dom_pmc.get("hbm_bytes_per_launch"), "profiles/r01_pmc_hbm_traffic.json"
     roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+                "algorithmic_flops_per_launch": round(dflops / dcount),
                 "launches_per_step": dcount // 2, "avg_launch_ms": round(dtime / dcount * 1e3, 4),
                 "all_conv_kernels_ms_per_step": round(step_conv_time * 1e3, 2),
                 "all_conv_kernels_TFLOPs": round(sum(v[0] for v in by_kernel.values()) / 2 /

@@ -428,7 +428,12 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_K, wn = wave - wm * WAVES_K;
-    int b = blockIdx.x;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so consecutive *logical* tiles -- the
+    // k-tiles of one pixel slice, which read the same dY rows and overlapping X rows -- are mapped to one XCD
+    // and share its L2 (measured HBM traffic of this kernel was 4x its algorithmic bytes without it).
+    const int nwg = a.ktiles * a.ctiles * a.S;
+    int b = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (b >= nwg) return;
     const int kt = b % a.ktiles; b /= a.ktiles;
     const int ct = b % a.ctiles; b /= a.ctiles;
     const int s = b;
@@ -677,7 +682,7 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     PD_REQUIRE(a.mper * ldd * 4 < 0x7fffffffL, "pd_conv2d_wgrad: slice too large for 32-bit offsets");
     PD_REQUIRE((a.mper / ((long)Ho * Wo) + 2) * sN * 4 < 0x7fffffffL, "pd_conv2d_wgrad: image too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((long)a.ktiles * a.ctiles * a.S)), block(NT);
+    const dim3 grid((unsigned)(((long)a.ktiles * a.ctiles * a.S + 7) / 8 * 8)), block(NT);
 #define PD_WG(T, V, MD) hipLaunchKernelGGL((conv_wgrad_kernel<T, V, MD>), grid, block, 0, st, a)
     if (tco == 64) {
         if (vec) { if (mode == MODE_ZERO) PD_WG(64, true, MODE_ZERO); else PD_WG(64, true, MODE_REFLECT); }
