@@ -102,6 +102,7 @@ int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tabl
  * 16-byte gather path, anything else (e.g. the NCHW 2/3/9-channel stem inputs) the scalar one;
  * w is [Cout][KH][KW][Cin] (torch channels_last storage of the [Cout,Cin,KH,KW] parameter);
  * y is NHWC with row stride ldy >= Cout (ldy > Cout writes into a channel slice of a wider buffer).
+ * (Ho, Wo) may be smaller than the full output grid: only the leading Ho x Wo outputs are computed.
  *
  * mode  0 zero padding | 1 reflection padding | 2 transposed (data gradient: x is dY on the
  *       forward output grid [N,H,W,C=Cout_fwd], (Ho,Wo) is the forward INPUT grid, w is the
@@ -128,6 +129,16 @@ int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* 
                     int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                     int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode,
                     int affine, float sub, float div, long ldd, int accumulate, void* stream);
+
+/* 7x7 / stride-2 / pad-3 stems (pre_encoders.py:54 ShallowEncoder.Conv1, torchvision resnet conv1) executed as a
+ * 4x4 / stride-1 / pad-2 convolution over the space-to-depth input [N][H/2][W/2][4C] (4C is a multiple of 4 ->
+ * 16-byte gather path): input transform (with the optional (x-sub)/div normalisation), weight regrouping
+ * [Cout][7][7][C] -> [Cout][4][4][4C] and the inverse mapping of the weight gradient.  pd_conv2d /
+ * pd_conv2d_wgrad are then called with KH=KW=4, stride 1, pad 2 and the (H/2, W/2) output grid. */
+int pd_stem_s2d_input(const void* x, void* out, int N, int C, int H, int W, long sN, long sC, long sH, long sW,
+                      int affine, float sub, float div, void* stream);
+int pd_stem_s2d_weight(const void* w, void* w2, int Cout, int C, void* stream);
+int pd_stem_s2d_weight_grad(const void* dw2, void* dw, int Cout, int C, int accumulate, void* stream);
 
 /* w [Cout][T][Cin] -> wt [Cin][T][Cout], T = KH*KW: operand of the mode-2 (data gradient) GEMM. */
 int pd_weight_transpose(const void* w, void* wt, int Cout, int T, int Cin, void* stream);

@@ -359,7 +359,8 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, void* y
         PD_REQUIRE(H == (Ho + 2 * pad - KH) / stride + 1 && W == (Wo + 2 * pad - KW) / stride + 1,
                    "pd_conv2d: transposed: x grid is not the forward output grid of a %dx%d input", Ho, Wo);
     } else {
-        PD_REQUIRE(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1,
+        // a smaller output grid computes the leading Ho x Wo outputs only (asymmetric bottom/right padding)
+        PD_REQUIRE(Ho <= (H + 2 * pad - KH) / stride + 1 && Wo <= (W + 2 * pad - KW) / stride + 1,
                    "pd_conv2d: output grid does not match input/filter geometry");
     }
     if (N == 0) return PD_OK;
@@ -659,7 +660,7 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
                                int affine, float sub, float div, long ldd, int accumulate, void* stream) {
     PD_REQUIRE(x && dy && dw && workspace, "pd_conv2d_wgrad: null tensor");
     PD_REQUIRE(mode == MODE_ZERO || mode == MODE_REFLECT, "pd_conv2d_wgrad: mode must be 0 or 1");
-    PD_REQUIRE(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1,
+    PD_REQUIRE(Ho <= (H + 2 * pad - KH) / stride + 1 && Wo <= (W + 2 * pad - KW) / stride + 1,
                "pd_conv2d_wgrad: output grid does not match input/filter geometry");
     PD_REQUIRE(ldd >= Co && (ldd % 4 == 0 || Co < 4) , "pd_conv2d_wgrad: bad dy row stride");
     if (N == 0) return PD_OK;
@@ -710,4 +711,80 @@ extern "C" int pd_weight_transpose(const void* w, void* wt, int Co, int T, int C
     hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)w, (float*)wt, Co, T, Ci);
     return pd::check_launch("pd_weight_transpose");
+}
+
+
+// ===================================================================== 7x7 / stride-2 stems as 4x4 / stride-1
+// A 7x7 stride-2 pad-3 convolution over [C,H,W] equals a 4x4 stride-1 pad-2 convolution over the
+// space-to-depth tensor X2[H/2][W/2][4C] (channel q = (dy*2+dx)*C + c holds x[c][2i+dy][2j+dx]) with the
+// filter taps regrouped: kh = 2a + dy - 1, kw = 2b + dx - 1 (taps -1 are zero).  4C is a multiple of 4, so the
+// 2/3/9-channel stems (ShallowEncoder.Conv1, resnet conv1) take the 16-byte gather path of the implicit GEMM
+// instead of the scalar one (K grows from 49C to 64C, the kernels get ~2x faster).
+namespace {
+
+// x: [N,C,H,W] with element strides; out: [N][H/2][W/2][4C]; optional (x - sub) / div
+__global__ __launch_bounds__(256) void s2d_input_kernel(const float* __restrict__ x, float* __restrict__ out, int N,
+                                                        int C, int H, int W, long sN, long sC, long sH, long sW,
+                                                        int affine, float sub, float div) {
+    const int H2 = H >> 1, W2 = W >> 1, C4 = 4 * C;
+    const long total = (long)N * H2 * W2 * C4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        long pix = i / C4;
+        const int j = (int)(pix % W2); pix /= W2;
+        const int ii = (int)(pix % H2);
+        const long n = pix / H2;
+        const int d = q / C, c = q - d * C;
+        float v = x[n * sN + c * sC + (2 * ii + (d >> 1)) * sH + (2 * j + (d & 1)) * sW];
+        if (affine) v = (v - sub) / div;
+        out[i] = v;
+    }
+}
+
+// w: [Co][7][7][C] -> w2: [Co][4][4][4C];  inverse (gradient): dw[co][kh][kw][c] (+)= dw2[co][a][b][(dy,dx,c)]
+__global__ __launch_bounds__(256) void s2d_weight_kernel(const float* __restrict__ w, float* __restrict__ w2, int Co,
+                                                         int C, int inverse, int accumulate, float* __restrict__ dw) {
+    const int C4 = 4 * C;
+    const long total = (long)Co * 16 * C4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        long r = i / C4;
+        const int b = (int)(r & 3); r >>= 2;
+        const int a = (int)(r & 3);
+        const long co = r >> 2;
+        const int d = q / C, c = q - d * C;
+        const int kh = 2 * a + (d >> 1) - 1, kw = 2 * b + (d & 1) - 1;
+        const bool ok = kh >= 0 && kw >= 0;
+        const long src = ((co * 7 + kh) * 7 + kw) * C + c;
+        if (!inverse) w2[i] = ok ? w[src] : 0.f;
+        else if (ok) dw[src] = (accumulate ? dw[src] : 0.f) + w2[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int pd_stem_s2d_input(const void* x, void* out, int N, int C, int H, int W, long sN, long sC, long sH,
+                                 long sW, int affine, float sub, float div, void* stream) {
+    PD_REQUIRE(x && out && N >= 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "pd_stem_s2d_input: bad arguments");
+    if (N == 0) return PD_OK;
+    const long total = (long)N * H * W * C;
+    hipLaunchKernelGGL(s2d_input_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256),
+                       0, (hipStream_t)stream, (const float*)x, (float*)out, N, C, H, W, sN, sC, sH, sW, affine, sub, div);
+    return pd::check_launch("pd_stem_s2d_input");
+}
+
+extern "C" int pd_stem_s2d_weight(const void* w, void* w2, int Co, int C, void* stream) {
+    PD_REQUIRE(w && w2 && Co > 0 && C > 0, "pd_stem_s2d_weight: bad arguments");
+    const long total = (long)Co * 64 * C;
+    hipLaunchKernelGGL(s2d_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)w, (float*)w2, Co, C, 0, 0, (float*)nullptr);
+    return pd::check_launch("pd_stem_s2d_weight");
+}
+
+extern "C" int pd_stem_s2d_weight_grad(const void* dw2, void* dw, int Co, int C, int accumulate, void* stream) {
+    PD_REQUIRE(dw2 && dw && Co > 0 && C > 0, "pd_stem_s2d_weight_grad: bad arguments");
+    const long total = (long)Co * 64 * C;
+    hipLaunchKernelGGL(s2d_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)nullptr, (float*)dw2, Co, C, 1, accumulate, (float*)dw);
+    return pd::check_launch("pd_stem_s2d_weight_grad");
 }

@@ -40,6 +40,7 @@ class DropoutState:
 # wait for the side stream through ``sync_wgrad_stream``.
 _WGRAD_STREAMS = {}
 USE_WGRAD_STREAM = os.environ.get("PD_WGRAD_STREAM", "1") == "1"
+USE_S2D_STEMS = os.environ.get("PD_S2D_STEMS", "1") == "1"
 
 
 def wgrad_stream(device):
@@ -148,10 +149,20 @@ class ConvBNChainFn(torch.autograd.Function):
         if not (x.stride(1) == 1) and x.shape[1] % 4 == 0:
             x = ops.as_nhwc(x)
         training = bn.training
-        if training:
-            z, part = ops.conv2d_fwd(x, weight, bias, cfg.stride, cfg.pad, want_stats=True, affine=cfg.affine)
+        # 7x7 / stride-2 / pad-3 stems run as a 4x4 / stride-1 conv over the space-to-depth input (vector gather)
+        s2d = (USE_S2D_STEMS and weight.shape[2] == 7 and weight.shape[3] == 7 and cfg.stride == 2 and cfg.pad == 3
+               and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+        ctx.s2d = s2d
+        if s2d:
+            x = ops.s2d_input(x, cfg.affine)                      # saved for the weight gradient
+            w_eff, stride, pad, aff = ops.s2d_weight(weight), 1, 2, None
+            out_hw = (x.shape[2], x.shape[3])
         else:
-            z, part = ops.conv2d_fwd(x, weight, bias, cfg.stride, cfg.pad, affine=cfg.affine), None
+            w_eff, stride, pad, aff, out_hw = weight, cfg.stride, cfg.pad, cfg.affine, None
+        if training:
+            z, part = ops.conv2d_fwd(x, w_eff, bias, stride, pad, want_stats=True, affine=aff, out_hw=out_hw)
+        else:
+            z, part = ops.conv2d_fwd(x, w_eff, bias, stride, pad, affine=aff, out_hw=out_hw), None
         _, _, Hz, Wz = z.shape
         scale, shift, mean, invstd = _f32(dev, Co), _f32(dev, Co), _f32(dev, Co), _f32(dev, Co)
         acc = torch.empty(2 * Co, dtype=torch.float64, device=dev) if training else None
@@ -208,12 +219,20 @@ class ConvBNChainFn(torch.autograd.Function):
         if weight.requires_grad:
             # the bias feeds a BatchNorm: its gradient is identically zero (mean subtraction)
             gw = grad_buf(weight)
-            _wgrad_async(x, dz, lambda: ops.conv2d_wgrad(x, dz, weight.shape, cfg.stride, cfg.pad, affine=cfg.affine,
-                                                         dw=gw, accumulate=True))
+            if ctx.s2d:
+                def _stem_wgrad():
+                    dw2 = ops.conv2d_wgrad(x, dz, (Co, x.shape[1], 4, 4), 1, 2)
+                    ops.s2d_weight_grad(dw2, gw, accumulate=True)
+                _wgrad_async(x, dz, _stem_wgrad)
+            else:
+                _wgrad_async(x, dz, lambda: ops.conv2d_wgrad(x, dz, weight.shape, cfg.stride, cfg.pad,
+                                                             affine=cfg.affine, dw=gw, accumulate=True))
             if bias is not None and bias.requires_grad:
                 grad_buf(bias)
         dx = None
         if ctx.needs_input_grad[0]:
+            if ctx.s2d:
+                raise NotImplementedError("input gradient of a space-to-depth stem (stems read data, not activations)")
             dx = ops.conv2d_dgrad(dz, weight, (x.shape[2], x.shape[3]), cfg.stride, cfg.pad)
         for p in (weight, bias, gamma, beta):
             if p is not None:

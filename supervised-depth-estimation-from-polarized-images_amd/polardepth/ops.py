@@ -60,7 +60,7 @@ def conv_out_size(h, k, s, p):
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, want_stats=False,
-               affine=None, out=None):
+               affine=None, out=None, out_hw=None):
     """y = act(conv(x, w) + bias).  x: [N,C,H,W] any strides; returns channels_last [N,Co,Ho,Wo].
 
     want_stats -> also returns the per-workgroup BatchNorm partials [rows, Co, 2] (sum, sum of squares
@@ -74,6 +74,9 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     assert Ci == C, f"channel mismatch {Ci} vs {C}"
     w = weight_cl(w)
     Ho, Wo = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
+    if out_hw is not None:          # leading part of the output grid only (asymmetric padding)
+        assert out_hw[0] <= Ho and out_hw[1] <= Wo
+        Ho, Wo = out_hw
     if out is None:
         out = empty_nhwc(N, Co, Ho, Wo, x.device)
     assert out.shape == (N, Co, Ho, Wo) and out.stride(1) == 1
@@ -195,3 +198,35 @@ def depth_metrics(gt, pred, min_depth, max_depth, mask=None, mask_value=0):
     check(lib.pd_depth_metrics(ptr(gt), ptr(pred), ptr(mask), int(mask_value), ptr(ws), ptr(out), N, P,
                                float(min_depth), float(max_depth), stream_ptr()), "pd_depth_metrics")
     return out
+
+
+# ------------------------------------------------------------------ 7x7/s2 stems as 4x4/s1 over space-to-depth
+def s2d_input(x, affine=None):
+    """[N,C,H,W] (any strides) -> channels_last [N,4C,H/2,W/2] with q = (dy*2+dx)*C + c; optional (x-sub)/div."""
+    _require_cuda(x)
+    N, C, H, W = x.shape
+    out = empty_nhwc(N, 4 * C, H // 2, W // 2, x.device)
+    sub, div = affine if affine is not None else (0.0, 1.0)
+    sN, sC, sH, sW = x.stride()
+    check(lib.pd_stem_s2d_input(ptr(x), ptr(out), N, C, H, W, sN, sC, sH, sW, int(affine is not None), sub, div,
+                                stream_ptr()), "pd_stem_s2d_input")
+    return out
+
+
+def s2d_weight(w):
+    """[Co,C,7,7] (channels_last) -> channels_last [Co,4C,4,4]."""
+    Co, C, KH, KW = w.shape
+    assert KH == 7 and KW == 7
+    w = weight_cl(w)
+    w2 = torch.empty((Co, 4 * C, 4, 4), dtype=torch.float32, device=w.device).contiguous(memory_format=CL)
+    check(lib.pd_stem_s2d_weight(ptr(w), ptr(w2), Co, C, stream_ptr()), "pd_stem_s2d_weight")
+    return w2
+
+
+def s2d_weight_grad(dw2, dw, accumulate=True):
+    """dW2 [Co,4C,4,4] (channels_last) -> (+)= dW [Co,C,7,7] (channels_last)."""
+    Co, C = dw.shape[0], dw.shape[1]
+    assert dw.is_contiguous(memory_format=CL) or C == 1
+    check(lib.pd_stem_s2d_weight_grad(ptr(dw2), ptr(dw), Co, C, int(accumulate), stream_ptr()),
+          "pd_stem_s2d_weight_grad")
+    return dw

@@ -107,3 +107,27 @@ def test_conv_writes_into_concat_slice_and_accumulates_wgrad():
     dw = ops.conv2d_wgrad(xd, dy, w.shape, stride=1, pad=1)
     dw2 = ops.conv2d_wgrad(xd, dy, w.shape, stride=1, pad=1, dw=dw.clone(), accumulate=True)
     _close(dw2.cpu(), 2 * dw.cpu(), 1e-6)
+
+
+@pytest.mark.parametrize("C", [2, 3, 9])
+def test_stem_as_space_to_depth_conv(C):
+    """7x7/s2/p3 stem == 4x4/s1/p2 conv over the space-to-depth input with regrouped weights (fwd + wgrad)."""
+    g = torch.Generator().manual_seed(C)
+    x = torch.rand(2, C, 32, 48, generator=g)
+    w = torch.randn(64, C, 7, 7, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d((x - 0.45) / 0.225, wr, b, stride=2, padding=3)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd = x.cuda()
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    x2 = ops.s2d_input(xd, (0.45, 0.225))
+    w2 = ops.s2d_weight(wd)
+    assert x2.shape == (2, 4 * C, 16, 24) and w2.shape == (64, 4 * C, 4, 4)
+    y = ops.conv2d_fwd(x2, w2, b.cuda(), stride=1, pad=2, out_hw=(16, 24))
+    _close(y.cpu(), ref.detach())
+    dw2 = ops.conv2d_wgrad(x2, dy.cuda().contiguous(memory_format=torch.channels_last), (64, 4 * C, 4, 4), stride=1, pad=2)
+    dw = torch.zeros_like(wd)
+    ops.s2d_weight_grad(dw2, dw, accumulate=True)
+    _close(dw.cpu(), wr.grad)
