@@ -147,7 +147,7 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
     assert Ci == C
     Ho, Wo = dy.shape[2], dy.shape[3]
     if dw is None:
-        dw = torch.empty(w_shape, dtype=torch.float32, device=x.device).contiguous(memory_format=CL)
+        dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device, memory_format=CL)
         accumulate = False
     assert dw.is_contiguous(memory_format=CL) or dw.numel() == dw.shape[0] * dw.shape[1]
     if want_bias and dbias is None:
@@ -218,7 +218,7 @@ def s2d_weight(w):
     Co, C, KH, KW = w.shape
     assert KH == 7 and KW == 7
     w = weight_cl(w)
-    w2 = torch.empty((Co, 4 * C, 4, 4), dtype=torch.float32, device=w.device).contiguous(memory_format=CL)
+    w2 = torch.empty((Co, 4 * C, 4, 4), dtype=torch.float32, device=w.device, memory_format=CL)
     check(lib.pd_stem_s2d_weight(ptr(w), ptr(w2), Co, C, stream_ptr()), "pd_stem_s2d_weight")
     return w2
 
