@@ -1,12 +1,20 @@
 """Datasets of the façade.
 
-``HAMMER_Dataset`` keeps the reference's constructor signature (hammer_dataset.py:23, as called at
-trainer.py:276-303).  File decoding of the real HAMMER tree is outside the hot path (SURVEY.md §8f
-rank 1); this build serves seeded synthetic HAMMER-shaped items (same keys, dtypes and shapes as
-indoor_dataset.py:277-425) and additionally hands over the four raw polarizer planes as
-``("pol", 0, 0)`` uint8 so that DoLP/AoLP/normals are computed on the device by K1 instead of in the
-DataLoader workers (indoor_dataset.py:430-442).
+``HAMMER_Dataset`` keeps the reference's constructor signature (hammer_dataset.py:23 / indoor_dataset.py:39-57, as
+called at trainer.py:276-303).  When ``data_path`` holds a HAMMER tree
+(``<scene>/<modality>/{rgb,pol00,pol01,pol10,pol11,_gt,<depth_modality>,_instance}/%06d.png`` + ``intrinsics.txt``,
+indoor_dataset.py:118-190, hammer_dataset.py:59-169) the items are decoded from disk with PIL (LANCZOS resize =
+the reference's Image.ANTIALIAS, nearest for depth / instance masks, 16-bit depth in mm -> m); otherwise seeded
+synthetic HAMMER-shaped items with the same keys, dtypes and shapes are served.
+
+Difference to the reference by design: the four polarizer grays are handed over raw as ``("pol", 0, 0)`` uint8
+[4,H,W] (order 0/45/90/135 deg = pol00, pol01, pol10, pol11, indoor_dataset.py:435-439) and DoLP/AoLP/normals are
+computed on the device by K1, instead of the per-pixel ``lstsq`` in the DataLoader workers (:430-442).
+Colour jitter (:414-418) needs torchvision, which is not installed here: ``color_aug`` equals ``color``.
 """
+import glob
+import os
+
 import numpy as np
 import torch
 from torch.utils.data import Dataset
@@ -17,15 +25,80 @@ class HAMMER_Dataset(Dataset):
                  offset=10, modality="polarization", supervised_depth=True, supervised_depth_only=True,
                  depth_modality="_gt", items_per_scene=8):
         super().__init__()
+        self.data_path, self.modality, self.depth_modality, self.img_ext = data_path, modality, depth_modality, img_ext
         self.height, self.width, self.num_scales = height, width, num_scales
         self.filenames = list(filenames) if filenames else ["synthetic_scene"]
-        self.items = len(self.filenames) * items_per_scene
         self.is_train = is_train
+        self.frames = self._discover(filenames) if data_path and os.path.isdir(str(data_path)) else []
+        self.items = len(self.frames) if self.frames else len(self.filenames) * items_per_scene
+
+    # ---- real HAMMER tree -------------------------------------------------------------------------------
+    def _discover(self, scenes):
+        """(folder, frame_index) of every frame that has rgb, the four polarizer images, _gt and depth_modality."""
+        frames = []
+        for scene in scenes or []:
+            folder = os.path.join(self.data_path, scene, self.modality)
+            for f in sorted(glob.glob(os.path.join(folder, "rgb", "*" + self.img_ext))):
+                idx = int(os.path.basename(f).split('.')[0])
+                need = ["pol00", "pol01", "pol10", "pol11", "_gt", self.depth_modality]
+                if all(os.path.isfile(os.path.join(folder, d, "{:06d}.png".format(idx))) for d in need):
+                    frames.append((folder, idx))
+        return frames
+
+    def _load_item(self, folder, idx):
+        from PIL import Image
+        H, W = self.height, self.width
+        name = "{:06d}{}".format(idx, self.img_ext)
+        to_t = lambda im: torch.from_numpy(np.asarray(im, dtype=np.float32).transpose(2, 0, 1) / 255.0)
+        inputs = {}
+        color = Image.open(os.path.join(folder, "rgb", name)).convert("RGB")
+        full_w, full_h = color.size
+        prev = color
+        for s in range(self.num_scales):          # successive LANCZOS resizes (indoor_dataset.py:192-215)
+            prev = prev.resize((W >> s, H >> s), Image.LANCZOS)
+            inputs[("color", 0, s)] = to_t(prev)
+            inputs[("color_aug", 0, s)] = inputs[("color", 0, s)]
+        planes = [np.asarray(Image.open(os.path.join(folder, d, name)).convert("L").resize((W, H), Image.LANCZOS))
+                  for d in ("pol00", "pol01", "pol10", "pol11")]                  # 0, 45, 90, 135 degrees
+        inputs[("pol", 0, 0)] = torch.from_numpy(np.stack(planes).astype(np.uint8))
+
+        def depth_of(sub):                        # 16-bit PNG in mm -> metres, nearest resize (hammer_dataset.py:135-169)
+            im = Image.open(os.path.join(folder, sub, "{:06d}.png".format(idx)))
+            arr = np.asarray(im.resize((W, H), Image.NEAREST)).astype(np.uint16)
+            return torch.from_numpy((arr / 1000).astype(np.float32))[None]
+        inputs["depth"] = depth_of(self.depth_modality)
+        inputs["depth_gt"] = depth_of("_gt")
+        mpath = os.path.join(folder, "_instance", "{:06d}.png".format(idx))
+        if os.path.isfile(mpath):
+            m = np.asarray(Image.open(mpath).convert("L").resize((W, H), Image.NEAREST))
+        else:
+            m = np.zeros((H, W), np.uint8)
+        inputs[("mask", 0, 0)] = torch.from_numpy(m.astype(np.int32))[None]
+        K0 = np.eye(4, dtype=np.float32)          # indoor_dataset.py:261-275, 379-388
+        with open(os.path.join(folder, "intrinsics.txt")) as f:
+            K0[:3, :3] = np.array(f.read().split(), dtype=np.float32).reshape(3, 3)
+        K0[0, :] /= full_w
+        K0[1, :] /= full_h
+        for s in range(self.num_scales):
+            K = K0.copy()
+            K[0, :] *= W // (2 ** s)
+            K[1, :] *= H // (2 ** s)
+            inputs[("K", s)] = torch.from_numpy(K)
+            inputs[("inv_K", s)] = torch.from_numpy(np.linalg.pinv(K))
+        inputs["stereo_T"] = torch.eye(4)
+        inputs["stereo_T"][0, 3] = -0.0498921
+        return inputs
 
     def __len__(self):
         return self.items
 
     def __getitem__(self, index):
+        if self.frames:
+            return self._load_item(*self.frames[index])
+        return self._synthetic_item(index)
+
+    # ---- synthetic items --------------------------------------------------------------------------------
+    def _synthetic_item(self, index):
         rng = np.random.default_rng(index)
         H, W = self.height, self.width
         inputs = {}

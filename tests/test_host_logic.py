@@ -99,3 +99,35 @@ def test_no_cpu_fallback_anywhere():
         Trainer(opts)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.conv2d_fwd(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 3, 3))
+
+
+def test_hammer_dataset_reads_a_real_tree_and_falls_back_to_synthetic(tmp_path):
+    """File-backed HAMMER items (PIL) have the keys / dtypes / shapes of indoor_dataset.py:277-425."""
+    from PIL import Image
+    from manydepth.datasets import HAMMER_Dataset
+    rng = np.random.default_rng(0)
+    scene = tmp_path / "scene1_traj1_1" / "polarization"
+    for d in ("rgb", "pol00", "pol01", "pol10", "pol11", "_gt", "_instance"):
+        (scene / d).mkdir(parents=True)
+    for idx in (3, 4):
+        Image.fromarray(rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)).save(scene / "rgb" / f"{idx:06d}.png")
+        for d in ("pol00", "pol01", "pol10", "pol11"):
+            Image.fromarray(rng.integers(0, 256, (96, 128), dtype=np.uint8)).save(scene / d / f"{idx:06d}.png")
+        Image.fromarray(rng.integers(300, 1800, (96, 128)).astype(np.uint16)).save(scene / "_gt" / f"{idx:06d}.png")
+        Image.fromarray((rng.integers(0, 11, (96, 128)) * 20).astype(np.uint8)).save(scene / "_instance" / f"{idx:06d}.png")
+    (scene / "intrinsics.txt").write_text("80 0 64\n0 82 48\n0 0 1\n")
+    ds = HAMMER_Dataset(str(tmp_path), ["scene1_traj1_1"], 64, 96, [0], 4, is_train=True)
+    assert len(ds) == 2
+    it = ds[0]
+    assert it[("pol", 0, 0)].dtype == torch.uint8 and it[("pol", 0, 0)].shape == (4, 64, 96)
+    assert it[("color", 0, 2)].shape == (3, 16, 24) and 0 <= it[("color", 0, 0)].min() and it[("color", 0, 0)].max() <= 1
+    assert it["depth"].shape == (1, 64, 96) and 0.3 <= it["depth"].min() and it["depth"].max() < 1.8
+    assert it[("mask", 0, 0)].dtype == torch.int32 and set(np.unique(it[("mask", 0, 0)].numpy())) <= set(range(0, 201, 20))
+    K = it[("K", 0)]
+    assert abs(K[0, 0].item() - 80 / 128 * 96) < 1e-4 and abs(K[1, 2].item() - 48 / 96 * 64) < 1e-4
+    assert torch.allclose(it[("K", 1)][0, 0], K[0, 0] / 2)
+    synth = HAMMER_Dataset("does/not/exist", ["a"], 64, 96, [0], 4)
+    s = synth[0]
+    assert set(it.keys()) == set(s.keys())
+    for k in it:
+        assert it[k].dtype == s[k].dtype and it[k].shape == s[k].shape, k
