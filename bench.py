@@ -107,7 +107,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--attention", action="store_true",
+                    help="BASELINE configs[4] variant (single-head attention at the joint-encoder merge, fp32); "
+                         "not the headline workload")
     args = ap.parse_args()
+    if args.attention:
+        os.environ["PD_JOINT_ATTENTION"] = "1"
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -195,12 +200,13 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: full 3-encoder (augment_xolp+augment_normals), multi-scale loss "
                                "scales=[0,1,2,3], batch 16 per GPU, 512x612 frames (network/loss on 512x640 padded), "
-                               "dropout 0.1, Adam lr 1e-4, fp32",
+                               "dropout 0.1, Adam lr 1e-4, fp32" + (" + joint-encoder attention (configs[4] variant)"
+                                                                   if args.attention else ""),
                    "global_batch": args.batch * world, "height": H, "width": W, "frame_width": FRAME_W,
                    "parallelism": f"dp{world}"},
         "final_loss": round(loss_val, 6), "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.attention:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -234,6 +234,13 @@ int pd_ssim_fwd(const void* x, const void* y, void* out, int N, int C, int H, in
 int pd_depth_metrics(const void* gt, const void* pred, const void* mask, int mask_value, void* partial_ws,
                      void* metrics, int N, long P, float min_depth, float max_depth, void* stream);
 
+/* Row softmax of the attention variant (BASELINE config 5; SURVEY A17 -- defined by this build, the reference
+ * branch is absent): in place x[r][:] = softmax(scale * x[r][:]) and its backward
+ * dp[r][:] <- scale * p * (dp - sum(dp * p)).  The score GEMMs (Q K^T, P V and their gradients) are pd_conv2d /
+ * pd_conv2d_wgrad calls with 1x1 filters. */
+int pd_softmax_rows_fwd(void* x, long R, long L, float scale, void* stream);
+int pd_softmax_rows_bwd(const void* p, void* dp, long R, long L, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

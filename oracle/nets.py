@@ -99,10 +99,29 @@ class ShallowNormalsEncoder(ShallowEncoder):
         return super().forward(self.get_normals(x).float())
 
 
+class JointAttention(nn.Module):
+    """Attention variant (BASELINE config 5): the reference branch `arch1++_attention` is not in the checkout
+    (README.md:53, presentation slide 38 only name it), so this restates the build's own definition --
+    **parity unpinned**:  y = x + o(softmax(q k^T / sqrt(C)) v) over the H*W tokens, q/k/v/o = 1x1 convs."""
+
+    def __init__(self, channels=128):
+        super().__init__()
+        self.q, self.k, self.v, self.o = (nn.Conv2d(channels, channels, 1) for _ in range(4))
+
+    def forward(self, x):
+        N, C, H, W = x.shape
+        tok = lambda t: t.flatten(2).transpose(1, 2)                 # [N, T, C]
+        q, k, v = tok(self.q(x)), tok(self.k(x)), tok(self.v(x))
+        p = torch.softmax(q @ k.transpose(1, 2) / C ** 0.5, dim=-1)
+        a = (p @ v).transpose(1, 2).reshape(N, C, H, W)
+        return x + self.o(a)
+
+
 class JointEncoder(nn.Module):
-    def __init__(self, dropout_rate=0.0, include_normals=True, include_xolp=True):
+    def __init__(self, dropout_rate=0.0, include_normals=True, include_xolp=True, attention=False):
         super().__init__()
         extra = 64 * (int(include_normals) + int(include_xolp))
+        self.attn = JointAttention(128) if attention else None
         p = dropout_rate
         self.fc1 = EncConv(128 + extra, 256, 1, 'none', 0, p)
         self.fc2 = EncConv(256, 128, 1, 'none', 0, p)
@@ -119,6 +138,8 @@ class JointEncoder(nn.Module):
         parts = [rgb_feats] + [f for f in (xolp_feats, normals_feats) if f is not None]   # order: rgb, xolp, normals
         f = torch.cat(parts, 1) if len(parts) > 1 else rgb_feats
         f = self.fc2(self.fc1(f))
+        if self.attn is not None:
+            f = self.attn(f)
         f = self.ResBlock2(self.ResBlock1(f))
         a = self.ResBlock4(self.ResBlock3(self.Conv1(f)))
         b = self.ResBlock6(self.ResBlock5(self.Conv2(a)))

@@ -710,3 +710,66 @@ extern "C" int pd_adam_step(void* p, const void* g, void* m, void* v, long n, fl
                        grad_scale);
     return pd::check_launch("pd_adam_step");
 }
+
+// ============================================================================ row softmax (attention variant)
+// Single-head self-attention at the JointEncoder merge (BASELINE config 5 / SURVEY A17; the reference branch
+// arch1++_attention is absent from the checkout, so the block is defined by this build: see DESIGN.md).
+// The score matrix is materialised in fp32 (T = H/8*W/8 = 5120 tokens -> 105 MB per image, trivially resident in
+// 288 GB of HBM) and the two GEMMs run on the fp32-MFMA implicit-GEMM kernels; these kernels do the row softmax.
+namespace {
+
+__device__ __forceinline__ float block_reduce(float v, float* sm, bool is_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(v, o); v = is_max ? fmaxf(v, t) : v + t; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    float r = sm[0];
+#pragma unroll
+    for (int w = 1; w < EW_T / 64; ++w) r = is_max ? fmaxf(r, sm[w]) : r + sm[w];
+    return r;
+}
+
+// in place: x[r][:] = softmax(scale * x[r][:]); one workgroup per row
+__global__ __launch_bounds__(EW_T) void softmax_fwd_kernel(float* __restrict__ x, long L, float scale) {
+    __shared__ float sm[EW_T / 64];
+    float* row = x + (long)blockIdx.x * L;
+    float m = -INFINITY;
+    for (long i = threadIdx.x; i < L; i += EW_T) m = fmaxf(m, row[i] * scale);
+    m = block_reduce(m, sm, true);
+    float s = 0.f;
+    for (long i = threadIdx.x; i < L; i += EW_T) { const float e = expf(row[i] * scale - m); row[i] = e; s += e; }
+    s = block_reduce(s, sm, false);
+    const float inv = 1.f / s;
+    for (long i = threadIdx.x; i < L; i += EW_T) row[i] *= inv;
+}
+
+// in place on dp: ds[r][:] = scale * p[r][:] * (dp[r][:] - sum_j dp[r][j] p[r][j])
+__global__ __launch_bounds__(EW_T) void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long L,
+                                                           float scale) {
+    __shared__ float sm[EW_T / 64];
+    const float* pr = p + (long)blockIdx.x * L;
+    float* dr = dp + (long)blockIdx.x * L;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < L; i += EW_T) s += pr[i] * dr[i];
+    s = block_reduce(s, sm, false);
+    for (long i = threadIdx.x; i < L; i += EW_T) dr[i] = scale * pr[i] * (dr[i] - s);
+}
+
+}  // namespace
+
+extern "C" int pd_softmax_rows_fwd(void* x, long R, long L, float scale, void* stream) {
+    PD_REQUIRE(x && R >= 0 && L > 0, "pd_softmax_rows_fwd: bad arguments");
+    if (R == 0) return PD_OK;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)R), dim3(EW_T), 0, (hipStream_t)stream, (float*)x, L, scale);
+    return pd::check_launch("pd_softmax_rows_fwd");
+}
+
+extern "C" int pd_softmax_rows_bwd(const void* p, void* dp, long R, long L, float scale, void* stream) {
+    PD_REQUIRE(p && dp && R >= 0 && L > 0, "pd_softmax_rows_bwd: bad arguments");
+    if (R == 0) return PD_OK;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)R), dim3(EW_T), 0, (hipStream_t)stream, (const float*)p,
+                       (float*)dp, L, scale);
+    return pd::check_launch("pd_softmax_rows_bwd");
+}

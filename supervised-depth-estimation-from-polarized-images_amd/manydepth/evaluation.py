@@ -18,7 +18,7 @@ _MATERIAL_GREY = {"box": 20, "bottle": 40, "can": 60, "cup": 80, "remote": 100, 
 
 class Evaluation:
     def __init__(self, load_weights_folder=None, data_path=None, height=320, width=480, batch_size=12,
-                 augment_xolp=True, augment_normals=True, num_workers=0):
+                 augment_xolp=True, augment_normals=True, num_workers=0, joint_attention=None):
         if not torch.cuda.is_available():
             raise RuntimeError("Evaluation needs the MI355X: there is no CPU fallback")
         self.height, self.width, self.batch_size = height, width, batch_size
@@ -31,7 +31,9 @@ class Evaluation:
             self.models["normals_encoder"] = networks.ShallowNormalsEncoder(9, 0.0)
         if augment_xolp:
             self.models["xolp_encoder"] = networks.ShallowEncoder('XOLP', 2, 0.0)
-        self.models["joint_encoder"] = networks.JointEncoder(0.0, augment_normals, augment_xolp)
+        self.models["joint_encoder"] = networks.JointEncoder(
+            0.0, augment_normals, augment_xolp,
+            attention=(os.environ.get("PD_JOINT_ATTENTION") == "1") if joint_attention is None else joint_attention)
         self.models["mono_depth"] = networks.DepthDecoder(self.models["rgb_encoder"].num_ch_enc, self.scales)
         for m in self.models.values():
             m.to(self.device).eval()

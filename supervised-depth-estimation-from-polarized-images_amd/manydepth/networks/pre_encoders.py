@@ -103,10 +103,27 @@ class ShallowNormalsEncoder(ShallowEncoder):
         return _get_normals(x, n)
 
 
+class JointAttention(nn.Module):
+    """Single-head softmax self-attention + residual over the H/8 x W/8 token grid after the modality merge
+    (BASELINE config 5 "arch1++_attention"; README.md:53 / presentation slide 38 of the reference describe it, the
+    branch itself is not in the checkout, so this block is the build's definition -- DESIGN.md):
+        y = x + o(softmax(q(x) k(x)^T / sqrt(C)) v(x)),   q, k, v, o = 1x1 convolutions with bias."""
+
+    def __init__(self, channels=128):
+        super().__init__()
+        mk = lambda: _channels_last_(nn.Conv2d(channels, channels, 1))
+        self.q, self.k, self.v, self.o = mk(), mk(), mk(), mk()
+
+    def forward(self, x):
+        a = PF.self_attention(PF.conv_bias(x, self.q), PF.conv_bias(x, self.k), PF.conv_bias(x, self.v))
+        return x + PF.conv_bias(a, self.o)
+
+
 class JointEncoder(nn.Module):
-    def __init__(self, dropout_rate=0.0, include_normals=True, include_xolp=True):
+    def __init__(self, dropout_rate=0.0, include_normals=True, include_xolp=True, attention=False):
         super().__init__()
         additional_ch = 64 * (int(include_normals) + int(include_xolp))
+        self.attn = JointAttention(128) if attention else None
         self.fc1 = ConvBlock(128 + additional_ch, 256, 1, 'none', 0, dropout_rate)
         self.fc2 = ConvBlock(256, 128, 1, 'none', 0, dropout_rate)
         self.ResBlock1 = ResidualBlock(128, 3, 1, dropout_rate)
@@ -122,6 +139,8 @@ class JointEncoder(nn.Module):
         parts = [rgb_feats] + [f for f in (xolp_feats, normals_feats) if f is not None]   # rgb, xolp, normals (:142-151)
         feats = torch.cat(parts, dim=1) if len(parts) > 1 else rgb_feats
         feats = self.fc2(self.fc1(feats))
+        if self.attn is not None:
+            feats = self.attn(feats)
         feats = self.ResBlock2(self.ResBlock1(feats))
         a = self.ResBlock4(self.ResBlock3(self.Conv1(feats)))
         b = self.ResBlock6(self.ResBlock5(self.Conv2(a)))

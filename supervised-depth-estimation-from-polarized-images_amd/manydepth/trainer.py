@@ -53,6 +53,13 @@ def _unused_resnet_param(model_name, param_name):
     return model_name == "rgb_encoder" and param_name.split(".")[1] in ("layer3", "layer4", "fc")
 
 
+def _attention_variant(opt):
+    """BASELINE config 5 ("arch1++_attention"): the reference's master parser has no flag for it, so the option
+    table stays identical to manydepth/options.py and the variant is switched by an attribute set on the options
+    object (``opt.joint_attention = True``) or by ``PD_JOINT_ATTENTION=1``."""
+    return bool(getattr(opt, "joint_attention", False)) or os.environ.get("PD_JOINT_ATTENTION") == "1"
+
+
 class Trainer:
     def __init__(self, options):
         self.opt = options
@@ -96,7 +103,8 @@ class Trainer:
                                                                   dropout_rate=self.opt.dropout_rate)
         self.models["joint_encoder"] = networks.JointEncoder(dropout_rate=self.opt.dropout_rate,
                                                              include_normals=self.opt.augment_normals,
-                                                             include_xolp=self.opt.augment_xolp)
+                                                             include_xolp=self.opt.augment_xolp,
+                                                             attention=_attention_variant(self.opt))
         self.models["mono_depth"] = networks.DepthDecoder(self.models["rgb_encoder"].num_ch_enc, self.opt.scales)
         for m in self.models.values():
             m.to(self.device)

@@ -349,6 +349,87 @@ def maxpool3s2(x):
     return MaxPool3s2Fn.apply(x)
 
 
+# ------------------------------------------------------------------ plain convolution with bias (no BatchNorm)
+class ConvBiasFn(torch.autograd.Function):
+    """nn.Conv2d (zero padding, bias) without a normalisation layer behind it, e.g. the 1x1 q/k/v/o projections."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        x = ops.as_nhwc(x)
+        y = ops.conv2d_fwd(x, weight, bias, stride, pad)
+        ctx.geom = (stride, pad)
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        weight, bias = ctx.params
+        stride, pad = ctx.geom
+        dy = ops.as_nhwc(dy)
+        if weight.requires_grad:
+            db = grad_buf(bias) if bias is not None and bias.requires_grad else None
+            gw = grad_buf(weight)
+            _wgrad_async(x, dy, lambda: ops.conv2d_wgrad(x, dy, weight.shape, stride, pad, dw=gw, dbias=db, accumulate=True))
+        dx = ops.conv2d_dgrad(dy, weight, (x.shape[2], x.shape[3]), stride, pad) if ctx.needs_input_grad[0] else None
+        for p in (weight, bias):
+            if p is not None:
+                _ready(p)
+        return dx, None, None, None, None
+
+
+def conv_bias(x, conv):
+    return ConvBiasFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+
+
+# ------------------------------------------------------------------ single-head self-attention (config 5 variant)
+class SelfAttentionFn(torch.autograd.Function):
+    """o = softmax(q k^T / sqrt(C)) v over the T = H*W tokens of each image; q, k, v: [N,C,H,W] NHWC.
+
+    The score matrix is materialised in fp32 per image ([T,T]; 105 MB at T = 5120) and every matrix product
+    runs on the fp32-MFMA GEMM kernels (exact fp32, same parity bar as the rest of the network)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = ops.as_nhwc(q), ops.as_nhwc(k), ops.as_nhwc(v)
+        N, C, H, W = q.shape
+        T = H * W
+        scale = 1.0 / (C ** 0.5)
+        qm, km, vm = (t.permute(0, 2, 3, 1).reshape(N, T, C) for t in (q, k, v))      # views of the NHWC storage
+        P = torch.empty((N, T, T), dtype=torch.float32, device=q.device)
+        o = ops.empty_nhwc(N, C, H, W, q.device)
+        om = o.permute(0, 2, 3, 1).reshape(N, T, C)
+        for n in range(N):
+            ops.gemm_nt(qm[n], km[n], out=P[n])
+            ops.softmax_rows_(P[n], scale)
+            ops.gemm_nt(P[n], ops.transpose2d(vm[n]), out=om[n])
+        ctx.scale = scale
+        ctx.save_for_backward(qm, km, vm, P)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qm, km, vm, P = ctx.saved_tensors
+        N, T, C = qm.shape
+        do = ops.as_nhwc(do)
+        H, W = do.shape[2], do.shape[3]
+        dom = do.permute(0, 2, 3, 1).reshape(N, T, C)
+        dq, dk, dv = (ops.empty_nhwc(N, C, H, W, do.device) for _ in range(3))
+        dqm, dkm, dvm = (t.permute(0, 2, 3, 1).reshape(N, T, C) for t in (dq, dk, dv))
+        for n in range(N):
+            ops.transpose2d(ops.gemm_tn(dom[n], P[n]), out=dvm[n])             # dV = P^T dO
+            dP = ops.gemm_nt(dom[n], vm[n])                                    # dP = dO V^T
+            ops.softmax_rows_bwd_(P[n], dP, ctx.scale)                         # dS (in place)
+            ops.gemm_nt(dP, ops.transpose2d(km[n]), out=dqm[n])                # dQ = dS K
+            ops.transpose2d(ops.gemm_tn(qm[n], dP), out=dkm[n])                # dK = dS^T Q
+        return dq, dk, dv
+
+
+def self_attention(q, k, v):
+    return SelfAttentionFn.apply(q, k, v)
+
+
 # ------------------------------------------------------------------ multi-scale loss
 class LossCfg:
     def __init__(self, scales, min_depth, max_depth, normals_loss_weight, disparity_smoothness, height, width):

@@ -230,3 +230,57 @@ def s2d_weight_grad(dw2, dw, accumulate=True):
     check(lib.pd_stem_s2d_weight_grad(ptr(dw2), ptr(dw), Co, C, int(accumulate), stream_ptr()),
           "pd_stem_s2d_weight_grad")
     return dw
+
+
+# ------------------------------------------------------------------ dense GEMMs on the conv kernels (attention)
+def gemm_nt(a, b, out=None):
+    """C[M,N] = A[M,K] @ B[N,K]^T (fp32 MFMA): pd_conv2d with a 1x1 filter, A as a [1,M,1,K] NHWC image."""
+    _require_cuda(a, b)
+    M, K = a.shape
+    Nn, Kb = b.shape
+    assert K == Kb and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty((M, Nn), dtype=torch.float32, device=a.device)
+    _profiled(_igemm_label(M, Nn, K % 4 == 0, "gemm"), 2.0 * M * Nn * K,
+              lambda: check(lib.pd_conv2d(ptr(a), ptr(b), None, ptr(out), None, 1, M, 1, K, M * K, K, K, 1,
+                                          M, 1, Nn, 1, 1, 1, 0, MODE_ZERO, ACT_NONE, 0, 0.0, 1.0, out.stride(0),
+                                          stream_ptr()), "pd_conv2d(gemm_nt)"))
+    return out
+
+
+def gemm_tn(dy, x):
+    """C[N,K] = dY[M,N]^T @ X[M,K] (contraction over rows): pd_conv2d_wgrad with a 1x1 filter."""
+    _require_cuda(dy, x)
+    M, Nn = dy.shape
+    Mx, K = x.shape
+    assert M == Mx and dy.is_contiguous() and x.is_contiguous()
+    out = torch.empty((Nn, K), dtype=torch.float32, device=x.device)
+    nbytes = lib.pd_conv2d_wgrad_workspace(M, Nn, K)
+    ws = _workspace(nbytes, x.device)
+    _profiled("conv_wgrad_kernel", 2.0 * M * Nn * K,
+              lambda: check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(out), None, ptr(ws), ws.numel(), 1, M, 1, K,
+                                                M * K, K, K, 1, M, 1, Nn, 1, 1, 1, 0, MODE_ZERO, 0, 0.0, 1.0, Nn, 0,
+                                                stream_ptr()), "pd_conv2d_wgrad(gemm_tn)"))
+    return out
+
+
+def transpose2d(a, out=None):
+    """[R,C] -> [C,R] (pd_weight_transpose)."""
+    R, C = a.shape
+    if out is None:
+        out = torch.empty((C, R), dtype=torch.float32, device=a.device)
+    assert out.shape == (C, R) and out.is_contiguous() and a.is_contiguous()
+    check(lib.pd_weight_transpose(ptr(a), ptr(out), R, 1, C, stream_ptr()), "pd_weight_transpose")
+    return out
+
+
+def softmax_rows_(x, scale):
+    R, L = x.shape
+    check(lib.pd_softmax_rows_fwd(ptr(x), R, L, float(scale), stream_ptr()), "pd_softmax_rows_fwd")
+    return x
+
+
+def softmax_rows_bwd_(p, dp, scale):
+    R, L = p.shape
+    check(lib.pd_softmax_rows_bwd(ptr(p), ptr(dp), R, L, float(scale), stream_ptr()), "pd_softmax_rows_bwd")
+    return dp

@@ -136,3 +136,45 @@ def test_resnet_stem_matches_oracle():
                     _close(pm.grad, pr.grad, GRAD_TOL, k)
             _close(mod.encoder.bn1.running_mean, ref.encoder.bn1.running_mean, 1e-5)
             _close(mod.encoder.layer2[0].downsample[1].running_var, ref.encoder.layer2[0].downsample[1].running_var, 1e-5)
+
+
+def test_attention_variant_matches_oracle():
+    """BASELINE config 5 (attention at the joint-encoder merge): HIP path vs the CPU restatement (the reference
+    branch is absent: parity unpinned).  Also checks the raw attention op against torch softmax attention."""
+    from manydepth.networks.pre_encoders import JointEncoder, JointAttention
+    from polardepth import functional as PF
+    from oracle import nets as onets
+    g = torch.Generator().manual_seed(12)
+    q, k, v = (torch.randn(2, 128, 8, 12, generator=g) for _ in range(3))
+    qc, kc, vc = (t.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) for t in (q, k, v))
+    o = PF.self_attention(qc, kc, vc)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    tok = lambda t: t.flatten(2).transpose(1, 2)
+    ref = (torch.softmax(tok(qr) @ tok(kr).transpose(1, 2) / 128 ** 0.5, -1) @ tok(vr)).transpose(1, 2).reshape(2, 128, 8, 12)
+    _close(o, ref.detach(), FWD_TOL, "attention fwd")
+    w = torch.randn(ref.shape, generator=g)
+    (o * w.cuda()).sum().backward(); (ref * w).sum().backward()
+    for name, a, b in (("dq", qc, qr), ("dk", kc, kr), ("dv", vc, vr)):
+        _close(a.grad, b.grad, GRAD_TOL, name)
+    # whole joint encoder with the attention block
+    ref_m = onets.JointEncoder(0.0, True, True, attention=True)
+    fill_state_dict(ref_m, 0, prefix="joint_attn.")
+    mod = JointEncoder(0.0, True, True, attention=True)
+    mod.load_state_dict(ref_m.state_dict())
+    mod.cuda().train(); ref_m.train()
+    rgbf, xf, nf = T(G4["joint.rgbf"]), T(G4["joint.xf"]), T(G4["joint.nf"])
+    ins = [t.clone().requires_grad_(True) for t in (rgbf, xf, nf)]
+    cins = [t.cuda().requires_grad_(True) for t in (rgbf, xf, nf)]
+    yr = ref_m(*ins); ym = mod(*cins)
+    obj_r = obj_m = 0
+    for i in range(2):
+        _close(ym[i], yr[i].detach(), FWD_TOL, f"joint+attn out{i}")
+        w = torch.randn(yr[i].shape, generator=torch.Generator().manual_seed(400 + i))
+        obj_r = obj_r + (yr[i] * w).sum(); obj_m = obj_m + (ym[i] * w.cuda()).sum()
+    obj_r.backward(); obj_m.backward()
+    for (kname, pr), (_, pm) in zip(ref_m.named_parameters(), mod.named_parameters()):
+        if kname.endswith("conv.bias") or kname == "attn.k.bias":
+            continue                  # exactly-zero gradients (BN / softmax shift invariance): rounding noise only
+        _close(pm.grad, pr.grad, GRAD_TOL, kname)
+    for a, b in zip(cins, ins):
+        _close(a.grad, b.grad, GRAD_TOL, "input grad")
