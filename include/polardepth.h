@@ -56,6 +56,10 @@ int pd_version(void);
  * PD_POLAR_FAST_NORMALS = fp32 angle addition on fp32 tables with residuals (|err| ~1e-7, cos/sin(phi+pi/2) by
  * identity), ~8 % faster.  DoLP / AoLP / index maps are bit-exact in both. */
 #define PD_POLAR_FAST_NORMALS 1
+/* PD_POLAR_IEEE_RHO = evaluate the reference's fp64 sqrt/div sequence for every pixel instead of the
+ * Newton-refined hardware seeds with a rounding test (same bits, ~1.3x the arithmetic); the exhaustive test
+ * compares the two over all 2^32 uint8 quadruples. */
+#define PD_POLAR_IEEE_RHO 2
 
 /* bytes needed for the table blob with n_d / n_s1 / n_s2 table nodes */
 size_t pd_polar_tables_bytes(int n_d, int n_s1, int n_s2);

@@ -380,132 +380,206 @@ __device__ __forceinline__ void normals9(float rho, float phi, const Tabs& t, fl
 
 struct Px {
     float rho, phi;
-    int d1, d2;
+    float d1, d2;    // I0 - I90, I45 - I135 (exact small integers)
 };
 
+// The reference's fp64 operation sequence, executed literally (IEEE sqrt / div, one rounding to fp32).
+// S = I0 + I45 + I90 + I135 (LS) or I0 + I90 (Stokes); all arguments are exact small integers.
 template <int MODE>
-__device__ __forceinline__ Px xolp_pixel(int i0, int i45, int i90, int i135, const float* __restrict__ lut) {
-    Px p;
-    p.d1 = i0 - i90;
-    p.d2 = i45 - i135;
+__device__ __noinline__ float rho_ieee(float S, float d1, float d2) {
     double rho;
     if (MODE == PD_POLAR_LS) {
         // x = closed-form least-squares solution; then xolp.py:22-29 literally, in fp64.
-        double x0 = static_cast<double>(i0 + i45 + i90 + i135) * 0.25;
-        double x1 = static_cast<double>(p.d1) * 0.5;
-        double x2 = static_cast<double>(p.d2) * 0.5;
-        double r = sqrt(x1 * x1 + x2 * x2);
-        double imax = x0 + r;
-        double imin = x0 - r;
+        const double x0 = static_cast<double>(S) * 0.25;
+        const double x1 = static_cast<double>(d1) * 0.5;
+        const double x2 = static_cast<double>(d2) * 0.5;
+        const double r = sqrt(x1 * x1 + x2 * x2);
+        const double imax = x0 + r;
+        const double imin = x0 - r;
         rho = (imax - imin) / (imax + imin);
         if (isinf(rho) || isnan(rho)) rho = 0.0;  // rho[rho == inf] = 0; nan_to_num
     } else {
         // physical_normals_channels.py:21-26: rho = sqrt(s1^2 + s2^2) / s0, no guard.
-        double s0 = static_cast<double>(i0 + i90);
-        double s1 = static_cast<double>(p.d1);
-        double s2 = static_cast<double>(p.d2);
-        rho = sqrt(s1 * s1 + s2 * s2) / s0;
+        const double s1 = static_cast<double>(d1), s2 = static_cast<double>(d2);
+        rho = sqrt(s1 * s1 + s2 * s2) / static_cast<double>(S);
     }
-    p.rho = static_cast<float>(rho);
-    p.phi = lut[(p.d2 + 255) * kLutSide + (p.d1 + 255)];
+    return static_cast<float>(rho);
+}
+
+// DoLP without the IEEE sqrt/div sequences (Ziv's rounding test).  Mathematically rho = sqrt(s4) / den with the
+// integers s4 = d1^2 + d2^2 and den = S/2 (LS) or S (Stokes).  The reference's fp64 chain differs from that
+// value by < 2^-42 relative (its largest term: the roundings of x0 +- r, 2^-53 * x0/r <= 2^-44 for uint8 data).
+// Here: hardware rsq/rcp seeds (1 ulp fp32) and one Newton step each in fp64, relative error < 2^-43.  Both
+// therefore round to the same fp32 unless the value lies within 2^-42 of a rounding midpoint; whenever the
+// low 29 mantissa bits of q are within 2^14 fp64-ulps (2^-38 relative) of the midpoint pattern the pixel takes
+// the literal sequence instead (about one pixel in 16k).  tests/test_polar_gpu.py checks the equality against
+// the literal sequence over all 2^32 uint8 quadruples.
+template <int MODE>
+__device__ __forceinline__ float rho_pixel(float S, float d1, float d2, float s4, bool ieee) {
+    const float den = MODE == PD_POLAR_LS ? 0.5f * S : S;
+    const float y = __builtin_amdgcn_rsqf(s4);
+    const float z = __builtin_amdgcn_rcpf(den);
+    const double A = static_cast<double>(s4), D = static_cast<double>(den);
+    const double Y = static_cast<double>(y), Yh = static_cast<double>(-0.5f * y);
+    double Z = static_cast<double>(z);
+    double g = A * Y;                          // sqrt(s4) (1 + d),        |d| < 2^-22
+    g = fma(g, fma(Yh, g, 0.5), g);            // sqrt(s4) (1 - 1.5 d^2)
+    Z = fma(Z, fma(-D, Z, 1.0), Z);            // 1 / den  (1 - d'^2)
+    const double q = g * Z;
+    const unsigned lo = static_cast<unsigned>(__double2loint(q)) & 0x1fffffffu;
+    bool slow = (lo - 0x0fffc000u) < 0x8000u;  // within 2^14 ulps of the fp32 rounding midpoint
+    if (MODE == PD_POLAR_STOKES) slow |= (S == 0.f);   // x / 0 -> inf, 0 / 0 -> NaN like numpy
+    float rho = static_cast<float>(q);
+    if (s4 == 0.f) { rho = 0.f; if (MODE == PD_POLAR_LS || S != 0.f) slow = false; }
+    if (slow | ieee) rho = rho_ieee<MODE>(S, d1, d2);
+    return rho;
+}
+
+template <int MODE>
+__device__ __forceinline__ Px xolp_pixel(float f0, float f45, float f90, float f135, const float* __restrict__ lut, bool ieee) {
+    Px p;
+    p.d1 = f0 - f90;
+    p.d2 = f45 - f135;
+    const float s4 = fmaf(p.d1, p.d1, p.d2 * p.d2);                      // <= 130050: exact in fp32
+    const float S = MODE == PD_POLAR_LS ? (f0 + f90) + (f45 + f135) : f0 + f90;
+    p.rho = rho_pixel<MODE>(S, p.d1, p.d2, s4, ieee);
+    // (d2 + 255) * 511 + (d1 + 255), exact in fp32
+    const unsigned idx = static_cast<unsigned>(static_cast<int>(fmaf(p.d2, 511.f, p.d1 + 130560.f)));
+    p.phi = lut[idx];
     return p;
 }
 
-constexpr int kThreads = 512;    // XOLP-only kernels: 64 VGPRs, 4 workgroups per CU
+// (x - mean) / std with the correctly rounded quotient (Markstein: q = RN(a*y), r = a - q*b exactly, RN(q + r*y)
+// equals RN(a / b) when y = RN(1/b) and b's significand is not all ones; checked over every fp32 in [-4, 4] by
+// tests/test_polar_gpu.py).  Replaces the ten-instruction IEEE division sequence.
+__device__ __forceinline__ float standardise(float x) {
+    const float kMean = static_cast<float>(0.08693199701957657);
+    const float kStd = static_cast<float>(0.44430732785457433);
+    const float kInv = 1.0f / kStd;
+    const float a = x - kMean;
+    const float q = a * kInv;
+    return fmaf(fmaf(-q, kStd, a), kInv, q);
+}
+
+constexpr int kThreads = 512;    // XOLP-only kernels: 4 workgroups per CU
 constexpr int kThreadsN = 768;   // kernels with the fp64 normals: one 12-wave workgroup per CU (3 waves/SIMD, <= 168 VGPRs);
                                  // its 90 KB LDS image of the tables is staged once per CU
 
 constexpr int kThreadsF = 1024;  // fast (fp32) normals: 112 VGPRs -> one 16-wave workgroup per CU (4 waves/SIMD)
 
+// Launch geometry: every index is 32-bit (the host splits a batch whose planes would exceed 2^32 bytes).
+// The output of one image is Hrows rows of wq_out quads (4 pixels); with a pitched output (Wout > W) a row is
+// an image row, otherwise the whole plane is one row.  A thread walks (image, row, quad) by a constant step.
+struct PolarGeo {
+    int B, Hrows, wq_in, wq_out;
+    int drow, dcq;                 // persistent-loop step (grid * block quads) as rows + quads
+    unsigned P, Pout;              // pixels per input / output plane
+    int flags;
+};
+
 template <int MODE, bool NORMALS, bool PRECISE>
 __global__ __launch_bounds__(NORMALS ? (PRECISE ? kThreadsN : kThreadsF) : kThreads) void polar_kernel(
     const uint8_t* __restrict__ pol, const uint8_t* __restrict__ mask, float* __restrict__ xolp,
     float* __restrict__ xolp_std, float* __restrict__ normals, int* __restrict__ ints,
-    const char* __restrict__ blob, long P, long Pout, int wq_in, int wq_out, long quads_per_img, long total_quads) {
+    const char* __restrict__ blob, const PolarGeo g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
     const float* lut = reinterpret_cast<const float*>(blob + h->off_lut);
     constexpr int NTH = NORMALS ? (PRECISE ? kThreadsN : kThreadsF) : kThreads;
     Tabs tabs;
     if (NORMALS) stage_tables<PRECISE>(blob, smem, NTH, tabs);
-    const float kMean = static_cast<float>(0.08693199701957657);
-    const float kStd = static_cast<float>(0.44430732785457433);
+    const bool ieee = (g.flags & PD_POLAR_IEEE_RHO) != 0;
 
-    for (long q = blockIdx.x * (long)NTH + threadIdx.x; q < total_quads; q += (long)gridDim.x * NTH) {
-        const long b = q / quads_per_img;
-        const long ro = q - b * quads_per_img;          // quad index inside the (pitched) output plane
-        const long row = ro / wq_out;
-        const int cq = (int)(ro - row * wq_out);
-        const long po = ro * 4;                          // first output pixel of the quad
-        if (cq >= wq_in) {                               // right padding columns of a pitched output: zeros
+    const unsigned q0 = blockIdx.x * (unsigned)NTH + threadIdx.x;
+    unsigned row = q0 / (unsigned)g.wq_out;
+    int cq = (int)(q0 - row * (unsigned)g.wq_out);
+    int b = (int)(row / (unsigned)g.Hrows);
+    row -= (unsigned)b * (unsigned)g.Hrows;
+    const unsigned in_row = 4u * g.wq_in, out_row = 4u * g.wq_out;
+
+    while (b < g.B) {
+        const unsigned po = row * out_row + 4u * cq;     // first output pixel of the quad inside its plane
+        if (cq >= g.wq_in) {                             // right padding columns of a pitched output: zeros
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xolp) { *reinterpret_cast<float4*>(xolp + (b * 2) * Pout + po) = z; *reinterpret_cast<float4*>(xolp + (b * 2 + 1) * Pout + po) = z; }
-            if (xolp_std) { *reinterpret_cast<float4*>(xolp_std + (b * 2) * Pout + po) = z; *reinterpret_cast<float4*>(xolp_std + (b * 2 + 1) * Pout + po) = z; }
+            if (xolp) { *reinterpret_cast<float4*>(xolp + ((unsigned)b * 2u * g.Pout + po)) = z; *reinterpret_cast<float4*>(xolp + ((unsigned)b * 2u * g.Pout + g.Pout + po)) = z; }
+            if (xolp_std) { *reinterpret_cast<float4*>(xolp_std + ((unsigned)b * 2u * g.Pout + po)) = z; *reinterpret_cast<float4*>(xolp_std + ((unsigned)b * 2u * g.Pout + g.Pout + po)) = z; }
             if (NORMALS && normals)
-                for (int c = 0; c < 9; ++c) *reinterpret_cast<float4*>(normals + (b * 9 + c) * Pout + po) = z;
+                for (unsigned c = 0; c < 9; ++c) *reinterpret_cast<float4*>(normals + (((unsigned)b * 9u + c) * g.Pout + po)) = z;
             if (ints)
-                for (int c = 0; c < (NORMALS ? 5 : 2); ++c) *reinterpret_cast<int4*>(ints + (b * 5 + c) * Pout + po) = make_int4(0, 0, 0, 0);
-            continue;
-        }
-        const long p4 = (row * wq_in + cq) * 4;          // first input pixel of the quad inside its plane
-        const uint8_t* pb = pol + (b * 4) * P + p4;
-        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(pb);
-        const uint32_t w45 = *reinterpret_cast<const uint32_t*>(pb + P);
-        const uint32_t w90 = *reinterpret_cast<const uint32_t*>(pb + 2 * P);
-        const uint32_t w135 = *reinterpret_cast<const uint32_t*>(pb + 3 * P);
-        uint32_t wm = 0x01010101u;
-        if (MODE == PD_POLAR_STOKES && mask) wm = *reinterpret_cast<const uint32_t*>(mask + b * P + p4);
+                for (unsigned c = 0; c < (NORMALS ? 5u : 2u); ++c) *reinterpret_cast<int4*>(ints + (((unsigned)b * 5u + c) * g.Pout + po)) = make_int4(0, 0, 0, 0);
+        } else {
+            const unsigned p4 = (unsigned)b * 4u * g.P + row * in_row + 4u * cq;   // first input pixel (plane 0)
+            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(pol + p4);
+            const uint32_t w45 = *reinterpret_cast<const uint32_t*>(pol + (p4 + g.P));
+            const uint32_t w90 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P));
+            const uint32_t w135 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P));
+            uint32_t wm = 0x01010101u;
+            if (MODE == PD_POLAR_STOKES && mask) wm = *reinterpret_cast<const uint32_t*>(mask + ((unsigned)b * g.P + row * in_row + 4u * cq));
 
-        float o_rho[4], o_phi[4], o_n[9][4];
-        int o_i[5][4];
-        // With the normals the four pixels are processed strictly one after the other (scheduling barrier
-        // between them): interleaving four fp64 trig chains quadruples the live registers.
+            float o_rho[4], o_phi[4], o_n[9][4];
+            int o_i[5][4];
+            // With the normals the four pixels are processed in pairs (scheduling barrier between them):
+            // interleaving four fp64 trig chains quadruples the live registers.
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (NORMALS && (j & 1) == 0) __builtin_amdgcn_sched_barrier(0);   // pixels are interleaved in pairs
-            const int sh = 8 * j;
-            const bool on = ((wm >> sh) & 0xffu) != 0;
-            int i0 = (w0 >> sh) & 0xff, i45 = (w45 >> sh) & 0xff, i90 = (w90 >> sh) & 0xff, i135 = (w135 >> sh) & 0xff;
-            if (MODE == PD_POLAR_STOKES && !on) { i0 = i45 = i90 = i135 = 0; }  // images are masked first (:117-121)
-            Px p = xolp_pixel<MODE>(i0, i45, i90, i135, lut);
-            if (MODE == PD_POLAR_STOKES && !on) { p.rho = 0.f; p.phi = 0.f; }
-            o_rho[j] = p.rho;
-            o_phi[j] = p.phi;
-            o_i[0][j] = p.d1;
-            o_i[1][j] = p.d2;
-            if (NORMALS) {
-                int bi[3];
-                float v[9];
-                normals9<PRECISE>(p.rho, p.phi, tabs, v, bi);
-                o_i[2][j] = bi[0]; o_i[3][j] = bi[1]; o_i[4][j] = bi[2];
+            for (int j = 0; j < 4; ++j) {
+                if (NORMALS && (j & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+                const int sh = 8 * j;
+                const bool on = MODE != PD_POLAR_STOKES || ((wm >> sh) & 0xffu) != 0;
+                // v_cvt_f32_ubyteN: byte -> float in one instruction
+                float f0 = static_cast<float>((w0 >> sh) & 0xffu), f45 = static_cast<float>((w45 >> sh) & 0xffu);
+                float f90 = static_cast<float>((w90 >> sh) & 0xffu), f135 = static_cast<float>((w135 >> sh) & 0xffu);
+                Px p;
+                if (MODE == PD_POLAR_STOKES && !on) {   // images are masked first (:117-121); outputs are zero outside
+                    p.rho = 0.f; p.phi = 0.f; p.d1 = 0.f; p.d2 = 0.f;
+                } else {
+                    p = xolp_pixel<MODE>(f0, f45, f90, f135, lut, ieee);
+                }
+                o_rho[j] = p.rho;
+                o_phi[j] = p.phi;
+                o_i[0][j] = static_cast<int>(p.d1);
+                o_i[1][j] = static_cast<int>(p.d2);
+                if (NORMALS) {
+                    int bi[3];
+                    float v[9];
+                    normals9<PRECISE>(p.rho, p.phi, tabs, v, bi);
+                    o_i[2][j] = bi[0]; o_i[3][j] = bi[1]; o_i[4][j] = bi[2];
 #pragma unroll
-                for (int c = 0; c < 9; ++c) o_n[c][j] = (MODE == PD_POLAR_STOKES && !on) ? 0.f : v[c];
+                    for (int c = 0; c < 9; ++c) o_n[c][j] = on ? v[c] : 0.f;
+                }
+            }
+            if (xolp) {
+                float* o = xolp + ((unsigned)b * 2u * g.Pout + po);
+                *reinterpret_cast<float4*>(o) = make_float4(o_rho[0], o_rho[1], o_rho[2], o_rho[3]);
+                *reinterpret_cast<float4*>(o + g.Pout) = make_float4(o_phi[0], o_phi[1], o_phi[2], o_phi[3]);
+            }
+            if (xolp_std) {
+                float* o = xolp_std + ((unsigned)b * 2u * g.Pout + po);
+                *reinterpret_cast<float4*>(o) = make_float4(standardise(o_rho[0]), standardise(o_rho[1]),
+                                                            standardise(o_rho[2]), standardise(o_rho[3]));
+                *reinterpret_cast<float4*>(o + g.Pout) = make_float4(standardise(o_phi[0]), standardise(o_phi[1]),
+                                                                     standardise(o_phi[2]), standardise(o_phi[3]));
+            }
+            if (NORMALS && normals) {
+                float* o = normals + ((unsigned)b * 9u * g.Pout + po);
+#pragma unroll
+                for (unsigned c = 0; c < 9; ++c)
+                    *reinterpret_cast<float4*>(o + c * g.Pout) = make_float4(o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
+            }
+            if (ints) {
+                int* o = ints + ((unsigned)b * 5u * g.Pout + po);
+                const unsigned nch = NORMALS ? 5 : 2;
+#pragma unroll
+                for (unsigned c = 0; c < 5; ++c)
+                    if (c < nch) *reinterpret_cast<int4*>(o + c * g.Pout) = make_int4(o_i[c][0], o_i[c][1], o_i[c][2], o_i[c][3]);
             }
         }
-        if (xolp) {
-            float* o = xolp + (b * 2) * Pout + po;
-            *reinterpret_cast<float4*>(o) = make_float4(o_rho[0], o_rho[1], o_rho[2], o_rho[3]);
-            *reinterpret_cast<float4*>(o + Pout) = make_float4(o_phi[0], o_phi[1], o_phi[2], o_phi[3]);
-        }
-        if (xolp_std) {
-            float* o = xolp_std + (b * 2) * Pout + po;
-            *reinterpret_cast<float4*>(o) = make_float4((o_rho[0] - kMean) / kStd, (o_rho[1] - kMean) / kStd,
-                                                        (o_rho[2] - kMean) / kStd, (o_rho[3] - kMean) / kStd);
-            *reinterpret_cast<float4*>(o + Pout) = make_float4((o_phi[0] - kMean) / kStd, (o_phi[1] - kMean) / kStd,
-                                                            (o_phi[2] - kMean) / kStd, (o_phi[3] - kMean) / kStd);
-        }
-        if (NORMALS && normals) {
-            float* o = normals + (b * 9) * Pout + po;
-#pragma unroll
-            for (int c = 0; c < 9; ++c)
-                *reinterpret_cast<float4*>(o + c * Pout) = make_float4(o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
-        }
-        if (ints) {
-            int* o = ints + (b * 5) * Pout + po;
-            const int nch = NORMALS ? 5 : 2;
-#pragma unroll
-            for (int c = 0; c < 5; ++c)
-                if (c < nch) *reinterpret_cast<int4*>(o + c * Pout) = make_int4(o_i[c][0], o_i[c][1], o_i[c][2], o_i[c][3]);
+        // next quad of this thread
+        cq += g.dcq;
+        row += (unsigned)g.drow;
+        if (cq >= g.wq_out) { cq -= g.wq_out; ++row; }
+        if (row >= (unsigned)g.Hrows) {
+            if (row < 2u * (unsigned)g.Hrows) { row -= (unsigned)g.Hrows; ++b; }
+            else { const unsigned k = row / (unsigned)g.Hrows; row -= k * (unsigned)g.Hrows; b += (int)k; }
         }
     }
 }
@@ -607,36 +681,51 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
                "pd_polar_fwd: pointers must be 16-byte aligned");
     PD_REQUIRE(xolp || xolp_std || normals || ints, "pd_polar_fwd: no output requested");
     const long Pout = (long)H * Wout;
-    const int wq_in = Wout == W ? (int)(P / 4) : W / 4, wq_out = Wout == W ? (int)(P / 4) : Wout / 4;
-    const long qpi = Pout / 4, total = qpi * B;
+    const bool pitched = Wout != W;
     const bool need_normals = normals != nullptr || ints != nullptr;
     const bool precise = (flags & PD_POLAR_FAST_NORMALS) == 0;
-    // LDS image size is fixed by the table node counts (72,016 bytes for the default 1000/625/375 nodes)
+    // LDS image size is fixed by the table node counts (90,072 bytes for the default 1000/625/375 nodes)
     const size_t lds = need_normals ? lds_from_blob_bytes(tables_bytes) : 0;
     PD_REQUIRE(!need_normals || (lds > 0 && lds <= 160 * 1024), "pd_polar_fwd: tables blob has an unexpected size");
     const int nth = need_normals ? (precise ? kThreadsN : kThreadsF) : kThreads;
-    long blocks = (total + nth - 1) / nth;
-    // with normals: persistent, one workgroup per CU (the 90 KB table image is staged once per CU);
-    // XOLP only: no tables to amortise -> one quad per thread, hardware-scheduled (measured 1.4x faster)
-    const long cap = need_normals ? 256L : (1L << 30);
-    if (blocks > cap) blocks = cap;
+    // 32-bit addressing inside the kernel: at most 2^30 elements per output tensor and 2^31 quads per launch
+    PD_REQUIRE(9 * Pout < (1L << 30), "pd_polar_fwd: image too large (%ld output pixels)", Pout);
+    const long max_b = (1L << 30) / (9 * Pout);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    auto go = [&](auto kern) -> int {
-        int rc = set_lds_limit(kern, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nth), lds, st,
-                           static_cast<const uint8_t*>(pol), static_cast<const uint8_t*>(mask),
-                           static_cast<float*>(xolp), static_cast<float*>(xolp_std), static_cast<float*>(normals),
-                           static_cast<int*>(ints), static_cast<const char*>(tables), P, Pout, wq_in, wq_out, qpi, total);
-        return PD_OK;
-    };
-    int rc;
-    if (mode == PD_POLAR_LS) {
-        if (!need_normals) rc = go(polar_kernel<PD_POLAR_LS, false, false>);
-        else rc = precise ? go(polar_kernel<PD_POLAR_LS, true, true>) : go(polar_kernel<PD_POLAR_LS, true, false>);
-    } else {
-        if (!need_normals) rc = go(polar_kernel<PD_POLAR_STOKES, false, false>);
-        else rc = precise ? go(polar_kernel<PD_POLAR_STOKES, true, true>) : go(polar_kernel<PD_POLAR_STOKES, true, false>);
+    int rc = PD_OK;
+    for (long b0 = 0; b0 < B && rc == PD_OK; b0 += max_b) {
+        const int nb = (int)std::min<long>(max_b, B - b0);
+        PolarGeo g;
+        g.B = nb; g.Hrows = pitched ? H : 1;
+        g.wq_in = pitched ? W / 4 : (int)(P / 4); g.wq_out = pitched ? Wout / 4 : (int)(P / 4);
+        g.P = (unsigned)P; g.Pout = (unsigned)Pout; g.flags = flags;
+        const long total = (long)nb * (Pout / 4);
+        long blocks = (total + nth - 1) / nth;
+        // with normals: persistent, one workgroup per CU (the 90 KB table image is staged once per CU);
+        // XOLP only: no tables to amortise -> one quad per thread, hardware-scheduled (measured 1.4x faster)
+        if (need_normals && blocks > 256) blocks = 256;
+        const long step = blocks * nth;
+        g.drow = (int)(step / g.wq_out); g.dcq = (int)(step % g.wq_out);
+        const uint8_t* pol_b = static_cast<const uint8_t*>(pol) + b0 * 4 * P;
+        const uint8_t* mask_b = mask ? static_cast<const uint8_t*>(mask) + b0 * P : nullptr;
+        float* xolp_b = xolp ? static_cast<float*>(xolp) + b0 * 2 * Pout : nullptr;
+        float* std_b = xolp_std ? static_cast<float*>(xolp_std) + b0 * 2 * Pout : nullptr;
+        float* nrm_b = normals ? static_cast<float*>(normals) + b0 * 9 * Pout : nullptr;
+        int* ints_b = ints ? static_cast<int*>(ints) + b0 * 5 * Pout : nullptr;
+        auto go = [&](auto kern) -> int {
+            int r = set_lds_limit(kern, lds);
+            if (r) return r;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nth), lds, st, pol_b, mask_b, xolp_b, std_b, nrm_b,
+                               ints_b, static_cast<const char*>(tables), g);
+            return PD_OK;
+        };
+        if (mode == PD_POLAR_LS) {
+            if (!need_normals) rc = go(polar_kernel<PD_POLAR_LS, false, false>);
+            else rc = precise ? go(polar_kernel<PD_POLAR_LS, true, true>) : go(polar_kernel<PD_POLAR_LS, true, false>);
+        } else {
+            if (!need_normals) rc = go(polar_kernel<PD_POLAR_STOKES, false, false>);
+            else rc = precise ? go(polar_kernel<PD_POLAR_STOKES, true, true>) : go(polar_kernel<PD_POLAR_STOKES, true, false>);
+        }
     }
     if (rc) return rc;
     return pd::check_launch("pd_polar_fwd");

@@ -158,3 +158,28 @@ def test_pitched_output_zero_pads_right_columns():
         g = got[k].cpu()
         assert g.shape[-1] == 64
         assert torch.equal(g[..., :36], ref[k]) and g[..., 36:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("mode", [pdpolar.MODE_LS, pdpolar.MODE_STOKES])
+def test_rounding_test_path_equals_ieee_sequence_on_all_2_32_inputs(mode):
+    """K1's DoLP uses Newton-refined hardware seeds plus a rounding test (Ziv) and falls back to the reference's
+    literal fp64 sqrt/div sequence near fp32 rounding midpoints.  This sweeps *every* uint8 quadruple
+    (256 launches of 2^24 pixels) and requires bit-equality (NaN/inf patterns included) with
+    PD_POLAR_IEEE_RHO, the path that runs the literal sequence on every pixel -- which the other tests pin to
+    the oracle.  The standardised output (Markstein division by a constant) is checked against IEEE division."""
+    idx = torch.arange(1 << 24, dtype=torch.int32, device="cuda")
+    planes = torch.empty((1, 4, 4096, 4096), dtype=torch.uint8, device="cuda")
+    planes[0, 1] = ((idx >> 16) & 255).to(torch.uint8).view(4096, 4096)
+    planes[0, 2] = ((idx >> 8) & 255).to(torch.uint8).view(4096, 4096)
+    planes[0, 3] = (idx & 255).to(torch.uint8).view(4096, 4096)
+    mean = torch.tensor(0.08693199701957657, dtype=torch.float32, device="cuda")
+    std = torch.tensor(0.44430732785457433, dtype=torch.float32, device="cuda")
+    fast, ieee = {}, {}
+    for i0 in range(256):
+        planes[0, 0].fill_(i0)
+        fast = pdpolar.polar_forward(planes, mode=mode, want=("xolp", "xolp_std"), out=fast)
+        ieee = pdpolar.polar_forward(planes, mode=mode, want=("xolp",), out=ieee, ieee_rho=True)
+        assert torch.equal(fast["xolp"].view(torch.int32), ieee["xolp"].view(torch.int32)), f"I0={i0}"
+        ref_std = (ieee["xolp"] - mean) / std
+        finite = torch.isfinite(ref_std)
+        assert torch.equal(fast["xolp_std"][finite], ref_std[finite]), f"standardise, I0={i0}"
