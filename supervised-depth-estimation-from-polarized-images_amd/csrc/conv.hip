@@ -20,6 +20,7 @@
 //
 // The weight-gradient kernel (contraction over pixels, "TN" GEMM) lives below in the same file.
 #include "pd_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -260,36 +261,55 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Straight-line code: the activation is a template argument, the row step of every store is a scalar offset
+    // and out-of-range elements are dropped by the bounds check of the buffer store (offset OOB), so the 32 stores
+    // of a wave issue back to back (with per-element branches the compiler drained vmcnt to zero after each one).
     const int col_l = lane & 31;
     const int rbase = 4 * (lane >> 5);
+    {
+        const long rows_left = a.M - m0;
+        const int rows = rows_left < BM ? (int)rows_left : BM;
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)rows * a.ldy * 4));
+        const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(a.bias ? a.bias : a.w, a.bias ? (unsigned)a.Co * 4u : 0u);
+        auto body = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WN + 32 * j + col_l;
-        const bool cv = col < a.Co;
-        const float bv = (a.bias && cv) ? a.bias[col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WN + 32 * j + col_l;
+                const bool cv = col < a.Co;
+                const float bv = a.bias ? buf_ld1(rb_, cv ? (unsigned)col * 4u : OOB) : 0.f;
+                float s1 = 0.f, s2 = 0.f;
+                const int row_l = wm * WM + rbase;                      // this lane's first row in the tile
+                const unsigned off_l = (unsigned)(row_l * (int)a.ldy + col) * 4u;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+                for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + rbase;
-                float v = acc[i][j][r] + bv;
-                if (m < a.M && cv) {
-                    s1 += v;
-                    s2 += v * v;
-                    if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (a.act == ACT_ELU) v = v > 0.f ? v : expm1f(v);
-                    else if (a.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-                    a.y[m * a.ldy + col] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = 32 * i + (r & 3) + 8 * (r >> 2);   // compile-time row step: scalar offset
+                        const bool ok = cv & (row_l < rows - rr);
+                        float v = acc[i][j][r] + bv;
+                        const float vs = ok ? v : 0.f;
+                        s1 += vs;
+                        s2 += vs * vs;
+                        if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (ACT == ACT_ELU) v = v > 0.f ? v : expm1f(v);
+                        else if (ACT == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ok ? off_l : OOB,
+                                                              rr * (int)a.ldy * 4, 0);
+                    }
+                }
+                if (a.stats) {
+                    s1 += __shfl_xor(s1, 32);
+                    s2 += __shfl_xor(s2, 32);
+                    if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
                 }
             }
-        }
-        if (a.stats) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
-        }
+        };
+        if (a.act == ACT_NONE) body(std::integral_constant<int, ACT_NONE>{});
+        else if (a.act == ACT_RELU) body(std::integral_constant<int, ACT_RELU>{});
+        else if (a.act == ACT_ELU) body(std::integral_constant<int, ACT_ELU>{});
+        else body(std::integral_constant<int, ACT_SIGMOID>{});
     }
     if (a.stats) {
         __syncthreads();
@@ -351,7 +371,7 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, void* y
     PD_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "pd_conv2d: bad filter geometry");
     PD_REQUIRE(mode >= 0 && mode <= 2 && act >= 0 && act <= 3, "pd_conv2d: bad mode/act");
     PD_REQUIRE(mode != MODE_REFLECT || (pad < H && pad < W), "pd_conv2d: reflect pad must be < input size");
-    PD_REQUIRE(ldy >= Co, "pd_conv2d: ldy < Cout");
+    PD_REQUIRE(ldy >= Co && ldy < (1L << 22), "pd_conv2d: bad output row stride %ld (Cout=%d)", ldy, Co);
     int sshift = 0;
     while ((1 << sshift) < stride) ++sshift;
     if (mode == MODE_TRANSPOSED) {

@@ -31,7 +31,10 @@ def timeit(fn, iters=5):
     return e0.elapsed_time(e1) / iters
 
 
+ONLY = os.environ.get("ONLY")        # substring filter on the layer name
 for name, C, H, W, Co, k, s, p, mode in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
     x = torch.randn(B, C, H, W, device="cuda")
     if C >= 16:
         x = x.contiguous(memory_format=torch.channels_last)
