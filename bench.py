@@ -168,7 +168,7 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     PF.USE_WGRAD_STREAM = overlap
     by_kernel = {}
-    for name, flops, e0, e1 in prof:
+    for name, flops, e0, e1, _shape in prof:
         k = by_kernel.setdefault(name, [0.0, 0.0, 0])
         k[0] += flops; k[1] += e0.elapsed_time(e1) * 1e-3; k[2] += 1
     dom = max(by_kernel.items(), key=lambda kv: kv[1][1])

@@ -245,6 +245,23 @@ int pd_depth_metrics(const void* gt, const void* pred, const void* mask, int mas
 int pd_softmax_rows_fwd(void* x, long R, long L, float scale, void* stream);
 int pd_softmax_rows_bwd(const void* p, void* dp, long R, long L, float scale, void* stream);
 
+/* ---- disparity heads: sigmoid(Conv3x3(x)) with one output channel
+ * (manydepth/networks/depth_decoder.py:52-53,69-71; layers.py:364-380 Conv3x3 = ReflectionPad2d(1) + Conv2d(C,1,3)).
+ * Direct memory-bound kernels instead of a 32-wide MFMA tile with one useful column.
+ *   x  [N,H,W,C] NHWC fp32, C in {16,32,64,128};  w [3][3][C] (= channels_last storage of the [1,C,3,3] weight);
+ *   y / dy [N,H,W] (= [N,1,H,W]);  bias [1] or NULL.
+ * pd_disphead_fwd:        y = sigmoid(bias + conv)
+ * pd_disphead_bwd_data:   dx [N,H,W,C] = gradient w.r.t. x given dy (gradient w.r.t. y) and y; the fold of the
+ *                         reflection padding is built in
+ * pd_disphead_bwd_weight: dw [3][3][C] (+)= , dbias [1] (+)= (NULL to skip); workspace >= pd_disphead_workspace(C)
+ *                         bytes, 16-byte aligned; deterministic two-stage summation */
+int pd_disphead_fwd(const void* x, const void* w, const void* bias, void* y, int N, int H, int W, int C, void* stream);
+int pd_disphead_bwd_data(const void* dy, const void* y, const void* w, void* dx, int N, int H, int W, int C,
+                         void* stream);
+size_t pd_disphead_workspace(int C);
+int pd_disphead_bwd_weight(const void* dy, const void* y, const void* x, void* dw, void* dbias, void* workspace,
+                           size_t ws_bytes, int N, int H, int W, int C, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@
 //
 // The weight-gradient kernel (contraction over pixels, "TN" GEMM) lives below in the same file.
 #include "pd_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -146,24 +147,40 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     };
 
     // ---- per-thread gather state
+    // Linear addressing (zero padding, or transposed with stride 1): the element offset of tap (kh,kw,c) for a row
+    // is rowbase + tapoff with tapoff = +-(kh*sH + kw*sW) + c kept incrementally -- no multiplications in the loop.
+    // Then rb[] holds rowbase and rows beyond M carry a poisoned rh that fails every bounds test.
+    const bool lin = VEC && (MODE == MODE_ZERO || (MODE == MODE_TRANSPOSED && a.sshift == 0));
+    const int dW = MODE == MODE_TRANSPOSED ? -(int)a.sW : (int)a.sW;
+    const int dH = MODE == MODE_TRANSPOSED ? -(int)a.sH : (int)a.sH;
     int rb[VEC ? A_VEC_ITERS : 1], rh[VEC ? A_VEC_ITERS : 1], rwc[VEC ? A_VEC_ITERS : 1];
     if (VEC) {
 #pragma unroll
-        for (int i = 0; i < A_VEC_ITERS; ++i) row_coords(m0 + (tid >> 3) + 32 * i, rb[i], rh[i], rwc[i]);
+        for (int i = 0; i < A_VEC_ITERS; ++i) {
+            row_coords(m0 + (tid >> 3) + 32 * i, rb[i], rh[i], rwc[i]);
+            if (lin) {
+                if (rb[i] < 0) { rb[i] = 0; rh[i] = -(1 << 28); }
+                else rb[i] += rh[i] * (int)a.sH + rwc[i] * (int)a.sW;
+            }
+        }
     } else {
         for (int r = tid; r < BM; r += NT) row_coords(m0 + r, rowinfo[r][0], rowinfo[r][1], rowinfo[r][2]);
         __syncthreads();
     }
     // tap of this thread's k column, advanced by BK per chunk (no divisions in the loop)
     int tk = VEC ? 4 * (tid & 7) : (tid & 31);
-    int tkh, tkw, tc;
+    int tkh, tkw, tc, tapoff;
     {
         const int tap = tk / a.C;
         tc = tk - tap * a.C; tkh = tap / a.KW; tkw = tap - tkh * a.KW;
+        tapoff = tkh * dH + tkw * dW + tc;
     }
     auto advance_tap = [&]() {
-        tk += BK; tc += BK;
-        while (tc >= a.C) { tc -= a.C; if (++tkw == a.KW) { tkw = 0; ++tkh; } }
+        tk += BK; tc += BK; tapoff += BK;
+        while (tc >= a.C) {
+            tc -= a.C; tapoff += dW - a.C;
+            if (++tkw == a.KW) { tkw = 0; ++tkh; tapoff += dH - a.KW * dW; }
+        }
     };
 
     const int nchunks = (a.K + BK - 1) / BK;
@@ -175,10 +192,17 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
         if (VEC) {
 #pragma unroll
             for (int i = 0; i < A_VEC_ITERS; ++i) {
-                int ih, iw;
-                const bool ok = tap_in<MODE>(rh[i], rwc[i], tkh, tkw, a.H, a.W, a.sshift, ih, iw) & kv & (rb[i] >= 0);
-                const unsigned off = (unsigned)(rb[i] + ih * (int)a.sH + iw * (int)a.sW + tc) * 4u;
-                pa[i] = buf_ld4(rx, ok ? off : OOB);
+                if (lin) {
+                    const int ih = MODE == MODE_TRANSPOSED ? rh[i] - tkh : rh[i] + tkh;
+                    const int iw = MODE == MODE_TRANSPOSED ? rwc[i] - tkw : rwc[i] + tkw;
+                    const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & kv;
+                    pa[i] = buf_ld4(rx, ok ? (unsigned)(rb[i] + tapoff) * 4u : OOB);
+                } else {
+                    int ih, iw;
+                    const bool ok = tap_in<MODE>(rh[i], rwc[i], tkh, tkw, a.H, a.W, a.sshift, ih, iw) & kv & (rb[i] >= 0);
+                    const unsigned off = (unsigned)(rb[i] + ih * (int)a.sH + iw * (int)a.sW + tc) * 4u;
+                    pa[i] = buf_ld4(rx, ok ? off : OOB);
+                }
             }
 #pragma unroll
             for (int i = 0; i < B_VEC_ITERS; ++i) {
@@ -354,6 +378,8 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
 
 extern "C" int pd_conv2d_tile_m(long M, int Co) {
     if (Co <= 32) return 128;   // 128x32 tile: four waves of one 32x32 MFMA tile each
+    static const int forced = getenv("PD_CONV_BM") ? atoi(getenv("PD_CONV_BM")) : 0;   // tuning aid: 64 or 128
+    if (forced == 64 || forced == 128) return forced;
     return M >= 64 * 1024 ? 128 : 64;
 }
 
@@ -501,10 +527,32 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         roh[i] = rem / a.Wo; row_[i] = rem - roh[i] * a.Wo;
         rb[i] = n * (int)a.sN;
     }
+    // Zero-padding mode, 16-byte path: input coordinates and the element offset of this thread's tap are carried
+    // incrementally from chunk to chunk (additions only; the general form below multiplies per row and chunk).
+    constexpr bool INC = VEC && MODE == MODE_ZERO;
+    int xih[INC ? XR : 1], xiw[INC ? XR : 1], xoff[INC ? XR : 1];
+    const int c_w = WG_MC * a.stride, c_wo = c_w * (int)a.sW;
+    const int c_row = a.Wo * a.stride, c_rowo = a.stride * (int)a.sH - c_row * (int)a.sW;
+    const int c_img = a.Ho * a.stride, c_imgo = (int)a.sN - c_img * (int)a.sH;
+    if (INC) {
+        for (int i = 0; i < XR; ++i) {
+            xih[i] = roh[i] * a.stride - a.pad + vkh;
+            xiw[i] = row_[i] * a.stride - a.pad + vkw;
+            xoff[i] = rb[i] + xih[i] * (int)a.sH + xiw[i] * (int)a.sW + vc;
+        }
+    }
     auto advance = [&](int i) {
         rloc[i] += WG_MC;
         row_[i] += WG_MC;
-        while (row_[i] >= a.Wo) { row_[i] -= a.Wo; if (++roh[i] == a.Ho) { roh[i] = 0; rb[i] += (int)a.sN; } }
+        if (INC) { xiw[i] += c_w; xoff[i] += c_wo; }
+        while (row_[i] >= a.Wo) {
+            row_[i] -= a.Wo;
+            if (INC) { xiw[i] -= c_row; xih[i] += a.stride; xoff[i] += c_rowo; }
+            if (++roh[i] == a.Ho) {
+                roh[i] = 0; rb[i] += (int)a.sN;
+                if (INC) { xih[i] -= c_img; xoff[i] += c_imgo; }
+            }
+        }
     };
 
     float4 pd[DY_ITERS], px[VEC ? 4 : 1];
@@ -531,11 +579,16 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         if (VEC) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int ih, iw;
-                const bool ok = tap_in<MODE>(roh[i] * a.stride - a.pad, row_[i] * a.stride - a.pad, vkh, vkw, a.H, a.W, 0, ih, iw) &
-                                vkv & (rloc[i] < nrows);
-                const unsigned off = (unsigned)(rb[i] + ih * (int)a.sH + iw * (int)a.sW + vc) * 4u;
-                px[i] = buf_ld4(rx, ok ? off : OOB);
+                if (INC) {
+                    const bool ok = ((unsigned)xih[i] < (unsigned)a.H) & ((unsigned)xiw[i] < (unsigned)a.W) & vkv & (rloc[i] < nrows);
+                    px[i] = buf_ld4(rx, ok ? (unsigned)xoff[i] * 4u : OOB);
+                } else {
+                    int ih, iw;
+                    const bool ok = tap_in<MODE>(roh[i] * a.stride - a.pad, row_[i] * a.stride - a.pad, vkh, vkw, a.H, a.W, 0, ih, iw) &
+                                    vkv & (rloc[i] < nrows);
+                    const unsigned off = (unsigned)(rb[i] + ih * (int)a.sH + iw * (int)a.sW + vc) * 4u;
+                    px[i] = buf_ld4(rx, ok ? off : OOB);
+                }
                 advance(i);
             }
         } else {

@@ -1,0 +1,273 @@
+// Disparity heads of the depth decoder: sigmoid(Conv3x3(x)) with ONE output channel
+// (depth_decoder.py:52-53,69-71: Conv3x3 = ReflectionPad2d(1) + Conv2d(C, 1, 3); layers.py:364-380).
+//
+// As an implicit GEMM these layers waste 31/32 of a 32-wide MFMA tile (2-3 TFLOP/s, 3.4 ms of the
+// train step for 0.02 % of its flops).  They are memory-bound reductions over the channel vector, so they
+// get direct kernels: C/4 lanes share a pixel (one float4 of channels each), a wave covers 64/(C/4)
+// consecutive pixels, every tap is a fully coalesced read of the NHWC tensor and the eight re-reads of a
+// pixel by its neighbours hit the cache.
+//   forward          y  = sigmoid(b + sum_t x[refl(p + t - 1)] . w[t])
+//   data gradient    dx[p] = sum_{q in Q(p)} sum_t dz[q - t + 1] w[t],  dz = dy * y * (1 - y),
+//                    Q(p) = virtual (padded-grid) positions that reflect onto p: p itself, -1 if p == 1,
+//                    H if p == H-2 (per axis) -- the fold of the reflection padding is built in
+//   weight gradient  dw[t] = sum_p dz[p] x[refl(p + t - 1)],  db = sum_p dz[p]   (deterministic two-stage sum)
+#include "pd_common.h"
+
+namespace {
+
+__device__ __forceinline__ int refl(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
+    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc);
+    return fmaf(a.w, b.w, acc);
+}
+
+struct Pix {
+    int n, h, w;
+    bool valid;
+};
+__device__ __forceinline__ Pix decode(int p, int npix, int H, int W) {
+    Pix r;
+    r.valid = p < npix;
+    const int pc = r.valid ? p : npix - 1;
+    const int hw = H * W;
+    r.n = pc / hw;
+    const int rem = pc - r.n * hw;
+    r.h = rem / W;
+    r.w = rem - r.h * W;
+    return r;
+}
+
+template <int L>   // lanes per pixel, C = 4 L
+__global__ __launch_bounds__(256) void disphead_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int npix, int H, int W) {
+    constexpr int C = 4 * L, PPW = 64 / L;
+    const int lane = threadIdx.x & 63, c4 = lane % L, pl = lane / L;
+    float4 wr[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t] = ld4(w + t * C + 4 * c4);
+    const float b = bias ? bias[0] : 0.f;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int p0 = wave * PPW; p0 < npix; p0 += nwaves * PPW) {
+        const int p = p0 + pl;
+        const Pix q = decode(p, npix, H, W);
+        const float* xn = x + (long)q.n * H * W * C + 4 * c4;
+        float acc = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = refl(q.h + kh - 1, H);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = refl(q.w + kw - 1, W);
+                acc = dot4(ld4(xn + ((long)hh * W + ww) * C), wr[kh * 3 + kw], acc);
+            }
+        }
+#pragma unroll
+        for (int m = L / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+        if (c4 == 0 && q.valid) y[p] = 1.f / (1.f + expf(-(acc + b)));
+    }
+}
+
+// dz at (n, h, w) or 0 outside the image
+__device__ __forceinline__ float dz_at(const float* __restrict__ dy, const float* __restrict__ y, int n, int h, int w,
+                                       int H, int W) {
+    if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) return 0.f;
+    const long i = ((long)n * H + h) * W + w;
+    const float s = y[i];
+    return dy[i] * s * (1.f - s);
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void disphead_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                const float* __restrict__ w, float* __restrict__ dx,
+                                                                int npix, int H, int W) {
+    constexpr int C = 4 * L, PPW = 64 / L;
+    const int lane = threadIdx.x & 63, c4 = lane % L, pl = lane / L;
+    float4 wr[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t] = ld4(w + t * C + 4 * c4);
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int p0 = wave * PPW; p0 < npix; p0 += nwaves * PPW) {
+        const int p = p0 + pl;
+        const Pix q = decode(p, npix, H, W);
+        float g[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) g[t] = 0.f;
+        // virtual rows / columns whose reflection is (h, w): the pixel itself plus, next to a border, the padded line
+        const int qh[3] = {q.h, -1, H}, qw[3] = {q.w, -1, W};
+        const bool uh[3] = {true, q.h == 1, q.h == H - 2}, uw[3] = {true, q.w == 1, q.w == W - 2};
+        for (int a = 0; a < 3; ++a) {
+            if (!uh[a]) continue;
+            for (int bq = 0; bq < 3; ++bq) {
+                if (!uw[bq]) continue;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        g[kh * 3 + kw] += dz_at(dy, y, q.n, qh[a] - kh + 1, qw[bq] - kw + 1, H, W);
+            }
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            o.x = fmaf(g[t], wr[t].x, o.x); o.y = fmaf(g[t], wr[t].y, o.y);
+            o.z = fmaf(g[t], wr[t].z, o.z); o.w = fmaf(g[t], wr[t].w, o.w);
+        }
+        if (q.valid) *reinterpret_cast<float4*>(dx + (long)p * C + 4 * c4) = o;
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void disphead_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                  const float* __restrict__ x, float* __restrict__ part,
+                                                                  float* __restrict__ bpart, int npix, int H, int W) {
+    constexpr int C = 4 * L, PPW = 64 / L;
+    __shared__ float4 red[4][9][L];
+    __shared__ float bred[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c4 = lane % L, pl = lane / L;
+    float4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bsum = 0.f;
+    const int wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    for (int p0 = wave * PPW; p0 < npix; p0 += nwaves * PPW) {
+        const int p = p0 + pl;
+        const Pix q = decode(p, npix, H, W);
+        float g = 0.f;
+        if (q.valid) { const float s = y[p]; g = dy[p] * s * (1.f - s); }
+        bsum += g;
+        const float* xn = x + (long)q.n * H * W * C + 4 * c4;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = refl(q.h + kh - 1, H);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = refl(q.w + kw - 1, W);
+                const float4 v = ld4(xn + ((long)hh * W + ww) * C);
+                float4& a = acc[kh * 3 + kw];
+                a.x = fmaf(g, v.x, a.x); a.y = fmaf(g, v.y, a.y); a.z = fmaf(g, v.z, a.z); a.w = fmaf(g, v.w, a.w);
+            }
+        }
+    }
+    // pixels of the wave (lanes with equal c4), then the four waves, in a fixed order
+#pragma unroll
+    for (int m = L; m < 64; m <<= 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            acc[t].x += __shfl_xor(acc[t].x, m); acc[t].y += __shfl_xor(acc[t].y, m);
+            acc[t].z += __shfl_xor(acc[t].z, m); acc[t].w += __shfl_xor(acc[t].w, m);
+        }
+        bsum += __shfl_xor(bsum, m);
+    }
+    if (pl == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[wv][t][c4] = acc[t];
+        if (c4 == 0) bred[wv] = bsum;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * L; i += 256) {
+        const int t = i / L, c = i - t * L;
+        float4 s = red[0][t][c];
+        for (int k = 1; k < 4; ++k) { s.x += red[k][t][c].x; s.y += red[k][t][c].y; s.z += red[k][t][c].z; s.w += red[k][t][c].w; }
+        *reinterpret_cast<float4*>(part + (long)blockIdx.x * 9 * C + t * C + 4 * c) = s;
+    }
+    if (threadIdx.x == 0) bpart[blockIdx.x] = (bred[0] + bred[1]) + (bred[2] + bred[3]);
+}
+
+// out[i] (+)= sum_s part[s][i], fixed order
+__global__ __launch_bounds__(256) void disphead_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S,
+                                                              int n, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < S; s += 4) {
+        a0 += part[(long)s * n + i]; a1 += part[(long)(s + 1) * n + i];
+        a2 += part[(long)(s + 2) * n + i]; a3 += part[(long)(s + 3) * n + i];
+    }
+    for (; s < S; ++s) a0 += part[(long)s * n + i];
+    const float v = (a0 + a1) + (a2 + a3);
+    out[i] = accumulate ? out[i] + v : v;
+}
+
+constexpr int kWgradBlocks = 1024;
+
+int check_dims(const char* what, int N, int H, int W, int C) {
+    if (!(N >= 0 && H >= 2 && W >= 2)) return pd::fail(PD_EINVAL, "%s: bad shape N=%d H=%d W=%d (reflection needs H, W >= 2)", what, N, H, W);
+    if (!(C == 16 || C == 32 || C == 64 || C == 128)) return pd::fail(PD_EINVAL, "%s: C=%d not in {16,32,64,128}", what, C);
+    if ((long)N * H * W >= (1L << 31) - 64 * 4096) return pd::fail(PD_EINVAL, "%s: too many pixels for 32-bit indexing", what);
+    return PD_OK;
+}
+
+inline unsigned grid_for(long npix, int C) {
+    const int ppw = 64 / (C / 4);
+    long blocks = (npix + 4L * ppw - 1) / (4L * ppw);
+    return (unsigned)(blocks > 16384 ? 16384 : blocks);
+}
+
+}  // namespace
+
+#define PD_DISPATCH_L(C, CALL)                 \
+    switch (C) {                               \
+        case 16: { constexpr int L = 4; CALL; } break;   \
+        case 32: { constexpr int L = 8; CALL; } break;   \
+        case 64: { constexpr int L = 16; CALL; } break;  \
+        default: { constexpr int L = 32; CALL; } break;  \
+    }
+
+extern "C" int pd_disphead_fwd(const void* x, const void* w, const void* bias, void* y, int N, int H, int W, int C,
+                               void* stream) {
+    int rc = check_dims("pd_disphead_fwd", N, H, W, C);
+    if (rc) return rc;
+    if (N == 0) return PD_OK;
+    PD_REQUIRE(x && w && y, "pd_disphead_fwd: null tensor");
+    PD_REQUIRE(pd::aligned16(x) && pd::aligned16(w), "pd_disphead_fwd: x and w must be 16-byte aligned");
+    const int npix = N * H * W;
+    PD_DISPATCH_L(C, hipLaunchKernelGGL(disphead_fwd_kernel<L>, dim3(grid_for(npix, C)), dim3(256), 0, (hipStream_t)stream,
+                                        (const float*)x, (const float*)w, (const float*)bias, (float*)y, npix, H, W));
+    return pd::check_launch("pd_disphead_fwd");
+}
+
+extern "C" int pd_disphead_bwd_data(const void* dy, const void* y, const void* w, void* dx, int N, int H, int W, int C,
+                                    void* stream) {
+    int rc = check_dims("pd_disphead_bwd_data", N, H, W, C);
+    if (rc) return rc;
+    if (N == 0) return PD_OK;
+    PD_REQUIRE(dy && y && w && dx, "pd_disphead_bwd_data: null tensor");
+    PD_REQUIRE(pd::aligned16(dx) && pd::aligned16(w), "pd_disphead_bwd_data: dx and w must be 16-byte aligned");
+    const int npix = N * H * W;
+    PD_DISPATCH_L(C, hipLaunchKernelGGL(disphead_bwd_data_kernel<L>, dim3(grid_for(npix, C)), dim3(256), 0,
+                                        (hipStream_t)stream, (const float*)dy, (const float*)y, (const float*)w, (float*)dx,
+                                        npix, H, W));
+    return pd::check_launch("pd_disphead_bwd_data");
+}
+
+extern "C" size_t pd_disphead_workspace(int C) { return (size_t)kWgradBlocks * (9 * (size_t)C + 1) * sizeof(float); }
+
+extern "C" int pd_disphead_bwd_weight(const void* dy, const void* y, const void* x, void* dw, void* dbias, void* workspace,
+                                      size_t ws_bytes, int N, int H, int W, int C, int accumulate, void* stream) {
+    int rc = check_dims("pd_disphead_bwd_weight", N, H, W, C);
+    if (rc) return rc;
+    if (N == 0) return PD_OK;
+    PD_REQUIRE(dy && y && x && dw && workspace, "pd_disphead_bwd_weight: null tensor");
+    PD_REQUIRE(ws_bytes >= pd_disphead_workspace(C), "pd_disphead_bwd_weight: workspace too small");
+    PD_REQUIRE(pd::aligned16(x) && pd::aligned16(workspace), "pd_disphead_bwd_weight: x and workspace must be 16-byte aligned");
+    const int npix = N * H * W;
+    unsigned blocks = grid_for(npix, C);
+    if (blocks > (unsigned)kWgradBlocks) blocks = kWgradBlocks;
+    float* part = (float*)workspace;
+    float* bpart = part + (size_t)kWgradBlocks * 9 * C;
+    hipStream_t st = (hipStream_t)stream;
+    PD_DISPATCH_L(C, hipLaunchKernelGGL(disphead_bwd_weight_kernel<L>, dim3(blocks), dim3(256), 0, st, (const float*)dy,
+                                        (const float*)y, (const float*)x, part, bpart, npix, H, W));
+    rc = pd::check_launch("pd_disphead_bwd_weight");
+    if (rc) return rc;
+    hipLaunchKernelGGL(disphead_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, st, part, (float*)dw, (int)blocks,
+                       9 * C, accumulate);
+    if (dbias) hipLaunchKernelGGL(disphead_reduce_kernel, dim3(1), dim3(256), 0, st, bpart, (float*)dbias, (int)blocks, 1, accumulate);
+    return pd::check_launch("pd_disphead_bwd_weight/reduce");
+}

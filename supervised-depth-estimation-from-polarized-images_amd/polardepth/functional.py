@@ -40,6 +40,7 @@ class DropoutState:
 # wait for the side stream through ``sync_wgrad_stream``.
 _WGRAD_STREAMS = {}
 USE_WGRAD_STREAM = os.environ.get("PD_WGRAD_STREAM", "1") == "1"
+USE_DISP_HEADS = os.environ.get("PD_DISP_HEADS", "1") != "0"     # direct kernels for the 1-channel disparity heads
 USE_S2D_STEMS = os.environ.get("PD_S2D_STEMS", "1") == "1"
 
 
@@ -289,8 +290,54 @@ class ReflectConvActFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class DispHeadFn(torch.autograd.Function):
+    """sigmoid(Conv3x3(x)) with one output channel (depth_decoder.py:52-53,69-71): direct memory-bound kernels
+    (pd_disphead_*) instead of an MFMA tile with a single useful column."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = ops.as_nhwc(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, 1, H, W), dtype=torch.float32, device=x.device)
+        check(lib.pd_disphead_fwd(ptr(x), ptr(ops.weight_cl(weight)), ptr(bias), ptr(y), N, H, W, C, stream_ptr()),
+              "pd_disphead_fwd")
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, bias = ctx.params
+        N, C, H, W = x.shape
+        dy = dy.contiguous()
+        if weight.requires_grad:
+            db = grad_buf(bias) if bias is not None and bias.requires_grad else None
+            gw = grad_buf(weight)
+
+            def wgrad():
+                nbytes = lib.pd_disphead_workspace(C)
+                ws = ops._workspace(nbytes, x.device)
+                check(lib.pd_disphead_bwd_weight(ptr(dy), ptr(y), ptr(x), ptr(gw), ptr(db), ptr(ws), ws.numel(), N, H, W, C,
+                                                 1, stream_ptr()), "pd_disphead_bwd_weight")
+            _wgrad_async(x, dy, wgrad)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.empty_nhwc(N, C, H, W, x.device)
+            check(lib.pd_disphead_bwd_data(ptr(dy), ptr(y), ptr(ops.weight_cl(weight)), ptr(dx), N, H, W, C, stream_ptr()),
+                  "pd_disphead_bwd_data")
+        for p in (weight, bias):
+            if p is not None:
+                _ready(p)
+        return dx, None, None
+
+
 def reflect_conv_act(x, conv, act):
-    return ReflectConvActFn.apply(x, conv.weight, conv.bias, act)
+    w = conv.weight
+    if (act == ops.ACT_SIGMOID and w.shape[0] == 1 and w.shape[1] in (16, 32, 64, 128) and USE_DISP_HEADS
+            and x.shape[2] >= 2 and x.shape[3] >= 2):
+        return DispHeadFn.apply(x, w, conv.bias)
+    return ReflectConvActFn.apply(x, w, conv.bias, act)
 
 
 class UpCatFn(torch.autograd.Function):

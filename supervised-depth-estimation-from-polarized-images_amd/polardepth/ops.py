@@ -11,17 +11,17 @@ from ._lib import lib, check, ptr, stream_ptr
 MODE_ZERO, MODE_REFLECT, MODE_TRANSPOSED = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 CL = torch.channels_last
-PROFILE = None      # bench.py sets this to a list: (kernel label, algorithmic flops, start event, end event)
+PROFILE = None      # bench.py sets this to a list: (kernel label, algorithmic flops, start event, end event, shape)
 
 
-def _profiled(label, flops, fn):
+def _profiled(label, flops, fn, shape=None):
     if PROFILE is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    PROFILE.append((label, flops, e0, e1))
+    PROFILE.append((label, flops, e0, e1, shape))
     return r
 
 
@@ -92,7 +92,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd"), 2.0 * N * Ho * Wo * Co * C * KH * KW,
               lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
                                           Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub,
-                                          div, ldy, stream_ptr()), "pd_conv2d"))
+                                          div, ldy, stream_ptr()), "pd_conv2d"),
+              shape=("fwd", N, C, H, W, Co, KH, stride, mode))
     return (out, stats) if want_stats else out
 
 
@@ -121,7 +122,8 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None):
     _profiled(_igemm_label(N * H * W, Ci, True, "dgrad"), 2.0 * N * Hy * Wy * Co * Ci * KH * KW,
               lambda: check(lib.pd_conv2d(ptr(dy), ptr(wt), None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,
                                           H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci,
-                                          stream_ptr()), "pd_conv2d(dgrad)"))
+                                          stream_ptr()), "pd_conv2d(dgrad)"),
+              shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))
     return dx
 
 
@@ -161,7 +163,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
               lambda: check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), N, H, W, C,
                                                 sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride, pad, mode,
                                                 int(affine is not None), sub, div, dy.stride(3), int(accumulate),
-                                                stream_ptr()), "pd_conv2d_wgrad"))
+                                                stream_ptr()), "pd_conv2d_wgrad"),
+              shape=("wgrad", N, C, H, W, Co, KH, stride, mode))
     return (dw, dbias) if (want_bias or dbias is not None) else dw
 
 

@@ -131,3 +131,37 @@ def test_stem_as_space_to_depth_conv(C):
     dw = torch.zeros_like(wd)
     ops.s2d_weight_grad(dw2, dw, accumulate=True)
     _close(dw.cpu(), wr.grad)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 7, 9), (1, 32, 2, 2), (3, 64, 3, 5), (1, 128, 6, 4), (2, 16, 33, 21)])
+def test_disparity_head_direct_kernels(case):
+    """pd_disphead_{fwd,bwd_data,bwd_weight} (sigmoid(Conv3x3) with one output channel, reflection padding and its
+    gradient fold built in) vs autograd through a PyTorch fp32 CPU reference, including the smallest legal images
+    (H or W of 2 and 3, where both borders fold onto the same pixel) and ragged pixel counts."""
+    from polardepth import functional as PF
+    N, C, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g)
+    conv = torch.nn.Conv2d(C, 1, 3)
+    conv.weight.data = (torch.randn(1, C, 3, 3, generator=g) * 0.2)
+    conv.bias.data = torch.randn(1, generator=g) * 0.1
+    gy = torch.randn(N, 1, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.sigmoid(F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), conv.weight, conv.bias))
+    (yr * gy).sum().backward()
+    ref = (yr.detach(), xr.grad, conv.weight.grad.clone(), conv.bias.grad.clone())
+    conv.weight.grad = conv.bias.grad = None
+
+    conv = conv.cuda()
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    xc = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert PF.USE_DISP_HEADS
+    y = PF.reflect_conv_act(xc, conv, ops.ACT_SIGMOID)
+    assert y.grad_fn.__class__.__name__.startswith("DispHeadFn")
+    (y * gy.cuda()).sum().backward()
+    PF.sync_wgrad_stream()
+    torch.cuda.synchronize()
+    _close(y.cpu(), ref[0], 2e-6)
+    _close(xc.grad.cpu(), ref[1])
+    _close(conv.weight.grad.cpu(), ref[2])
+    _close(conv.bias.grad.cpu(), ref[3])

@@ -9,6 +9,11 @@ B = int(os.environ.get("B", 16))
 SHAPES = [  # name, C, H, W, Co, k, s, p, mode
     ("enc.ResBlock1 3x3 64->64 @256x320", 64, 256, 320, 64, 3, 1, 1, 0),
     ("enc.Conv2 5x5 64->64 @256x320", 64, 256, 320, 64, 5, 1, 2, 0),
+    ("enc.ResBlock2 3x3 64->64 @128x160", 64, 128, 160, 64, 3, 1, 1, 0),
+    ("enc.ResBlock3 3x3 64->64 @64x80", 64, 64, 80, 64, 3, 1, 1, 0),
+    ("rgb.layer2 3x3 128->128 @64x80", 128, 64, 80, 128, 3, 1, 1, 0),
+    ("dec.upconv(2,1) 128->64 @128x160 refl", 128, 128, 160, 64, 3, 1, 1, 1),
+    ("dec.upconv(3,1) 256->128 @64x80 refl", 256, 64, 80, 128, 3, 1, 1, 1),
     ("enc.Conv3 5x5 64->64 @128x160", 64, 128, 160, 64, 5, 1, 2, 0),
     ("joint.ResBlock1 3x3 128->128 @64x80", 128, 64, 80, 128, 3, 1, 1, 0),
     ("joint.Conv1 5x5 128->256 @64x80", 128, 64, 80, 256, 5, 1, 2, 0),
