@@ -145,6 +145,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = train_step(tr, batch)
+    t_enq = time.perf_counter() - t0              # host time to enqueue the steps (informational)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -204,7 +205,8 @@ def main():
                                                                    if args.attention else ""),
                    "global_batch": args.batch * world, "height": H, "width": W, "frame_width": FRAME_W,
                    "parallelism": f"dp{world}"},
-        "final_loss": round(loss_val, 6), "roofline": roofline,
+        "final_loss": round(loss_val, 6), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
+        "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.attention:
         result["cpu_baseline"] = cpu_baseline()

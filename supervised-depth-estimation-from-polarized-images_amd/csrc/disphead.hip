@@ -178,20 +178,26 @@ __global__ __launch_bounds__(256) void disphead_bwd_weight_kernel(const float* _
     if (threadIdx.x == 0) bpart[blockIdx.x] = (bred[0] + bred[1]) + (bred[2] + bred[3]);
 }
 
-// out[i] (+)= sum_s part[s][i], fixed order
+// out[i] (+)= sum_s part[s][i]: 16 columns x 16 slice lanes per workgroup, lane partials combined in a fixed order
 __global__ __launch_bounds__(256) void disphead_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S,
                                                               int n, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 3 < S; s += 4) {
-        a0 += part[(long)s * n + i]; a1 += part[(long)(s + 1) * n + i];
-        a2 += part[(long)(s + 2) * n + i]; a3 += part[(long)(s + 3) * n + i];
+    __shared__ float red[16][16];
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n) {
+        int s = sl;
+        for (; s + 16 < S; s += 32) { a0 += part[(long)s * n + i]; a1 += part[(long)(s + 16) * n + i]; }
+        if (s < S) a0 += part[(long)s * n + i];
     }
-    for (; s < S; ++s) a0 += part[(long)s * n + i];
-    const float v = (a0 + a1) + (a2 + a3);
-    out[i] = accumulate ? out[i] + v : v;
+    red[sl][col] = a0 + a1;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][col];
+        out[i] = accumulate ? out[i] + v : v;
+    }
 }
 
 constexpr int kWgradBlocks = 1024;
@@ -266,7 +272,7 @@ extern "C" int pd_disphead_bwd_weight(const void* dy, const void* y, const void*
                                         (const float*)y, (const float*)x, part, bpart, npix, H, W));
     rc = pd::check_launch("pd_disphead_bwd_weight");
     if (rc) return rc;
-    hipLaunchKernelGGL(disphead_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, st, part, (float*)dw, (int)blocks,
+    hipLaunchKernelGGL(disphead_reduce_kernel, dim3((9 * C + 15) / 16), dim3(256), 0, st, part, (float*)dw, (int)blocks,
                        9 * C, accumulate);
     if (dbias) hipLaunchKernelGGL(disphead_reduce_kernel, dim3(1), dim3(256), 0, st, bpart, (float*)dbias, (int)blocks, 1, accumulate);
     return pd::check_launch("pd_disphead_bwd_weight/reduce");

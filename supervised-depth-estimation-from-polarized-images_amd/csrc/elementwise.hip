@@ -149,55 +149,56 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
+// 32-bit element indices (the host checks N*H*W*C/4 < 2^31): 64-bit divisions per element cost more than the math
 __global__ __launch_bounds__(EW_T) void chain_fwd_kernel(const ChainArgs a) {
-    const int cq = a.C >> 2;
-    const int Ho = a.pool ? a.H >> 1 : a.H, Wo = a.pool ? a.W >> 1 : a.W;
-    const long total = (long)a.N * Ho * Wo * cq;
-    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int c4 = (int)(i % cq) * 4;
-        const long pix = i / cq;                    // output pixel index
+    const unsigned cq = a.C >> 2;
+    const unsigned Ho = a.pool ? a.H >> 1 : a.H, Wo = a.pool ? a.W >> 1 : a.W;
+    const unsigned total = (unsigned)a.N * Ho * Wo * cq;
+    for (unsigned i = blockIdx.x * (unsigned)EW_T + threadIdx.x; i < total; i += gridDim.x * (unsigned)EW_T) {
+        const unsigned pix = i / cq;                // output pixel index
+        const int c4 = (int)(i - pix * cq) * 4;
         const float4 s = a.scale ? ld4(a.scale + c4) : f4(1.f);
         const float4 b = a.scale ? ld4(a.shift + c4) : f4(0.f);
         float4 v;
         if (a.pool) {
-            const int wo = (int)(pix % Wo);
-            const long t = pix / Wo;
-            const int ho = (int)(t % Ho);
-            const long n = t / Ho;
-            const float* p = a.x + (((n * a.H + 2 * ho) * a.W) + 2 * wo) * a.C + c4;
+            const unsigned t = pix / Wo;
+            const unsigned wo = pix - t * Wo;
+            const unsigned n = t / Ho;
+            const unsigned ho = t - n * Ho;
+            const float* p = a.x + (((size_t)n * a.H + 2 * ho) * a.W + 2 * wo) * a.C + c4;
             float4 v00 = affine4(ld4(p), s, b), v01 = affine4(ld4(p + a.C), s, b);
             float4 v10 = affine4(ld4(p + (long)a.W * a.C), s, b), v11 = affine4(ld4(p + (long)a.W * a.C + a.C), s, b);
             if (a.relu_pre) { v00 = relu4(v00); v01 = relu4(v01); v10 = relu4(v10); v11 = relu4(v11); }
             v = max4(max4(v00, v01), max4(v10, v11));
         } else {
-            v = affine4(ld4(a.x + pix * a.C + c4), s, b);
+            v = affine4(ld4(a.x + (size_t)pix * a.C + c4), s, b);
             if (a.relu_pre) v = relu4(v);
         }
         if (a.drop_p > 0.f) v = mul4(v, dropout_scale(i, a.seed, a.offset, a.drop_p));
-        if (a.res) v = add4(v, ld4(a.res + pix * a.ld_res + c4));
+        if (a.res) v = add4(v, ld4(a.res + (size_t)pix * a.ld_res + c4));
         if (a.relu_post) v = relu4(v);
-        st4(a.out + pix * a.ld_out + c4, v);
+        st4(a.out + (size_t)pix * a.ld_out + c4, v);
     }
 }
 
 // gradient w.r.t. the BN output z at input pixel (n,h,w), channels c4..c4+3; also returns xhat.
 // Recomputes the forward masks from x (and `out` for the post-add ReLU).
-__device__ __forceinline__ float4 chain_grad(const ChainArgs& a, long n, int h, int w, int c4, float4 xv,
+__device__ __forceinline__ float4 chain_grad(const ChainArgs& a, unsigned n, unsigned h, unsigned w, int c4, float4 xv,
                                              float4 s, float4 b) {
-    const int Ho = a.pool ? a.H >> 1 : a.H, Wo = a.pool ? a.W >> 1 : a.W;
-    const int ho = a.pool ? h >> 1 : h, wo = a.pool ? w >> 1 : w;
+    const unsigned Ho = a.pool ? a.H >> 1 : a.H, Wo = a.pool ? a.W >> 1 : a.W;
+    const unsigned ho = a.pool ? h >> 1 : h, wo = a.pool ? w >> 1 : w;
     if (a.pool && (ho >= Ho || wo >= Wo)) return f4(0.f);   // odd trailing row/col is dropped by the pool
-    const long opix = (n * Ho + ho) * Wo + wo;
-    float4 g = ld4(a.dy + opix * a.ld_dy + c4);
+    const unsigned opix = (n * Ho + ho) * Wo + wo;
+    float4 g = ld4(a.dy + (size_t)opix * a.ld_dy + c4);
     if (a.relu_post) {
-        const float4 o = ld4(a.out + opix * a.ld_out + c4);
+        const float4 o = ld4(a.out + (size_t)opix * a.ld_out + c4);
         g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
     }
     if (a.drop_p > 0.f) g = mul4(g, dropout_scale(opix * (a.C >> 2) + (c4 >> 2), a.seed, a.offset, a.drop_p));
     float4 z = affine4(xv, s, b);
     if (a.pool) {
         // route to the first maximum of the 2x2 window (scan order), like torch max_pool2d
-        const float* p = a.x + (((n * a.H + 2 * ho) * a.W) + 2 * wo) * a.C + c4;
+        const float* p = a.x + (((size_t)n * a.H + 2 * ho) * a.W + 2 * wo) * a.C + c4;
         float4 v[4];
         v[0] = affine4(ld4(p), s, b); v[1] = affine4(ld4(p + a.C), s, b);
         v[2] = affine4(ld4(p + (long)a.W * a.C), s, b); v[3] = affine4(ld4(p + (long)a.W * a.C + a.C), s, b);
@@ -221,20 +222,20 @@ __device__ __forceinline__ float4 chain_grad(const ChainArgs& a, long n, int h, 
 
 template <bool APPLY>
 __global__ __launch_bounds__(EW_T) void chain_bwd_kernel(const ChainArgs a) {
-    const int cq = a.C >> 2;
-    const long total = (long)a.N * a.H * a.W * cq;
+    const unsigned cq = a.C >> 2;
+    const unsigned total = (unsigned)a.N * a.H * a.W * cq;
     float4 sg = f4(0.f), sgx = f4(0.f);
     // 256 % cq == 0 (checked on the host): every thread keeps its channel quad across the loop
-    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int c4 = (int)(i % cq) * 4;
-        const long pix = i / cq;
-        const int w = (int)(pix % a.W);
-        const long t = pix / a.W;
-        const int h = (int)(t % a.H);
-        const long n = t / a.H;
+    for (unsigned i = blockIdx.x * (unsigned)EW_T + threadIdx.x; i < total; i += gridDim.x * (unsigned)EW_T) {
+        const unsigned pix = i / cq;
+        const int c4 = (int)(i - pix * cq) * 4;
+        const unsigned t = pix / a.W;
+        const unsigned w = pix - t * a.W;
+        const unsigned n = t / a.H;
+        const unsigned h = t - n * a.H;
         const float4 s = a.scale ? ld4(a.scale + c4) : f4(1.f);
         const float4 b = a.scale ? ld4(a.shift + c4) : f4(0.f);
-        const float4 xv = ld4(a.x + pix * a.C + c4);
+        const float4 xv = ld4(a.x + (size_t)pix * a.C + c4);
         const float4 g = chain_grad(a, n, h, w, c4, xv, s, b);
         float4 xh = f4(0.f);
         if (a.mean) {
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(EW_T) void chain_bwd_kernel(const ChainArgs a) {
             } else {
                 d = mul4(g, s);
             }
-            st4(a.dx + pix * a.C + c4, d);
+            st4(a.dx + (size_t)pix * a.C + c4, d);
         }
     }
     if (!APPLY) {
@@ -557,6 +558,7 @@ extern "C" int pd_bn_bwd_finalize(const void* partial, long R, int C, double cou
 static int chain_check(int N, int H, int W, int C, int pool) {
     PD_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_chain: bad dims (C must be a multiple of 4)");
     PD_REQUIRE(!pool || (H >= 2 && W >= 2), "pd_chain: pooling needs H,W >= 2");
+    PD_REQUIRE((long)N * H * W * (C / 4) < (1L << 31) - (1L << 22), "pd_chain: tensor too large for 32-bit element indices");
     return PD_OK;
 }
 
