@@ -98,10 +98,14 @@ __device__ __forceinline__ bool tap_in(int rh, int rw, int kh, int kw, int H, in
 template <int BM, int BN, int WM, int WN, bool VEC, int MODE>
 __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int WAVES_N = BN / WN;
-    constexpr int TM = WM / 32, TN = WN / 32;     // 32x32 MFMA tiles per wave
+    // MFMA shape: 32x32x2 tiles, or 16x16x4 tiles for the 16-wide block tile (layers with <= 16 output channels
+    // would leave half of a 32-wide tile empty; both shapes have the same flops per cycle)
+    constexpr int MT = BN == 16 ? 16 : 32;
+    constexpr int TM = WM / MT, TN = WN / MT;     // MFMA tiles per wave
+    constexpr int ACCN = MT == 32 ? 16 : 4;       // accumulator registers per tile
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
     constexpr int A_VEC_ITERS = BM / 32;          // 16-byte pieces per thread per chunk (A)
-    constexpr int B_VEC_ITERS = BN / 32;
+    constexpr int B_VEC_ITERS = (BN + 31) / 32;   // (rows >= BN are skipped)
     constexpr int A_SC_ITERS = BM / 8;            // scalar elements per thread per chunk (A)
     constexpr int B_SC_ITERS = BN / 8;
 
@@ -206,8 +210,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < B_VEC_ITERS; ++i) {
-                const int nr = n0 + (tid >> 3) + 32 * i;
-                pb[i] = buf_ld4(rw_, (kv & (nr < a.Co)) ? (unsigned)(nr * a.K + tk) * 4u : OOB);
+                const int nl = (tid >> 3) + 32 * i, nr = n0 + nl;
+                if (BN % 32 == 0 || nl < BN) pb[i] = buf_ld4(rw_, (kv & (nr < a.Co)) ? (unsigned)(nr * a.K + tk) * 4u : OOB);
             }
         } else {
 #pragma unroll
@@ -237,7 +241,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
                 *reinterpret_cast<float4*>(&As[buf][(tid >> 3) + 32 * i][swz((tid >> 3) + 32 * i, pc)]) = pa[i];
 #pragma unroll
             for (int i = 0; i < B_VEC_ITERS; ++i)
-                *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) + 32 * i][swz((tid >> 3) + 32 * i, pc)]) = pb[i];
+                if (BN % 32 == 0 || (tid >> 3) + 32 * i < BN)
+                    *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) + 32 * i][swz((tid >> 3) + 32 * i, pc)]) = pb[i];
         } else {
             const int kc = tid & 31;
 #pragma unroll
@@ -247,50 +252,63 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
 
-    f32x16 acc[TM][TN];
+    typedef float accv_t __attribute__((ext_vector_type(ACCN)));
+    accv_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < ACCN; ++r) acc[i][j][r] = 0.f;
 
     load_chunk();
     store_chunk(0);
     __syncthreads();
-    const int frow = lane & 31, fh = lane >> 5;
+    // Fragment reads: lane -> (row = lane % MT, slot group = lane / MT).  One ds_read_b128 hands a lane four
+    // consecutive k; MFMA number c of a group contracts component c of every lane, i.e. k = 4*slot + c over the
+    // 2 (32x32x2) or 4 (16x16x4) slot groups -- a permutation of k shared by A and B.
+    constexpr int SG = 64 / MT;                    // slot groups per read: 2 or 4
+    const int frow = lane % MT, fh = lane / MT;
     for (int q = 0; q < nchunks; ++q) {
         const int buf = q & 1;
         if (q + 1 < nchunks) load_chunk();
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
+        for (int g = 0; g < BK / (4 * SG); ++g) {
             float4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const float4*>(&As[buf][wm * WM + 32 * i + frow][swz(wm * WM + 32 * i + frow, 2 * g + fh)]);
+                fa[i] = *reinterpret_cast<const float4*>(&As[buf][wm * WM + MT * i + frow][swz(wm * WM + MT * i + frow, SG * g + fh)]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * WN + 32 * j + frow][swz(wn * WN + 32 * j + frow, 2 * g + fh)]);
+                fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * WN + MT * j + frow][swz(wn * WN + MT * j + frow, SG * g + fh)]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    if constexpr (MT == 32) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
                 }
         }
         if (q + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // ---- epilogue: C/D layout of the MFMA: col = lane % MT; 32x32: row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
+    // 16x16: row = r + 4*(lane>>4), r < 4.
     // Straight-line code: the activation is a template argument, the row step of every store is a scalar offset
-    // and out-of-range elements are dropped by the bounds check of the buffer store (offset OOB), so the 32 stores
+    // and out-of-range elements are dropped by the bounds check of the buffer store (offset OOB), so the stores
     // of a wave issue back to back (with per-element branches the compiler drained vmcnt to zero after each one).
-    const int col_l = lane & 31;
-    const int rbase = 4 * (lane >> 5);
+    const int col_l = lane % MT;
+    const int rbase = 4 * (lane / MT);
     {
         const long rows_left = a.M - m0;
         const int rows = rows_left < BM ? (int)rows_left : BM;
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * WN + 32 * j + col_l;
+                const int col = n0 + wn * WN + MT * j + col_l;
                 const bool cv = col < a.Co;
                 const float bv = a.bias ? buf_ld1(rb_, cv ? (unsigned)col * 4u : OOB) : 0.f;
                 float s1 = 0.f, s2 = 0.f;
@@ -309,8 +327,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rr = 32 * i + (r & 3) + 8 * (r >> 2);   // compile-time row step: scalar offset
+                    for (int r = 0; r < ACCN; ++r) {
+                        const int rr = MT * i + (MT == 32 ? (r & 3) + 8 * (r >> 2) : r);   // compile-time row step: scalar offset
                         const bool ok = cv & (row_l < rows - rr);
                         float v = acc[i][j][r] + bv;
                         const float vs = ok ? v : 0.f;
@@ -324,9 +342,9 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
                     }
                 }
                 if (a.stats) {
-                    s1 += __shfl_xor(s1, 32);
-                    s2 += __shfl_xor(s2, 32);
-                    if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
+#pragma unroll
+                    for (int m = MT; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+                    if (lane < MT) { red[wave][MT * j + col_l][0] = s1; red[wave][MT * j + col_l][1] = s2; }
                 }
             }
         };
@@ -427,7 +445,8 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, void* y
     hipStream_t st = (hipStream_t)stream;
     const int bm = pd_conv2d_tile_m(a.M, Co);
     if (Co > 32) return bm == 128 ? launch_conv<128, 64, 64, 32>(a, vec, st) : launch_conv<64, 64, 32, 32>(a, vec, st);
-    return launch_conv<128, 32, 32, 32>(a, vec, st);
+    if (Co > 16) return launch_conv<128, 32, 32, 32>(a, vec, st);
+    return launch_conv<128, 16, 32, 16>(a, vec, st);   // 16x16x4 MFMA tiles
 }
 
 // ===================================================================== weight gradient
@@ -464,11 +483,14 @@ struct WgradArgs {
 template <int TCO, bool VEC, int MODE>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int LDD = TCO + 8;
-    constexpr int WAVES_CO = TCO / 32;            // 2 (TCO=64) or 1 (TCO=32)
+    constexpr int MT = TCO == 16 ? 16 : 32;       // MFMA tile: 32x32x2, or 16x16x4 for <= 16 output channels
+    constexpr int ACCN = MT == 32 ? 16 : 4;
+    constexpr int WAVES_CO = TCO / MT;            // 2 (TCO=64) or 1
     constexpr int WAVES_K = 4 / WAVES_CO;         // 2 or 4
-    constexpr int TK = WG_K / WAVES_K / 32;       // MFMA tiles along k per wave: 2 or 1
-    constexpr int DY_ITERS = WG_MC * TCO / 4 / NT;   // 16-byte dY pieces per thread per chunk: 2 or 1
+    constexpr int TK = WG_K / WAVES_K / MT;       // MFMA tiles along k per wave: 2, 1 or (16-wide) 2
+    constexpr int DY_ITERS = (WG_MC * TCO / 4 + NT - 1) / NT;   // 16-byte dY pieces per thread per chunk: 2 or 1
     constexpr int DY_PPR = TCO / 4;                  // pieces per row
+    constexpr bool DY_ALL = WG_MC * TCO / 4 >= NT;   // false: only the first WG_MC*TCO/4 threads load dY
     __shared__ __attribute__((aligned(16))) float Ds[2][WG_MC][LDD];
     __shared__ __attribute__((aligned(16))) float Xs[2][WG_MC][WG_LDX];
     __shared__ int ktab[VEC ? 1 : WG_K][3];
@@ -565,7 +587,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
             const int r = rbase + tid / DY_PPR + (NT / DY_PPR) * i;
             const int co = co0 + 4 * (tid % DY_PPR);
             const unsigned off = (unsigned)(r * (int)a.ldd + co) * 4u;
-            if ((a.Co & 3) == 0) {
+            if (!DY_ALL && tid >= WG_MC * DY_PPR) {
+                pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if ((a.Co & 3) == 0) {
                 pd[i] = buf_ld4(rd, (r < nrows && co < a.Co) ? off : OOB);
             } else {   // ragged channel count (e.g. the 1-channel disparity heads): element-wise
                 float4 v;
@@ -611,7 +635,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < DY_ITERS; ++i)
-            *reinterpret_cast<float4*>(&Ds[buf][tid / DY_PPR + (NT / DY_PPR) * i][4 * (tid % DY_PPR)]) = pd[i];
+            if (DY_ALL || tid < WG_MC * DY_PPR)
+                *reinterpret_cast<float4*>(&Ds[buf][tid / DY_PPR + (NT / DY_PPR) * i][4 * (tid % DY_PPR)]) = pd[i];
         if (VEC) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Xs[buf][(tid >> 5) + 8 * i][4 * (tid & 31)]) = px[i];
@@ -621,27 +646,31 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         }
     };
 
-    f32x16 acc[TK];
+    typedef float accv_t __attribute__((ext_vector_type(ACCN)));
+    accv_t acc[TK];
 #pragma unroll
     for (int t = 0; t < TK; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int r = 0; r < ACCN; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
     const bool do_bias = a.bpart != nullptr && kt == 0;
 
     if (nchunks > 0) { load_chunk(0); store_chunk(0); }
     __syncthreads();
-    const int fi = lane & 31, fk = lane >> 5;
+    // fragment lane -> (index inside the MFMA tile, pixel of the step): 2 pixels per 32x32x2, 4 per 16x16x4
+    constexpr int PS = 64 / MT;
+    const int fi = lane % MT, fk = lane / MT;
     for (int q = 0; q < nchunks; ++q) {
         const int buf = q & 1;
         if (q + 1 < nchunks) load_chunk(q + 1);
 #pragma unroll
-        for (int st = 0; st < WG_MC / 2; ++st) {
-            const float av = Ds[buf][2 * st + fk][wm * 32 + fi];
+        for (int st = 0; st < WG_MC / PS; ++st) {
+            const float av = Ds[buf][PS * st + fk][wm * MT + fi];
 #pragma unroll
             for (int t = 0; t < TK; ++t) {
-                const float bv = Xs[buf][2 * st + fk][(wn * TK + t) * 32 + fi];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                const float bv = Xs[buf][PS * st + fk][(wn * TK + t) * MT + fi];
+                if constexpr (MT == 32) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
             }
         }
         if (do_bias && tid < TCO) {
@@ -651,13 +680,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
         if (q + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
     }
-    // C/D layout: col = lane&31 -> k, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co
+    // C/D layout: col = lane % MT -> k; row -> co: (r&3) + 8*(r>>2) + 4*(lane>>5) (32x32), r + 4*(lane>>4) (16x16)
 #pragma unroll
     for (int t = 0; t < TK; ++t) {
-        const int k = k0 + (wn * TK + t) * 32 + (lane & 31);
+        const int k = k0 + (wn * TK + t) * MT + fi;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        for (int r = 0; r < ACCN; ++r) {
+            const int co = co0 + wm * MT + (MT == 32 ? (r & 3) + 8 * (r >> 2) : r) + 4 * fk;
             if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc[t][r];
         }
     }
@@ -703,7 +732,7 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     }
 }
 
-inline int wgrad_tco(int Co) { return Co > 32 ? 64 : 32; }
+inline int wgrad_tco(int Co) { return Co > 32 ? 64 : (Co > 16 ? 32 : 16); }
 
 void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
     const int tco = wgrad_tco(Co);
@@ -761,9 +790,12 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     if (tco == 64) {
         if (vec) { if (mode == MODE_ZERO) PD_WG(64, true, MODE_ZERO); else PD_WG(64, true, MODE_REFLECT); }
         else { if (mode == MODE_ZERO) PD_WG(64, false, MODE_ZERO); else PD_WG(64, false, MODE_REFLECT); }
-    } else {
+    } else if (tco == 32) {
         if (vec) { if (mode == MODE_ZERO) PD_WG(32, true, MODE_ZERO); else PD_WG(32, true, MODE_REFLECT); }
         else { if (mode == MODE_ZERO) PD_WG(32, false, MODE_ZERO); else PD_WG(32, false, MODE_REFLECT); }
+    } else {
+        if (vec) { if (mode == MODE_ZERO) PD_WG(16, true, MODE_ZERO); else PD_WG(16, true, MODE_REFLECT); }
+        else { if (mode == MODE_ZERO) PD_WG(16, false, MODE_ZERO); else PD_WG(16, false, MODE_REFLECT); }
     }
 #undef PD_WG
     int rc = pd::check_launch("pd_conv2d_wgrad");

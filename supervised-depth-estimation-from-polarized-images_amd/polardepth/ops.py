@@ -27,7 +27,7 @@ def _profiled(label, flops, fn, shape=None):
 
 def _igemm_label(M, Co, vec, kind):
     bm = lib.pd_conv2d_tile_m(M, Co)
-    bn = 64 if Co > 32 else 32
+    bn = 64 if Co > 32 else (32 if Co > 16 else 16)
     return f"conv_igemm_kernel<{bm},{bn},{'vec' if vec else 'scalar'}>"
 
 
