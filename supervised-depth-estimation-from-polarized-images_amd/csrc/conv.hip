@@ -663,15 +663,31 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     for (int q = 0; q < nchunks; ++q) {
         const int buf = q & 1;
         if (q + 1 < nchunks) load_chunk(q + 1);
+        // Fragments are read one group (four pixel steps) ahead of their MFMAs; scheduling barriers keep the order
+        // (left alone, the compiler reads each step right before its two MFMAs and waits for LDS every time).
+        constexpr int NST = WG_MC / PS, UG = 4, NG = NST / UG;
+        float av[2][UG], bv[2][UG][TK];
+        auto read_group = [&](int sg, int slot) {
 #pragma unroll
-        for (int st = 0; st < WG_MC / PS; ++st) {
-            const float av = Ds[buf][PS * st + fk][wm * MT + fi];
+            for (int u = 0; u < UG; ++u) {
+                av[slot][u] = Ds[buf][PS * (UG * sg + u) + fk][wm * MT + fi];
 #pragma unroll
-            for (int t = 0; t < TK; ++t) {
-                const float bv = Xs[buf][PS * st + fk][(wn * TK + t) * MT + fi];
-                if constexpr (MT == 32) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+                for (int t = 0; t < TK; ++t) bv[slot][u][t] = Xs[buf][PS * (UG * sg + u) + fk][(wn * TK + t) * MT + fi];
             }
+        };
+        read_group(0, 0);
+#pragma unroll
+        for (int sg = 0; sg < NG; ++sg) {
+            if (sg + 1 < NG) read_group(sg + 1, (sg + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UG; ++u)
+#pragma unroll
+                for (int t = 0; t < TK; ++t) {
+                    if constexpr (MT == 32) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sg & 1][u], bv[sg & 1][u][t], acc[t], 0, 0, 0);
+                    else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sg & 1][u], bv[sg & 1][u][t], acc[t], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (do_bias && tid < TCO) {
 #pragma unroll 8
