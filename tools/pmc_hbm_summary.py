@@ -1,0 +1,57 @@
+"""Summarise two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) into HBM bytes per launch and kernel.
+
+    cd /tmp && export TMPDIR=/tmp
+    PD_WGRAD_STREAM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out/fetch -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline
+    PD_WGRAD_STREAM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d out/write -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline
+    python tools/pmc_hbm_summary.py out/fetch out/write profiles/rNN_pmc_hbm_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KB, summed over the XCDs; FETCH_SIZE is doubled (MI355X_MICROARCH.md:
+gfx950 counts the 128-byte requests of wide coalesced reads as 64 bytes)."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def short(name):
+    name = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    m = re.match(r"conv_igemm_kernel<(\d+), (\d+), \d+, \d+, (true|false), \d+>", name)
+    if m:
+        return f"conv_igemm_kernel<{m.group(1)},{m.group(2)},{'vec' if m.group(3) == 'true' else 'scalar'}>"
+    return name.split("(")[0]
+
+
+def load(d, counter):
+    per = collections.defaultdict(lambda: [0.0, set()])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            per[k][0] += float(r["Counter_Value"])
+            per[k][1].add(r["Dispatch_Id"])
+    return {k: (v[0] / max(len(v[1]), 1), len(v[1])) for k, v in per.items()}
+
+
+if __name__ == "__main__":
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, n = fetch.get(k, (0.0, 0))
+        w, _ = write.get(k, (0.0, 0))
+        kernels[k] = {"FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
+                      "hbm_bytes_per_launch": int((2 * f + w) * 1024), "launches": n}
+    conv = {k: v for k, v in kernels.items() if k.startswith("conv_")}
+    dom = max(conv.items(), key=lambda kv: kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[0] if conv else None
+    dom = "conv_igemm_kernel<128,64,vec>" if "conv_igemm_kernel<128,64,vec>" in kernels else dom
+    out = {"_about": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- "
+                     "PD_WGRAD_STREAM=0 python bench.py --steps 1 --warmup 1 --no_cpu_baseline; KB per launch (mean over "
+                     "the launches of the run); hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                     "(tools/pmc_hbm_summary.py)",
+           "dominant": {"kernel": dom, **({"hbm_bytes_per_launch": kernels[dom]["hbm_bytes_per_launch"],
+                                           "launches": kernels[dom]["launches"]} if dom else {})},
+           "kernels": kernels}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    print(json.dumps(out["dominant"]))
