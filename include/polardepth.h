@@ -151,7 +151,9 @@ int pd_weight_transpose(const void* w, void* wt, int Cout, int T, int Cin, void*
  * Memory-bound kernels fused around the convolutions (NHWC fp32, 16 bytes per lane).
  *
  * pd_bn_fwd_finalize: BatchNorm2d statistics.  training != 0: reduces the conv epilogue partials
- *   [R][C][2] in fp64 (acc_ws: 2*C doubles), updates running_mean/var with torch semantics
+ *   [R][C][2] in fp64 (acc_ws: 2*C doubles that must be ZERO on entry and are left zero by the call -- a
+ *   long-lived accumulator per stream saves a memset per layer; same contract in pd_bn_bwd_finalize),
+ *   updates running_mean/var with torch semantics
  *   (momentum, unbiased variance) and emits scale = gamma*invstd, shift = beta - mean*scale plus
  *   the saved mean / invstd; training == 0: coefficients from the running statistics.
  *   Replaces nn.BatchNorm2d's statistics pass (pre_encoders.py:19,29; torchvision BasicBlock.bn*).

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(EW_T) void colsum_kernel(const float* __restrict__ 
 }
 
 // training-mode statistics -> affine coefficients (+ running stats update, torch semantics)
-__global__ void bn_fwd_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ gamma,
+__global__ void bn_fwd_finalize_kernel(double* __restrict__ acc, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* __restrict__ rmean,
                                        float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
                                        float* __restrict__ smean, float* __restrict__ sinvstd, int C, double count,
@@ -82,6 +82,7 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ acc, const flo
     if (training) {
         const double m = acc[2 * c] / count;
         double var = acc[2 * c + 1] / count - m * m;
+        acc[2 * c] = 0.0; acc[2 * c + 1] = 0.0;       // leave the accumulator clean for the next call
         if (var < 0.0) var = 0.0;
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -102,12 +103,13 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ acc, const flo
 }
 
 // backward: acc = (sum g, sum g*xhat) -> dgamma, dbeta, coef = (mean g, mean g*xhat)
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, float* __restrict__ dgamma,
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ acc, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef, int C, double count,
                                        int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double sg = acc[2 * c], sgx = acc[2 * c + 1];
+    acc[2 * c] = 0.0; acc[2 * c + 1] = 0.0;           // leave the accumulator clean for the next call
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sgx;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sg;
     coef[c] = (float)(sg / count);
@@ -524,15 +526,13 @@ extern "C" int pd_bn_fwd_finalize(const void* partial, long R, int C, double cou
     PD_REQUIRE(training || (running_mean && running_var), "pd_bn_fwd_finalize: eval needs running stats");
     hipStream_t st = (hipStream_t)stream;
     if (training) {
-        if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * C, st) != hipSuccess)
-            return pd::fail(PD_ELAUNCH, "pd_bn_fwd_finalize: memset failed");
         const int cgroups = (C + 31) / 32;
         const int rpb = 256;
         const long rblocks = (R + rpb - 1) / rpb;
         hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(cgroups * rblocks)), dim3(EW_T), 0, st,
                            (const float*)partial, (double*)acc_ws, R, C, rpb);
     }
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, (const double*)acc_ws,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, (double*)acc_ws,
                        (const float*)gamma, (const float*)beta, (float*)running_mean, (float*)running_var,
                        (float*)scale, (float*)shift, (float*)save_mean, (float*)save_invstd, C, count, momentum, eps,
                        training);
@@ -543,14 +543,12 @@ extern "C" int pd_bn_bwd_finalize(const void* partial, long R, int C, double cou
                                   void* dbeta, void* coef, int accumulate, void* stream) {
     PD_REQUIRE(partial && acc_ws && coef && C > 0 && R > 0 && count > 0, "pd_bn_bwd_finalize: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * C, st) != hipSuccess)
-        return pd::fail(PD_ELAUNCH, "pd_bn_bwd_finalize: memset failed");
     const int cgroups = (C + 31) / 32;
     const int rpb = 256;
     const long rblocks = (R + rpb - 1) / rpb;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(cgroups * rblocks)), dim3(EW_T), 0, st, (const float*)partial,
                        (double*)acc_ws, R, C, rpb);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, (const double*)acc_ws,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, (double*)acc_ws,
                        (float*)dgamma, (float*)dbeta, (float*)coef, C, count, accumulate);
     return pd::check_launch("pd_bn_bwd_finalize");
 }

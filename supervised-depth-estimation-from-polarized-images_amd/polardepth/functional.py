@@ -138,6 +138,20 @@ class ChainCfg:
 
 
 # ------------------------------------------------------------------ conv -> BN -> ReLU -> pool -> dropout -> +res -> ReLU
+_BN_ACC = {}
+
+
+def _bn_acc(dev, C):
+    """fp64 accumulator of the BatchNorm partial sums: zero on entry, left zero by pd_bn_{fwd,bwd}_finalize, so one
+    long-lived buffer per (device, stream) replaces a memset per layer and direction."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _BN_ACC.get(key)
+    if buf is None or buf.numel() < 2 * C:
+        buf = torch.zeros(max(2 * C, 8192), dtype=torch.float64, device=dev)
+        _BN_ACC[key] = buf
+    return buf
+
+
 class ConvBNChainFn(torch.autograd.Function):
     """pre_encoders.ConvBlock (+ ResidualBlock add) and torchvision conv/bn/relu(/add) as one node."""
 
@@ -166,7 +180,7 @@ class ConvBNChainFn(torch.autograd.Function):
             z, part = ops.conv2d_fwd(x, w_eff, bias, stride, pad, affine=aff, out_hw=out_hw), None
         _, _, Hz, Wz = z.shape
         scale, shift, mean, invstd = _f32(dev, Co), _f32(dev, Co), _f32(dev, Co), _f32(dev, Co)
-        acc = torch.empty(2 * Co, dtype=torch.float64, device=dev) if training else None
+        acc = _bn_acc(dev, Co) if training else None
         check(lib.pd_bn_fwd_finalize(ptr(part), 0 if part is None else part.shape[0], Co, float(N * Hz * Wz),
                                      ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
                                      bn.momentum, bn.eps, ptr(acc), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
@@ -203,7 +217,7 @@ class ConvBNChainFn(torch.autograd.Function):
             check(lib.pd_chain_bwd_reduce(ptr(dy), ld_dy, ptr(z), ptr(out), Co, ptr(scale), ptr(shift), ptr(mean),
                                           ptr(invstd), ptr(part), N, Hz, Wz, Co, int(cfg.relu_pre), int(cfg.pool),
                                           ctx.drop, cfg.seed, cfg.offset, int(cfg.relu_post), st), "pd_chain_bwd_reduce")
-            acc = torch.empty(2 * Co, dtype=torch.float64, device=dev)
+            acc = _bn_acc(dev, Co)
             dgamma = grad_buf(gamma) if gamma is not None and gamma.requires_grad else None
             dbeta = grad_buf(beta) if beta is not None and beta.requires_grad else None
             check(lib.pd_bn_bwd_finalize(ptr(part), rows, Co, float(N * Hz * Wz), ptr(acc), ptr(dgamma), ptr(dbeta),
