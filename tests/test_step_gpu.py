@@ -19,14 +19,49 @@ from synth_weights import fill_state_dict  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _opts(tmp, extra=()):
+def _opts(tmp, extra=(), encoders=("--augment_xolp", "--augment_normals")):
     from manydepth.options import MonodepthOptions
     return MonodepthOptions().parse([
         "--png", "--batch_size", "2", "--height", "64", "--width", "96", "--dataset", "HAMMER", "--split", "HAMMER",
         "--eval_split", "HAMMER_unseen", "--min_depth", "0.1", "--max_depth", "2.0", "--depth_supervision_only", "True",
-        "--depth_supervision", "True", "--normals_loss_weight", "0.35", "--augment_xolp", "--augment_normals",
+        "--depth_supervision", "True", "--normals_loss_weight", "0.35", *encoders,
         "--log_dir", str(tmp), "--data_path", "synthetic", "--data_path_val", "synthetic", "--num_workers", "0",
         "--weights_init", "scratch", "--learning_rate", "1e-4", *extra])
+
+
+@pytest.mark.parametrize("encoders", [(), ("--augment_xolp",), ("--augment_normals",)])
+def test_training_step_other_encoder_sets_match_oracle(tmp_path, encoders):
+    """BASELINE configs[0] (RGB only) and configs[1] (RGB + XOLP) -- and RGB + normals -- through the same façade:
+    disparities 2e-5, loss 1e-4 relative vs the CPU oracle, and a finite optimizer step."""
+    from manydepth.trainer import Trainer
+    from polardepth import synthetic
+    from oracle import nets as onets, losses as ol, polar as opolar
+    tr = Trainer(_opts(tmp_path, ["--dropout_rate", "0.0"], encoders))
+    ax, an = "--augment_xolp" in encoders, "--augment_normals" in encoders
+    ref = onets.build_models(ax, an, 0.0)
+    assert set(ref) == set(tr.models)
+    for name, m in ref.items():
+        fill_state_dict(m, 0, prefix=name + ".")
+        tr.models[name].load_state_dict(m.state_dict())
+        m.train()
+    tr.set_train()
+    batch = synthetic.make_batch(2, 64, 96, frame_w=92, device="cuda", seed=9)
+    cpu = {k: v.cpu() for k, v in batch.items()}
+    tr.model_optimizer.zero_grad()
+    outputs, losses, _ = tr.process_batch(dict(batch), is_train=True)
+    losses["loss"].backward()
+    tr.model_optimizer.step()
+    torch.cuda.synchronize()
+    xolp, _, _, _ = opolar.polar_forward(cpu[("pol", 0, 0)].numpy())
+    outs = onets.forward_models(ref, cpu[("color_aug", 0, 0)], xolp)
+    ro = dict(outs)
+    for s in range(4):
+        ro[("depth", 0, s)] = ol.upsample_disp_to_depth(outs[("disp", s)], 64, 96, 0.1, 2.0)
+        assert (outputs[("disp", s)].detach().cpu() - outs[("disp", s)].detach()).abs().max().item() < 2e-5, f"disp {s}"
+    L = ol.compute_losses(cpu, ro, normals_loss_weight=0.35)
+    rel = abs(losses["loss"].item() - L["loss"].item()) / abs(L["loss"].item())
+    assert rel < 1e-4, (losses["loss"].item(), L["loss"].item())
+    assert torch.isfinite(tr.store.flat).all()
 
 
 def test_one_training_step_matches_oracle(tmp_path):
