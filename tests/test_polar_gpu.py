@@ -183,3 +183,21 @@ def test_rounding_test_path_equals_ieee_sequence_on_all_2_32_inputs(mode):
         ref_std = (ieee["xolp"] - mean) / std
         finite = torch.isfinite(ref_std)
         assert torch.equal(fast["xolp_std"][finite], ref_std[finite]), f"standardise, I0={i0}"
+
+
+def test_batch_is_split_when_planes_exceed_32bit_offsets():
+    """K1 indexes with 32 bits inside a launch; the host splits a batch whose output planes would exceed 2^30
+    elements per tensor (9 * H * Wout * images).  With 7744x7744 frames a single image fills a launch, so a batch
+    of two must equal the two single-image results."""
+    H = W = 7744
+    g = torch.Generator(device="cuda").manual_seed(3)
+    pol = torch.randint(0, 256, (2, 4, H, W), dtype=torch.uint8, device="cuda", generator=g)
+    both = pdpolar.polar_forward(pol, want=("xolp", "normals"))
+    for i in range(2):
+        one = pdpolar.polar_forward(pol[i:i + 1].contiguous(), want=("xolp", "normals"))
+        assert torch.equal(both["xolp"][i].view(torch.int32), one["xolp"][0].view(torch.int32))
+        assert torch.equal(both["normals"][i].view(torch.int32), one["normals"][0].view(torch.int32))
+    # spot-check a strip of the second image against the oracle
+    strip = pol[1:2, :, 4000:4004, 1000:1064].cpu().numpy()
+    xolp, _, _, _ = opolar.polar_forward(np.ascontiguousarray(strip))
+    assert torch.equal(both["xolp"][1, :, 4000:4004, 1000:1064].cpu(), xolp[0])
