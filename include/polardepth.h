@@ -112,6 +112,8 @@ int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tabl
  *       forward output grid [N,H,W,C=Cout_fwd], (Ho,Wo) is the forward INPUT grid, w is the
  *       transposed weight [Cin_fwd][KH][KW][Cout_fwd] from pd_weight_transpose)
  * act   0 none | 1 ReLU | 2 ELU(alpha=1) | 3 sigmoid      (applied after bias)
+ * out_scale  NULL or fp32 [Cout]: y = act(conv * out_scale + bias) -- an inference-mode BatchNorm folded into the
+ *       epilogue (scale = gamma / sqrt(var + eps), bias = beta - mean * scale + conv_bias * scale)
  * affine != 0: every in-bounds input tap is replaced by (x - sub) / div before the product
  *       (ShallowEncoder.normalizeInput pre_encoders.py:76-83, resnet_encoder.py:812), scalar path only.
  * stats  NULL or fp32 [pd_conv2d_stats_rows(M,Cout)][Cout][2]: per-workgroup column sums and sums
@@ -119,7 +121,7 @@ int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tabl
  */
 int pd_conv2d_tile_m(long M, int Cout);
 long pd_conv2d_stats_rows(long M, int Cout);
-int pd_conv2d(const void* x, const void* w, const void* bias, void* y, void* stats,
+int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
               int N, int H, int W, int C, long sN, long sH, long sW, long sC,
               int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode, int act,
               int affine, float sub, float div, long ldy, void* stream);

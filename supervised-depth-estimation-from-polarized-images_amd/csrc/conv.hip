@@ -40,6 +40,7 @@ struct ConvArgs {
     const float* x;
     const float* w;
     const float* bias;
+    const float* oscale;     // per-output-channel multiplier of the accumulator (folded BatchNorm) or null
     float* y;
     float* stats;            // [gridM][Co][2] or null
     int N, H, W, C;          // logical dims of x
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
         const int rows = rows_left < BM ? (int)rows_left : BM;
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)rows * a.ldy * 4));
         const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(a.bias ? a.bias : a.w, a.bias ? (unsigned)a.Co * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(a.oscale ? a.oscale : a.w, a.oscale ? (unsigned)a.Co * 4u : 0u);
         auto body = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
                 const int col = n0 + wn * WN + MT * j + col_l;
                 const bool cv = col < a.Co;
                 const float bv = a.bias ? buf_ld1(rb_, cv ? (unsigned)col * 4u : OOB) : 0.f;
+                const float sv = a.oscale ? buf_ld1(rs_, cv ? (unsigned)col * 4u : OOB) : 1.f;
                 float s1 = 0.f, s2 = 0.f;
                 const int row_l = wm * WM + rbase;                      // this lane's first row in the tile
                 const unsigned off_l = (unsigned)(row_l * (int)a.ldy + col) * 4u;
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
                     for (int r = 0; r < ACCN; ++r) {
                         const int rr = MT * i + (MT == 32 ? (r & 3) + 8 * (r >> 2) : r);   // compile-time row step: scalar offset
                         const bool ok = cv & (row_l < rows - rr);
-                        float v = acc[i][j][r] + bv;
+                        float v = fmaf(acc[i][j][r], sv, bv);    // sv == 1: exactly acc + bv
                         const float vs = ok ? v : 0.f;
                         s1 += vs;
                         s2 += vs * vs;
@@ -406,7 +409,7 @@ extern "C" long pd_conv2d_stats_rows(long M, int Co) {
     return (M + bm - 1) / bm;
 }
 
-extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, void* y, void* stats,
+extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
                          int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                          int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
                          int affine, float sub, float div, long ldy, void* stream) {
@@ -429,7 +432,7 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, void* y
     }
     if (N == 0) return PD_OK;
     ConvArgs a;
-    a.x = (const float*)x; a.w = (const float*)w; a.bias = (const float*)bias; a.y = (float*)y; a.stats = (float*)stats;
+    a.x = (const float*)x; a.w = (const float*)w; a.bias = (const float*)bias; a.oscale = (const float*)out_scale; a.y = (float*)y; a.stats = (float*)stats;
     a.N = N; a.H = H; a.W = W; a.C = C; a.sN = sN; a.sH = sH; a.sW = sW; a.sC = sC;
     a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.mode = mode; a.act = act; a.affine = affine; a.sub = sub; a.div = div;

@@ -40,6 +40,7 @@ class DropoutState:
 # wait for the side stream through ``sync_wgrad_stream``.
 _WGRAD_STREAMS = {}
 USE_WGRAD_STREAM = os.environ.get("PD_WGRAD_STREAM", "1") == "1"
+USE_BN_FOLDING = os.environ.get("PD_BN_FOLDING", "1") != "0"   # inference: BatchNorm folded into the conv epilogue
 USE_DISP_HEADS = os.environ.get("PD_DISP_HEADS", "1") != "0"     # direct kernels for the 1-channel disparity heads
 USE_S2D_STEMS = os.environ.get("PD_S2D_STEMS", "1") == "1"
 
@@ -129,12 +130,13 @@ class BNParams:
 
 
 class ChainCfg:
-    __slots__ = ("stride", "pad", "relu_pre", "pool", "drop_p", "relu_post", "affine", "bn", "seed", "offset")
+    __slots__ = ("stride", "pad", "relu_pre", "pool", "drop_p", "relu_post", "affine", "bn", "seed", "offset", "infer")
 
     def __init__(self, stride=1, pad=0, relu_pre=True, pool=False, drop_p=0.0, relu_post=False, affine=None, bn=None):
         self.stride, self.pad, self.relu_pre, self.pool = stride, pad, relu_pre, pool
         self.drop_p, self.relu_post, self.affine, self.bn = float(drop_p), relu_post, affine, bn
         self.seed = self.offset = 0
+        self.infer = False
 
 
 # ------------------------------------------------------------------ conv -> BN -> ReLU -> pool -> dropout -> +res -> ReLU
@@ -174,6 +176,8 @@ class ConvBNChainFn(torch.autograd.Function):
             out_hw = (x.shape[2], x.shape[3])
         else:
             w_eff, stride, pad, aff, out_hw = weight, cfg.stride, cfg.pad, cfg.affine, None
+        if getattr(cfg, "infer", False):
+            return ConvBNChainFn._inference(x, w_eff, bias, gamma, beta, res, cfg, stride, pad, aff, out_hw)
         if training:
             z, part = ops.conv2d_fwd(x, w_eff, bias, stride, pad, want_stats=True, affine=aff, out_hw=out_hw)
         else:
@@ -199,6 +203,33 @@ class ConvBNChainFn(torch.autograd.Function):
         ctx.cfg, ctx.drop, ctx.training, ctx.has_res = cfg, drop, training, res is not None
         ctx.params = (weight, bias, gamma, beta)
         ctx.save_for_backward(x, z, out, scale, shift, mean, invstd)
+        return out
+
+    @staticmethod
+    def _inference(x, w, bias, gamma, beta, res, cfg, stride, pad, aff, out_hw):
+        """Inference (eval mode, no autograd): the BatchNorm is folded into the conv epilogue,
+        y = relu(conv * scale + (shift + bias * scale)); plain blocks are ONE kernel, blocks with a max-pool, a
+        residual add or a post-add ReLU keep a (now affine-free) chain pass behind it."""
+        bn = cfg.bn
+        dev, N, Co = x.device, x.shape[0], w.shape[0]
+        scale, shift = _f32(dev, Co), _f32(dev, Co)
+        check(lib.pd_bn_fwd_finalize(None, 0, Co, 1.0, ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
+                                     bn.momentum, bn.eps, None, ptr(scale), ptr(shift), None, None, 0, stream_ptr()),
+              "pd_bn_fwd_finalize")
+        if bias is not None:
+            shift = torch.addcmul(shift, bias.detach(), scale)
+        act = ops.ACT_RELU if cfg.relu_pre else ops.ACT_NONE
+        y = ops.conv2d_fwd(x, w, shift, stride, pad, act=act, affine=aff, out_hw=out_hw, out_scale=scale)
+        if not (cfg.pool or res is not None or cfg.relu_post):
+            return y
+        _, _, Hz, Wz = y.shape
+        Ho, Wo = (Hz // 2, Wz // 2) if cfg.pool else (Hz, Wz)
+        out = ops.empty_nhwc(N, Co, Ho, Wo, dev)
+        ld_res = 0
+        if res is not None:
+            res, ld_res = nhwc_view(res)
+        check(lib.pd_chain_fwd(ptr(y), None, None, ptr(res), ptr(out), N, Hz, Wz, Co, ld_res, Co, 0, int(cfg.pool), 0.0,
+                               0, 0, int(cfg.relu_post), stream_ptr()), "pd_chain_fwd")
         return out
 
     @staticmethod
@@ -257,7 +288,15 @@ class ConvBNChainFn(torch.autograd.Function):
 
 def conv_bn_chain(x, conv, bn, cfg, res=None, training=True):
     cfg.bn = BNParams(bn, training)
+    # inference = eval mode outside autograd (decided here: inside Function.forward grad mode is always off)
+    cfg.infer = (not training) and (not torch.is_grad_enabled()) and USE_BN_FOLDING
+    if cfg.infer:
+        return ConvBNChainFn.forward(_NoCtx(), x, conv.weight, conv.bias, bn.weight, bn.bias, res, cfg)
     return ConvBNChainFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, res, cfg)
+
+
+class _NoCtx:
+    """Stand-in for the autograd context on the inference path (nothing is saved)."""
 
 
 # ------------------------------------------------------------------ decoder: reflect conv + activation

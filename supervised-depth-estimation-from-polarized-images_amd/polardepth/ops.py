@@ -60,15 +60,17 @@ def conv_out_size(h, k, s, p):
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, want_stats=False,
-               affine=None, out=None, out_hw=None):
-    """y = act(conv(x, w) + bias).  x: [N,C,H,W] any strides; returns channels_last [N,Co,Ho,Wo].
+               affine=None, out=None, out_hw=None, out_scale=None):
+    """y = act(conv(x, w) [* out_scale] + bias).  x: [N,C,H,W] any strides; returns channels_last [N,Co,Ho,Wo].
+
+    out_scale: optional fp32 [Co] multiplier of the accumulator (an inference-mode BatchNorm folded into the epilogue).
 
     want_stats -> also returns the per-workgroup BatchNorm partials [rows, Co, 2] (sum, sum of squares
     of the pre-activation output).  affine=(sub, div) applies (x-sub)/div to in-bounds input taps.
     out: optional pre-allocated NHWC tensor whose channel slice [:, c0:c0+Co] receives the result
     (pass the sliced view; its channel stride must be 1).
     """
-    _require_cuda(x, w, bias)
+    _require_cuda(x, w, bias, out_scale)
     N, C, H, W = x.shape
     Co, Ci, KH, KW = w.shape
     assert Ci == C, f"channel mismatch {Ci} vs {C}"
@@ -90,7 +92,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     sN, sC, sH, sW = x.stride()
     vec = C % 4 == 0 and sC == 1 and affine is None
     _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd"), 2.0 * N * Ho * Wo * Co * C * KH * KW,
-              lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
+              lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out_scale), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
                                           Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub,
                                           div, ldy, stream_ptr()), "pd_conv2d"),
               shape=("fwd", N, C, H, W, Co, KH, stride, mode))
@@ -120,7 +122,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None):
     sN, sC, sH, sW = dy.stride()
     # algorithmic flops of the data gradient = those of the forward conv it differentiates
     _profiled(_igemm_label(N * H * W, Ci, True, "dgrad"), 2.0 * N * Hy * Wy * Co * Ci * KH * KW,
-              lambda: check(lib.pd_conv2d(ptr(dy), ptr(wt), None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,
+              lambda: check(lib.pd_conv2d(ptr(dy), ptr(wt), None, None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,
                                           H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci,
                                           stream_ptr()), "pd_conv2d(dgrad)"),
               shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))
@@ -245,7 +247,7 @@ def gemm_nt(a, b, out=None):
     if out is None:
         out = torch.empty((M, Nn), dtype=torch.float32, device=a.device)
     _profiled(_igemm_label(M, Nn, K % 4 == 0, "gemm"), 2.0 * M * Nn * K,
-              lambda: check(lib.pd_conv2d(ptr(a), ptr(b), None, ptr(out), None, 1, M, 1, K, M * K, K, K, 1,
+              lambda: check(lib.pd_conv2d(ptr(a), ptr(b), None, None, ptr(out), None, 1, M, 1, K, M * K, K, K, 1,
                                           M, 1, Nn, 1, 1, 1, 0, MODE_ZERO, ACT_NONE, 0, 0.0, 1.0, out.stride(0),
                                           stream_ptr()), "pd_conv2d(gemm_nt)"))
     return out

@@ -184,3 +184,41 @@ def test_trainer_test_loop_runs_on_device_metrics(tmp_path, capsys):
     tr.test()
     out = capsys.readouterr().out
     assert "abs_rel" in out and "glass" in out and "nan" not in out.lower()
+
+
+def test_inference_with_folded_batchnorm_matches_oracle_and_unfolded_path(tmp_path):
+    """Eval mode under no_grad folds every BatchNorm into its conv epilogue (pd_conv2d out_scale); the disparities
+    must match the CPU oracle in eval mode and the unfolded kernels (conv -> finalize -> chain) to 2e-5 (fp32 rounding:
+    fma(acc, s, t) vs (acc + b) * s + t through ~20 layers)."""
+    from manydepth.trainer import Trainer
+    from polardepth import synthetic
+    from polardepth import functional as PF
+    from oracle import nets as onets, polar as opolar
+    tr = Trainer(_opts(tmp_path))
+    ref = onets.build_models(True, True, 0.1)
+    for name, m in ref.items():
+        fill_state_dict(m, 0, prefix=name + ".")
+        # non-trivial running statistics
+        for k, b in m.named_buffers():
+            if k.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=torch.Generator().manual_seed(len(k))))
+            elif k.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=torch.Generator().manual_seed(len(k) + 1)))
+        tr.models[name].load_state_dict(m.state_dict())
+        m.eval()
+    tr.set_eval()
+    batch = synthetic.make_batch(2, 64, 96, frame_w=92, device="cuda", seed=11)
+    assert PF.USE_BN_FOLDING
+    with torch.no_grad():
+        folded = tr._forward_models(dict(batch))
+        PF.USE_BN_FOLDING = False
+        try:
+            plain = tr._forward_models(dict(batch))
+        finally:
+            PF.USE_BN_FOLDING = True
+        xolp, _, _, _ = opolar.polar_forward(batch[("pol", 0, 0)].cpu().numpy())
+        outs = onets.forward_models(ref, batch[("color_aug", 0, 0)].cpu(), xolp)
+    for s in range(4):
+        f, p = folded[("disp", s)].cpu(), plain[("disp", s)].cpu()
+        assert (f - p).abs().max().item() < 2e-5, f"folded vs unfolded, scale {s}"
+        assert (f - outs[("disp", s)]).abs().max().item() < 2e-5, f"folded vs oracle, scale {s}"
