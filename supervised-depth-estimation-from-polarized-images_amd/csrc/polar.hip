@@ -20,7 +20,7 @@
 //     sorted key array gives p = #{merged keys < rho}; a rank table maps p to the three
 //     per-table counts (= the three searchsorted results).  The per-bin (x_lo, y_lo, slope)
 //     (x_lo, slope) pairs are precomputed in fp64 with the operations scipy performs, next to
-//     sin/cos(y_lo).  Keys, a sqrt(rho) bucket index, ranks and bins (90 KB) live in LDS.
+//     sin/cos(y_lo).  Keys, a sqrt(rho) bucket index, ranks and bins (96 KB) live in LDS.
 //   * normals: cos/sin(phi) in fp32 (torch CPU computes them on the fp32 tensor),
 //     promoted and multiplied with the fp64 sin/cos(theta), rounded to fp32.  Inside the tables
 //     sin/cos(theta) = angle addition of the tabulated sin/cos(y_lo) with a Taylor series of the
@@ -37,8 +37,9 @@
 
 namespace {
 
-constexpr uint32_t kMagic = 0x50444c33u;  // "PDL3"
-constexpr int kBuckets = 1024;            // sqrt(rho) buckets of the guided search
+constexpr uint32_t kMagic = 0x50444c34u;  // "PDL4"
+constexpr int kBuckets = 4096;            // sqrt(rho) buckets of the guided search (<= 4 keys in three buckets
+                                          // for 99.6 % of the default tables' range)
 constexpr int kLutSide = 511;
 constexpr int kLutCount = kLutSide * kLutSide;
 
@@ -66,7 +67,7 @@ static_assert(sizeof(PolarHeader) == 64, "header size");
 // bins[] in LDS:  float fbins[nk][8] = x_lo32 (= floor32 x_lo), (float)(x_lo - x_lo32), (float)slope,
 //                                      s = (float)sin, (float)(sin - s), c = (float)cos, (float)(cos - c), 0
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-inline int keys_padded(int nk) { return (nk + 3) / 4 * 4; }
+inline int keys_padded(int nk) { return (nk + 3) / 4 * 4 + 4; }   // +inf padding: four keys are read at once
 inline size_t lds_off_bstart(int nk) { return size_t(keys_padded(nk)) * 4; }
 inline size_t lds_off_rank(int nk) { return lds_off_bstart(nk) + size_t(kBuckets + 4) * 2 + 8; }
 inline size_t lds_off_bins(int nk) { return round_up(lds_off_rank(nk) + size_t(nk + 1) * 8, 16); }
@@ -226,7 +227,7 @@ __device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char
     for (int i = threadIdx.x; i < n16 - ncommon; i += nthreads) dst[ncommon + i] = bsrc[i];
     t.n_d = h->n_d; t.n_s1 = h->n_s1; t.n_s2 = h->n_s2;
     t.nk = t.n_d + t.n_s1 + t.n_s2;
-    const int nkp = (t.nk + 3) / 4 * 4;
+    const int nkp = (t.nk + 3) / 4 * 4 + 4;
     const int off_rank = nkp * 4 + (kBuckets + 4) * 2 + 8;
     t.mkeys = reinterpret_cast<const float*>(smem);
     t.bstart = reinterpret_cast<const uint16_t*>(smem + nkp * 4);
@@ -336,9 +337,15 @@ __device__ __forceinline__ void normals9(float rho, float phi, const Tabs& t, fl
     const float u = sqrtf(fmaxf(rho, 0.f)) * t.bscale;
     const int bk = (int)fminf(u, (float)kBuckets);
     int lo = t.bstart[max(bk - 1, 0)], hi = t.bstart[bk + 2];
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (t.mkeys[mid] < rho) lo = mid + 1; else hi = mid;
+    if (hi - lo <= 4) {
+        // the usual case: at most four candidate keys -> four independent LDS reads instead of a dependent
+        // binary-search chain (keys at or beyond hi are > rho, the array is padded with +inf)
+        lo += (t.mkeys[lo] < rho) + (t.mkeys[lo + 1] < rho) + (t.mkeys[lo + 2] < rho) + (t.mkeys[lo + 3] < rho);
+    } else {
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (t.mkeys[mid] < rho) lo = mid + 1; else hi = mid;
+        }
     }
     const uint2 rk = t.rank[lo];
     const bool isnan_ = rho != rho;   // NaN sorts last (numpy)
@@ -463,7 +470,7 @@ __device__ __forceinline__ float standardise(float x) {
 
 constexpr int kThreads = 512;    // XOLP-only kernels: 4 workgroups per CU
 constexpr int kThreadsN = 768;   // kernels with the fp64 normals: one 12-wave workgroup per CU (3 waves/SIMD, <= 168 VGPRs);
-                                 // its 90 KB LDS image of the tables is staged once per CU
+                                 // its 96 KB LDS image of the tables is staged once per CU
 
 constexpr int kThreadsF = 1024;  // fast (fp32) normals: 112 VGPRs -> one 16-wave workgroup per CU (4 waves/SIMD)
 
@@ -684,7 +691,7 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
     const bool pitched = Wout != W;
     const bool need_normals = normals != nullptr || ints != nullptr;
     const bool precise = (flags & PD_POLAR_FAST_NORMALS) == 0;
-    // LDS image size is fixed by the table node counts (90,072 bytes for the default 1000/625/375 nodes)
+    // LDS image size is fixed by the table node counts (96,232 bytes for the default 1000/625/375 nodes)
     const size_t lds = need_normals ? lds_from_blob_bytes(tables_bytes) : 0;
     PD_REQUIRE(!need_normals || (lds > 0 && lds <= 160 * 1024), "pd_polar_fwd: tables blob has an unexpected size");
     const int nth = need_normals ? (precise ? kThreadsN : kThreadsF) : kThreads;
@@ -701,7 +708,7 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
         g.P = (unsigned)P; g.Pout = (unsigned)Pout; g.flags = flags;
         const long total = (long)nb * (Pout / 4);
         long blocks = (total + nth - 1) / nth;
-        // with normals: persistent, one workgroup per CU (the 90 KB table image is staged once per CU);
+        // with normals: persistent, one workgroup per CU (the 96 KB table image is staged once per CU);
         // XOLP only: no tables to amortise -> one quad per thread, hardware-scheduled (measured 1.4x faster)
         if (need_normals && blocks > 256) blocks = 256;
         const long step = blocks * nth;

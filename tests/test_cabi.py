@@ -38,8 +38,11 @@ def test_table_blob_numpy_vs_oracle_tables():
         np.testing.assert_array_equal(y, t[k][1])
 
 
-def _blob_offsets(nk=2000, buckets=1024):
-    off_bstart = nk * 4
+BUCKETS = 4096
+
+
+def _blob_offsets(nk=2000, buckets=BUCKETS):
+    off_bstart = ((nk + 3) // 4 * 4 + 4) * 4        # keys padded with +inf: four are read at once
     off_rank = off_bstart + (buckets + 4) * 2 + 8
     off_bins = (off_rank + (nk + 1) * 8 + 15) // 16 * 16
     return off_bstart, off_rank, off_bins
@@ -48,7 +51,7 @@ def _blob_offsets(nk=2000, buckets=1024):
 def test_table_blob_layout_and_lut():
     blob = pdpolar.pack_tables(pdpolar.theta_tables_numpy(1.5)).numpy().tobytes()
     hdr = np.frombuffer(blob[:32], dtype=np.uint32)
-    assert hdr[0] == 0x50444c33 and tuple(hdr[1:4]) == (1000, 625, 375)
+    assert hdr[0] == 0x50444c34 and tuple(hdr[1:4]) == (1000, 625, 375)
     off_lut, off_lds, lds_bytes, total = (int(v) for v in hdr[4:8])
     assert total == len(blob) and lds_bytes <= 160 * 1024
     lut = np.frombuffer(blob[off_lut:off_lut + 511 * 511 * 4], dtype=np.float32).reshape(511, 511)
@@ -72,12 +75,15 @@ def test_table_blob_layout_and_lut():
     for t in range(3):
         np.testing.assert_array_equal(rank[pos, t], np.searchsorted(tabs[t], q.astype(np.float64), side="left"))
     # sqrt(rho) bucket index: the true position always lies in [bstart[b-1], bstart[b+2]] for the device's b
-    bstart = np.frombuffer(img[off_bstart:off_bstart + 1028 * 2], dtype=np.uint16).astype(int)
-    bscale = np.frombuffer(img[off_bstart + 1028 * 2:off_bstart + 1028 * 2 + 4], dtype=np.float32)[0]
-    assert np.all(np.diff(bstart) >= 0) and bstart[0] == 0 and bstart[1025] == nk
-    b = np.minimum(np.sqrt(np.maximum(q, 0)).astype(np.float32) * bscale, 1024).astype(int)
+    nb = BUCKETS + 4
+    bstart = np.frombuffer(img[off_bstart:off_bstart + nb * 2], dtype=np.uint16).astype(int)
+    bscale = np.frombuffer(img[off_bstart + nb * 2:off_bstart + nb * 2 + 4], dtype=np.float32)[0]
+    assert np.all(np.diff(bstart) >= 0) and bstart[0] == 0 and bstart[BUCKETS + 1] == nk
+    b = np.minimum(np.sqrt(np.maximum(q, 0)).astype(np.float32) * bscale, BUCKETS).astype(int)
     assert np.all(bstart[np.maximum(b - 1, 0)] <= pos) and np.all(pos <= bstart[b + 2])
-    assert (bstart[2:] - bstart[:-2]).max() <= 64          # the guided range stays small everywhere
+    span = bstart[3:] - bstart[:-3]
+    assert span.max() <= 32 and (span > 4).mean() < 0.01   # <= 4 candidate keys (one read each) almost everywhere
+    assert np.all(np.isinf(np.frombuffer(img[nk * 4:off_bstart], dtype=np.float32)))   # +inf key padding
     bins = np.frombuffer(img[off_bins:off_bins + nk * 32], dtype=np.float64).reshape(nk, 4)
     x, y = opolar.theta_tables(1.5)["diffuse"]
     np.testing.assert_array_equal(bins[1:1000, 0], x[:-1])
