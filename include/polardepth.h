@@ -249,6 +249,15 @@ int pd_depth_metrics(const void* gt, const void* pred, const void* mask, int mas
 int pd_softmax_rows_fwd(void* x, long R, long L, float scale, void* stream);
 int pd_softmax_rows_bwd(const void* p, void* dp, long R, long L, float scale, void* stream);
 
+/* ---- fused attention (flash-attention recurrence on the fp32 matrix cores).
+ * q, k, v, o, do, dq, dk, dv: [N][T][128] fp32 (token-major = NHWC), lse / delta: [N][T] fp32; T % 32 == 0.
+ * pd_attn_fwd:  o = softmax(q k^T * scale) v,  lse = log sum exp of the scaled scores (saved for the backward). */
+int pd_attn_fwd(const void* q, const void* k, const void* v, void* o, void* lse, int N, int T, int C, float scale,
+                void* stream);
+/* pd_attn_bwd: dq, dk, dv from do (recomputing the scores block by block); delta [N][T] is scratch (sum_c do*o). */
+int pd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const void* lse,
+                void* delta, void* dq, void* dk, void* dv, int N, int T, int C, float scale, void* stream);
+
 /* ---- disparity heads: sigmoid(Conv3x3(x)) with one output channel
  * (manydepth/networks/depth_decoder.py:52-53,69-71; layers.py:364-380 Conv3x3 = ReflectionPad2d(1) + Conv2d(C,1,3)).
  * Direct memory-bound kernels instead of a 32-wide MFMA tile with one useful column.

@@ -40,6 +40,7 @@ class DropoutState:
 # wait for the side stream through ``sync_wgrad_stream``.
 _WGRAD_STREAMS = {}
 USE_WGRAD_STREAM = os.environ.get("PD_WGRAD_STREAM", "1") == "1"
+USE_FLASH_ATTENTION = os.environ.get("PD_FLASH_ATTENTION", "1") != "0"   # fused attention kernels (config 5)
 USE_BN_FOLDING = os.environ.get("PD_BN_FOLDING", "1") != "0"   # inference: BatchNorm folded into the conv epilogue
 USE_DISP_HEADS = os.environ.get("PD_DISP_HEADS", "1") != "0"     # direct kernels for the 1-channel disparity heads
 USE_S2D_STEMS = os.environ.get("PD_S2D_STEMS", "1") == "1"
@@ -526,7 +527,39 @@ class SelfAttentionFn(torch.autograd.Function):
         return dq, dk, dv
 
 
+class FlashAttentionFn(torch.autograd.Function):
+    """The same attention as one fused kernel per direction (pd_attn_fwd / pd_attn_bwd): scores never leave the
+    registers (flash-attention recurrence on the fp32 matrix cores); needs C == 128 and T % 32 == 0."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = ops.as_nhwc(q), ops.as_nhwc(k), ops.as_nhwc(v)
+        N, C, H, W = q.shape
+        T = H * W
+        scale = 1.0 / (C ** 0.5)
+        o = ops.empty_nhwc(N, C, H, W, q.device)
+        lse = torch.empty((N, T), dtype=torch.float32, device=q.device)
+        check(lib.pd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), N, T, C, scale, stream_ptr()), "pd_attn_fwd")
+        ctx.scale = scale
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        N, C, H, W = q.shape
+        T = H * W
+        do = ops.as_nhwc(do)
+        dq, dk, dv = (ops.empty_nhwc(N, C, H, W, do.device) for _ in range(3))
+        delta = torch.empty_like(lse)
+        check(lib.pd_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                              N, T, C, ctx.scale, stream_ptr()), "pd_attn_bwd")
+        return dq, dk, dv
+
+
 def self_attention(q, k, v):
+    if USE_FLASH_ATTENTION and q.shape[1] == 128 and (q.shape[2] * q.shape[3]) % 32 == 0:
+        return FlashAttentionFn.apply(q, k, v)
     return SelfAttentionFn.apply(q, k, v)
 
 

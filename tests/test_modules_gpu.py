@@ -147,7 +147,13 @@ def test_attention_variant_matches_oracle():
     g = torch.Generator().manual_seed(12)
     q, k, v = (torch.randn(2, 128, 8, 12, generator=g) for _ in range(3))
     qc, kc, vc = (t.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) for t in (q, k, v))
+    assert PF.USE_FLASH_ATTENTION
     o = PF.self_attention(qc, kc, vc)
+    assert o.grad_fn.__class__.__name__.startswith("FlashAttentionFn")      # 8 x 12 = 96 tokens: fused kernels
+    # the materialised-score path (any C, any T) must agree
+    q2, k2, v2 = (t.detach().clone().requires_grad_(True) for t in (qc, kc, vc))
+    o2 = PF.SelfAttentionFn.apply(q2, k2, v2)
+    _close(o2, o.detach().cpu(), FWD_TOL, "materialised vs fused attention")
     qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
     tok = lambda t: t.flatten(2).transpose(1, 2)
     ref = (torch.softmax(tok(qr) @ tok(kr).transpose(1, 2) / 128 ** 0.5, -1) @ tok(vr)).transpose(1, 2).reshape(2, 128, 8, 12)
