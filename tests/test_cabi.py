@@ -121,3 +121,20 @@ def test_bad_arguments_are_rejected():
     import torch
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pdpolar.polar_forward(torch.zeros(1, 4, 4, 4, dtype=torch.uint8))
+
+
+def test_shape_validation_of_the_fused_kernels_needs_no_gpu():
+    """Argument checks of the entry points added for the decoder heads and the attention block return PD_EINVAL (-22)
+    with a message before anything touches the device."""
+    L = _lib.lib
+    p = ctypes.c_void_p(16)      # a non-null, 16-byte aligned dummy: never dereferenced on these paths
+    assert L.pd_attn_fwd(p, p, p, p, p, 1, 96, 64, 0.1, None) == -22 and b"head dimension" in L.pd_last_error()
+    assert L.pd_attn_fwd(p, p, p, p, p, 1, 100, 128, 0.1, None) == -22 and b"multiple of 32" in L.pd_last_error()
+    assert L.pd_attn_bwd(p, p, p, p, p, p, p, p, p, p, 1, 100, 128, 0.1, None) == -22
+    assert L.pd_attn_fwd(None, None, None, None, None, 0, 96, 128, 0.1, None) == 0          # empty batch
+    assert L.pd_disphead_fwd(p, p, p, p, 1, 8, 8, 24, None) == -22 and b"C=24" in L.pd_last_error()
+    assert L.pd_disphead_fwd(p, p, p, p, 1, 1, 8, 16, None) == -22 and b"reflection" in L.pd_last_error()
+    assert L.pd_disphead_bwd_weight(p, p, p, p, p, p, 16, 1, 8, 8, 16, 1, None) == -22 and b"workspace" in L.pd_last_error()
+    assert L.pd_disphead_workspace(16) == 1024 * (9 * 16 + 1) * 4
+    assert L.pd_conv2d(p, p, None, None, p, None, 1, 8, 8, 16, 1024, 128, 16, 1, 8, 8, 16, 3, 3, 1, 1, 0, 0, 0, 0.0, 1.0,
+                       8, None) == -22 and b"row stride" in L.pd_last_error()
