@@ -199,6 +199,24 @@ def main():
                 "all_conv_kernels_TFLOPs": round(sum(v[0] for v in by_kernel.values()) / 2 /
                                                  max(step_conv_time, 1e-9) / 1e12, 2)}
 
+    # ---- second half of the metric ("XOLP-kernel GB/s"): K1 exactly as the step calls it (512x612 planes in,
+    # XOLP + 9-channel normals out on the 512x640 pitch), kernel-only time by HIP events, algorithmic bytes
+    # = 4 B read + (8 + 36) B written per frame pixel
+    from polardepth import polar as pdpolar
+    pol = batch[("pol", 0, 0)]
+    k1_out = pdpolar.polar_forward(pol, want=("xolp", "normals"), out_width=W)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for e0, e1 in evs:
+        e0.record()
+        pdpolar.polar_forward(pol, want=("xolp", "normals"), out_width=W, out=k1_out)
+        e1.record()
+    torch.cuda.synchronize()
+    k1_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2]
+    k1_bytes = args.batch * H * FRAME_W * 48
+    xolp_kernel = {"kernel": "polar_kernel<LS,normals,precise>", "bound": "hbm", "achieved": round(k1_bytes / k1_ms / 1e6, 1),
+                   "peak": 8000.0, "unit": "GB/s", "frac": round(k1_bytes / k1_ms / 1e6 / 8000.0, 4),
+                   "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": round(k1_ms, 4)}
+
     result = {
         "metric": "train images/sec (512x612, 3-encoder)", "value": round(args.batch * world * args.steps / dt, 3),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,7 +229,7 @@ def main():
                    "global_batch": args.batch * world, "height": H, "width": W, "frame_width": FRAME_W,
                    "parallelism": f"dp{world}"},
         "final_loss": round(loss_val, 6), "host_enqueue_ms_per_step": None if t_host is None else round(t_host * 1e3, 2),
-        "roofline": roofline,
+        "roofline": roofline, "xolp_kernel": xolp_kernel,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.attention:
         result["cpu_baseline"] = cpu_baseline()
