@@ -249,6 +249,14 @@ int pd_depth_metrics(const void* gt, const void* pred, const void* mask, int mas
 int pd_softmax_rows_fwd(void* x, long R, long L, float scale, void* stream);
 int pd_softmax_rows_bwd(const void* p, void* dp, long R, long L, float scale, void* stream);
 
+/* ---- Pillow-compatible 8-bit LANCZOS resampling of uint8 planes (Image.resize(..., Image.ANTIALIAS),
+ * indoor_dataset.py:335-349): one pass of ImagingResample's 8bpc branch.
+ * src [P][Hs][Ws] uint8; vertical == 0: dst [P][Hs][out_size] (horizontal pass), else dst [P][out_size][Ws].
+ * coeffs int32 [out_size][ksize] (22-bit fixed point), bounds int32 [out_size][2] = (first input index, count):
+ * Pillow's precompute_coeffs + normalize_coeffs_8bpc, built by polardepth/resize.py on the host. */
+int pd_resize_u8_pass(const void* src, void* dst, const void* coeffs, const void* bounds, int ksize, int P, int Hs,
+                      int Ws, int out_size, int vertical, void* stream);
+
 /* ---- fused attention (flash-attention recurrence on the fp32 matrix cores).
  * q, k, v, o, do, dq, dk, dv: [N][T][128] fp32 (token-major = NHWC), lse / delta: [N][T] fp32; T % 32 == 0.
  * pd_attn_fwd:  o = softmax(q k^T * scale) v,  lse = log sum exp of the scaled scores (saved for the backward). */

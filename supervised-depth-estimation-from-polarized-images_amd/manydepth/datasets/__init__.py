@@ -23,8 +23,11 @@ from torch.utils.data import Dataset
 class HAMMER_Dataset(Dataset):
     def __init__(self, data_path, filenames, height, width, frame_idxs, num_scales, is_train=False, img_ext='.png',
                  offset=10, modality="polarization", supervised_depth=True, supervised_depth_only=True,
-                 depth_modality="_gt", items_per_scene=8):
+                 depth_modality="_gt", items_per_scene=8, raw_pol=None):
         super().__init__()
+        # raw_pol: hand the four polarizer images over at their native size; the Trainer resizes them on the device
+        # with the Pillow-exact LANCZOS kernels before K1.  Default: $PD_DEVICE_RESIZE == "1".
+        self.raw_pol = (os.environ.get("PD_DEVICE_RESIZE") == "1") if raw_pol is None else bool(raw_pol)
         self.data_path, self.modality, self.depth_modality, self.img_ext = data_path, modality, depth_modality, img_ext
         self.height, self.width, self.num_scales = height, width, num_scales
         self.filenames = list(filenames) if filenames else ["synthetic_scene"]
@@ -58,8 +61,9 @@ class HAMMER_Dataset(Dataset):
             prev = prev.resize((W >> s, H >> s), Image.LANCZOS)
             inputs[("color", 0, s)] = to_t(prev)
             inputs[("color_aug", 0, s)] = inputs[("color", 0, s)]
-        planes = [np.asarray(Image.open(os.path.join(folder, d, name)).convert("L").resize((W, H), Image.LANCZOS))
-                  for d in ("pol00", "pol01", "pol10", "pol11")]                  # 0, 45, 90, 135 degrees
+        pol_imgs = [Image.open(os.path.join(folder, d, name)).convert("L")
+                    for d in ("pol00", "pol01", "pol10", "pol11")]                # 0, 45, 90, 135 degrees
+        planes = [np.asarray(im if self.raw_pol else im.resize((W, H), Image.LANCZOS)) for im in pol_imgs]
         inputs[("pol", 0, 0)] = torch.from_numpy(np.stack(planes).astype(np.uint8))
 
         def depth_of(sub):                        # 16-bit PNG in mm -> metres, nearest resize (hammer_dataset.py:135-169)

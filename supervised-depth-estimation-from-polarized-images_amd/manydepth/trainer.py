@@ -31,6 +31,7 @@ from .layers import SSIM, compute_depth_errors, compute_depth_errors_numpy
 from manydepth import datasets, networks
 from polardepth import functional as PF
 from polardepth import polar as pdpolar
+from polardepth import resize as pdresize
 from polardepth import ops
 from polardepth.engine import ParamStore, FusedAdam, GradReducer
 from polardepth._lib import lib, check, ptr, stream_ptr
@@ -235,6 +236,9 @@ class Trainer:
         if ("pol", 0, 0) in inputs and (self.opt.augment_xolp or self.opt.augment_normals):
             want = ["xolp"] + (["normals"] if self.opt.augment_normals else [])
             pol = inputs[("pol", 0, 0)]
+            if pol.shape[2] != self.opt.height or pol.shape[3] > self.opt.width:
+                # raw frames from the loader (HAMMER_Dataset(raw_pol=True)): Pillow-exact LANCZOS resize on the device
+                pol = pdresize.resize_lanczos_u8(pol, (self.opt.height, self.opt.width))
             # planes narrower than the network width (512x612 frames -> 512x640): K1 pads on the fly
             out = pdpolar.polar_forward(pol, want=tuple(want),
                                         out_width=self.opt.width if pol.shape[3] < self.opt.width else None)

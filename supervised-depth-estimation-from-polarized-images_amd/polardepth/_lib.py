@@ -67,6 +67,7 @@ SIGNATURES = {
     "pd_loss_weights": (_i, [_vp, _ip, _i, _f, _f, _vp, _vp]),
     "pd_softmax_rows_fwd": (_i, [_vp, _l, _l, _f, _vp]),
     "pd_softmax_rows_bwd": (_i, [_vp, _vp, _l, _l, _f, _vp]),
+    "pd_resize_u8_pass": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pd_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "pd_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "pd_disphead_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -126,8 +126,32 @@ def test_hammer_dataset_reads_a_real_tree_and_falls_back_to_synthetic(tmp_path):
     K = it[("K", 0)]
     assert abs(K[0, 0].item() - 80 / 128 * 96) < 1e-4 and abs(K[1, 2].item() - 48 / 96 * 64) < 1e-4
     assert torch.allclose(it[("K", 1)][0, 0], K[0, 0] / 2)
+    raw = HAMMER_Dataset(str(tmp_path), ["scene1_traj1_1"], 64, 96, [0], 4, is_train=True, raw_pol=True)[0]
+    assert raw[("pol", 0, 0)].shape == (4, 96, 128) and raw[("color", 0, 0)].shape == (3, 64, 96)   # planes stay native
     synth = HAMMER_Dataset("does/not/exist", ["a"], 64, 96, [0], 4)
     s = synth[0]
     assert set(it.keys()) == set(s.keys())
     for k in it:
         assert it[k].dtype == s[k].dtype and it[k].shape == s[k].shape, k
+
+
+def test_lanczos_coefficient_tables_reproduce_pillow_on_the_host():
+    """polardepth.resize.lanczos_coeffs (Pillow's precompute_coeffs / normalize_coeffs_8bpc) applied with NumPy
+    integer arithmetic equals PIL's LANCZOS resize -- pins the tables the device kernels consume."""
+    from PIL import Image
+    from polardepth.resize import lanczos_coeffs, PRECISION_BITS
+    rng = np.random.default_rng(2)
+    for Hs, Ws, Hd, Wd in ((104, 136, 64, 76), (40, 50, 64, 96)):
+        img = rng.integers(0, 256, (Hs, Ws), dtype=np.uint8)
+        cur = img
+        for axis, (n_in, n_out) in ((1, (Ws, Wd)), (0, (Hs, Hd))):
+            kk, b = lanczos_coeffs(n_in, n_out)
+            src = cur if axis == 1 else cur.T
+            out = np.zeros((src.shape[0], n_out), np.uint8)
+            for xx in range(n_out):
+                x0, n = b[xx]
+                acc = (1 << (PRECISION_BITS - 1)) + (src[:, x0:x0 + n].astype(np.int64) * kk[xx, :n]).sum(1)
+                out[:, xx] = np.clip(acc >> PRECISION_BITS, 0, 255)
+            cur = out if axis == 1 else out.T
+        ref = np.asarray(Image.fromarray(img, "L").resize((Wd, Hd), Image.LANCZOS))
+        np.testing.assert_array_equal(cur, ref)

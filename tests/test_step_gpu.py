@@ -222,3 +222,24 @@ def test_inference_with_folded_batchnorm_matches_oracle_and_unfolded_path(tmp_pa
         f, p = folded[("disp", s)].cpu(), plain[("disp", s)].cpu()
         assert (f - p).abs().max().item() < 2e-5, f"folded vs unfolded, scale {s}"
         assert (f - outs[("disp", s)]).abs().max().item() < 2e-5, f"folded vs oracle, scale {s}"
+
+
+def test_raw_planes_are_resized_on_the_device_like_pillow(tmp_path):
+    """Loader hand-over of native-size polarizer frames (HAMMER_Dataset(raw_pol=True)): the Trainer's device LANCZOS
+    resize + K1 gives the same XOLP input and loss as PIL-resized planes."""
+    from PIL import Image
+    from manydepth.trainer import Trainer
+    from polardepth import synthetic
+    tr = Trainer(_opts(tmp_path))
+    tr.set_eval()
+    batch = synthetic.make_batch(2, 64, 96, frame_w=96, device="cuda", seed=4)
+    raw = torch.randint(0, 256, (2, 4, 160, 208), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    host = torch.from_numpy(np.stack([[np.asarray(Image.fromarray(raw[b, c].numpy(), "L").resize((96, 64), Image.LANCZOS))
+                                       for c in range(4)] for b in range(2)]))
+    with torch.no_grad():
+        b1 = dict(batch); b1[("pol", 0, 0)] = raw.cuda()
+        o1, l1, _ = tr.process_batch(b1)
+        b2 = dict(batch); b2[("pol", 0, 0)] = host.cuda()
+        o2, l2, _ = tr.process_batch(b2)
+    assert torch.equal(b1[("xolp", 0, 0)], b2[("xolp", 0, 0)])
+    assert torch.equal(o1[("disp", 0)], o2[("disp", 0)]) and torch.equal(l1["loss"], l2["loss"])
