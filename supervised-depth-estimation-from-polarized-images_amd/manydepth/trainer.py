@@ -196,10 +196,12 @@ class Trainer:
 
     # ------------------------------------------------------------------ training loop (trainer.py:379-467)
     def train(self):
-        self.epoch, self.step = 0, 0
+        # a loaded trainer_state.pth continues where the checkpoint stopped (the reference restarts at epoch 0)
+        first_epoch = getattr(self, "resume_epoch", 0)
+        self.epoch, self.step = first_epoch, getattr(self, "resume_step", 0)
         self.test()
         self.start_time = time.time()
-        for self.epoch in range(self.opt.num_epochs):
+        for self.epoch in range(first_epoch, self.opt.num_epochs):
             self.run_epoch()
             if (self.epoch + 1) % self.opt.save_frequency == 0:
                 self.save_model()
@@ -420,6 +422,10 @@ class Trainer:
             sd = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
             torch.save(sd, os.path.join(save_folder, "{}.pth".format(model_name)))
         torch.save(self.model_optimizer.state_dict(), os.path.join(save_folder, "adam.pth"))
+        # resume state (not in the reference, which restarts epoch/step/LR schedule on load)
+        torch.save({"epoch": self.epoch, "step": self.step, "lr_scheduler": self.model_lr_scheduler.state_dict(),
+                    "dropout_seed": PF.DropoutState.seed, "dropout_offset": PF.DropoutState.offset},
+                   os.path.join(save_folder, "trainer_state.pth"))
 
     def _load_into(self, name, path, strict=False):
         model_dict = self.models[name].state_dict()
@@ -448,3 +454,9 @@ class Trainer:
                 self.model_optimizer.load_state_dict(torch.load(opt_path, map_location=self.device))
             except (ValueError, KeyError):
                 print("Can't load Adam - using random")
+        state_path = os.path.join(folder, "trainer_state.pth")
+        if os.path.isfile(state_path) and getattr(self.opt, "resume_state", True):
+            st = torch.load(state_path, map_location="cpu")
+            self.resume_epoch, self.resume_step = int(st["epoch"]) + 1, int(st["step"])
+            self.model_lr_scheduler.load_state_dict(st["lr_scheduler"])
+            PF.DropoutState.seed, PF.DropoutState.offset = int(st["dropout_seed"]), int(st["dropout_offset"])

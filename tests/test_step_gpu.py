@@ -143,7 +143,7 @@ def test_checkpoint_roundtrip_and_eval_mode(tmp_path):
     tr.save_model()
     folder = os.path.join(tr.log_path, "models", "weights_0")
     assert sorted(os.listdir(folder)) == ["adam.pth", "joint_encoder.pth", "mono_depth.pth", "normals_encoder.pth",
-                                          "rgb_encoder.pth", "xolp_encoder.pth"]
+                                          "rgb_encoder.pth", "trainer_state.pth", "xolp_encoder.pth"]
     sd = torch.load(os.path.join(folder, "rgb_encoder.pth"))
     assert "encoder.layer4.1.bn2.running_var" in sd and sd["encoder.conv1.weight"].is_contiguous()
     tr.set_eval()
@@ -157,6 +157,7 @@ def test_checkpoint_roundtrip_and_eval_mode(tmp_path):
         out2, l2, _ = tr2.process_batch(dict(batch))
     assert torch.equal(out1[("disp", 0)], out2[("disp", 0)]) and torch.equal(l1["loss"], l2["loss"])
     assert tr2.model_optimizer.step_count == 1
+    assert (tr2.resume_epoch, tr2.resume_step) == (tr.epoch + 1, tr.step)        # trainer_state.pth: resume point
     assert torch.equal(tr2.model_optimizer.exp_avg, tr.model_optimizer.exp_avg)
 
 
