@@ -33,6 +33,9 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# the host driver of this pool only supports dmabuf IPC: RCCL between processes needs this (a no-op when already set)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
