@@ -52,10 +52,11 @@ int pd_version(void);
  */
 #define PD_POLAR_LS 0
 #define PD_POLAR_STOKES 1
-/* flags: default (0) = fp64 sin/cos(theta) rounded once and cos/sin(fl32(phi+pi/2)) like the reference;
- * PD_POLAR_FAST_NORMALS = fp32 angle addition on fp32 tables with residuals (|err| ~1e-7, cos/sin(phi+pi/2) by
- * identity), ~8 % faster.  DoLP / AoLP / index maps are bit-exact in both. */
-#define PD_POLAR_FAST_NORMALS 1
+/* flags: default (0) = fp32 theta trig (two-float bin constants, |err| <= ~3e-7; cos/sin(phi) from a LUT,
+ * cos/sin(phi+pi/2) by identity); PD_POLAR_PRECISE_NORMALS = fp64 sin/cos(theta) rounded once and
+ * cos/sin(fl32(phi+pi/2)) like the reference (~1e-7, slower: ALU-bound).  DoLP / AoLP / index maps are
+ * bit-exact in both. */
+#define PD_POLAR_PRECISE_NORMALS 1
 /* PD_POLAR_IEEE_RHO = evaluate the reference's fp64 sqrt/div sequence for every pixel instead of the
  * Newton-refined hardware seeds with a rounding test (same bits, ~1.3x the arithmetic); the exhaustive test
  * compares the two over all 2^32 uint8 quadruples. */

@@ -5,73 +5,79 @@
 //   standardised XOLP                        (manydepth/networks/pre_encoders.py:78-79)
 //   theta_diffuse, theta_spec1, theta_spec2  (manydepth/normals_vec.py:11-50, scipy _call_linear)
 //   the 9-channel physical normals           (manydepth/normals_vec.py:53-60, pre_encoders.py:99-113)
-// Memory-bound by design: 4 B/px read, 8..80 B/px written, every access a full
-// 4-byte (loads) or 16-byte (stores) per-lane vector on planar NCHW tensors.
+// Memory-bound by design: 4 B/px read, 8..80 B/px written, every access a full 4-byte (loads) or 16-byte
+// (stores) per-lane vector on planar NCHW tensors; outputs leave with nontemporal stores (a write-once
+// stream: +20 % on this access shape, tools/membench2.hip), the next quad's planes are loaded before the
+// current quad is computed.
 //
 // Exactness strategy
-//   * rho: the reference's fp64 op sequence (xolp.py:22-27) is executed literally in
-//     fp64 (IEEE sqrt / div / add, no FMA contraction in this file) and rounded once
-//     to fp32  ->  bit-equal to the CPU restatement.
-//   * phi: depends only on the integer pair (d1,d2) = (I0-I90, I45-I135) in
-//     [-255,255]^2; a 511x511 fp32 LUT built on the host in fp64 (L2-resident, 1 MB)
-//     gives the exactly-rounded value through integer indexing.
-//   * theta tables: searchsorted-left on fp32 keys floor32(x[i]) is exact for an fp32
-//     query.  The three tables are searched at once: ONE binary search over the merged,
-//     sorted key array gives p = #{merged keys < rho}; a rank table maps p to the three
-//     per-table counts (= the three searchsorted results).  The per-bin (x_lo, y_lo, slope)
-//     (x_lo, slope) pairs are precomputed in fp64 with the operations scipy performs, next to
-//     sin/cos(y_lo).  Keys, a sqrt(rho) bucket index, ranks and bins (96 KB) live in LDS.
-//   * normals: cos/sin(phi) in fp32 (torch CPU computes them on the fp32 tensor),
-//     promoted and multiplied with the fp64 sin/cos(theta), rounded to fp32.  Inside the tables
-//     sin/cos(theta) = angle addition of the tabulated sin/cos(y_lo) with a Taylor series of the
-//     sub-step delta (|delta| <= 1.6e-3 rad); extrapolated rho uses a 3-term Cody-Waite reduction
-//     + fdlibm kernels (< 1 ulp for |theta| < 1.6e6; LS mode reaches 1.4e2, Stokes mode 2.5e4).
+//   * rho: the reference's fp64 op sequence (xolp.py:22-27) rounded once to fp32 -> bit-equal to the CPU
+//     restatement (Newton-refined hardware seeds + Ziv's rounding test, literal IEEE sequence near midpoints).
+//   * phi: depends only on the integer pair (d1,d2) = (I0-I90, I45-I135) in [-255,255]^2; LUTs built on the
+//     host in fp64 (L2-resident) give the exactly rounded value through integer indexing: a 1 MB fp32 LUT
+//     (phi) and a 4 MB float4 LUT (phi, cos(fl32 phi), sin(fl32 phi)) for the fast normals.
+//   * theta tables: searchsorted-left on fp32 keys floor32(x[i]) is exact for an fp32 query.  All three tables
+//     are searched with ONE 16-byte LDS read: a monotone, exactly reproducible bucket function of rho (integer
+//     approximation of sqrt(rho): the tables are ~quadratic in theta) selects a record holding, per table, the
+//     number of keys in lower buckets and the single key inside the bucket; index = base + (key < rho), with
+//     scipy's clip(1, n-1) folded in by the host.  Buckets holding two or more keys of one table (rho within
+//     5e-3 of the specular maximum and a sliver near 0.004) are flagged and take exact binary searches.
+//   * normals, default (fast) path: theta - j*pi/2 = slope*(rho - x_lo) + c in fp32 with a two-float constant
+//     per bin (the bin knows its quadrant j), sin/cos by degree-9/8 polynomials on |r| < 0.79, products in fp32;
+//     |err| <= ~3e-7.  rho beyond the tables (extrapolation, |r| >= 0.79) and PD_POLAR_PRECISE_NORMALS take
+//     the fp64 path: angle addition of tabulated sin/cos(y_lo) with a Taylor series of the sub-step, or a
+//     3-term Cody-Waite reduction + fdlibm kernels (< 1 ulp for |theta| < 1.6e6).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #include "pd_common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
 
 namespace {
 
-constexpr uint32_t kMagic = 0x50444c34u;  // "PDL4"
-constexpr int kBuckets = 4096;            // sqrt(rho) buckets of the guided search (<= 4 keys in three buckets
-                                          // for 99.6 % of the default tables' range)
+constexpr uint32_t kMagic = 0x50444c35u;   // "PDL5"
+constexpr int kNB = 4096;                  // buckets of the one-read search
+constexpr uint32_t kSqrtMagic = 0x1fbd1df5u;   // as_float((bits(x) >> 1) + magic) ~ sqrt(x), monotone, integer-exact
 constexpr int kLutSide = 511;
 constexpr int kLutCount = kLutSide * kLutSide;
+constexpr int kMaxNodes = 1023;            // 10-bit bases in the bucket record
 
 struct PolarHeader {   // 64 bytes, little endian
     uint32_t magic;
     int32_t n_d, n_s1, n_s2;
-    uint32_t off_lut;    // float[511*511]
-    uint32_t off_lds;    // start of the LDS image (keys, then bins)
-    uint32_t lds_bytes;  // size of the LDS image (multiple of 16)
+    uint32_t off_lut;      // float[511*511]            phi
+    uint32_t off_lut4;     // float[511*511][4]         phi, cos(fl32 phi), sin(fl32 phi), 0
+    uint32_t off_img_fast;     // LDS image of the fast kernels:    buckets | keys | float4 fbins[nk] | pad to 1 KiB
+    uint32_t img_fast_bytes;
+    uint32_t off_img_precise;  // LDS image of the precise kernels: buckets | keys | double bins[nk][4] | pad to 1 KiB
+    uint32_t img_precise_bytes;
+    uint32_t common_bytes;     // buckets + keys = offset of the bins inside either image
     uint32_t total_bytes;
-    uint32_t off_bins32; // float[nk][8] fp32 image of the bins (fast normals), absolute offset
-    uint32_t img_bins;   // offset of the fp64 bins inside the LDS image (= bytes of the common part)
-    uint32_t pad[6];
+    float bscale;          // bucket = min(int(approx_sqrt(rho) * bscale), kNB - 1)
+    uint32_t n_buckets;
+    uint32_t pad[2];
 };
 static_assert(sizeof(PolarHeader) == 64, "header size");
 
-// LDS image layout (offsets relative to its start), nk = n_d + n_s1 + n_s2, nkp = nk rounded up to 4:
-//   float    mkeys[nkp]           all keys floor32(x) of the three tables, sorted ascending (+inf padding)
-//   uint16_t bstart[kBuckets + 4] bstart[b] = #{merged keys k : sqrt(k) < b * smax / kBuckets}; [kBuckets+1..] = nk
-//   float    bscale, pad          kBuckets / smax, smax = sqrt(largest finite key)   (8 bytes)
-//   uint16_t rank[nk + 1][4]      rank[p] = (#diffuse, #spec1, #spec2, 0) among the first p merged keys
-//   double   bins[nk][4]          per table (diffuse | spec1 | spec2), entry i describes bin idx == i:
-//                                 x_lo, slope, sin(y_lo), cos(y_lo)
-// After the image the blob carries the fp32 form of the bins used by the fast normals path, which replaces
-// bins[] in LDS:  float fbins[nk][8] = x_lo32 (= floor32 x_lo), (float)(x_lo - x_lo32), (float)slope,
-//                                      s = (float)sin, (float)(sin - s), c = (float)cos, (float)(cos - c), 0
+// Bucket record (16 bytes): x, y, z = the key (fp32 bits) of the diffuse / spec1 / spec2 table that lies inside the
+// bucket (+inf when none, or when clip(1, n-1) makes the comparison irrelevant); w = base_d | base_s1 << 10 |
+// base_s2 << 20 | multi << 30, base_T = clip(#{keys of T in lower buckets}, 1, n_T - 1).
+// keys[]: the three tables' keys floor32(x) back to back (diffuse | spec1 | spec2), for the flagged buckets.
+// Bin entry i of a table describes scipy's bin idx == i (x_lo = x[i-1]); entry 0 is unused:
+//   fast bins    float[nk][4]   x_lo32, slope32, c_hi, c_lo (bit 0 = quadrant j)
+//   precise bins double[nk][4]  x_lo, slope, sin(y_lo), cos(y_lo)
+// Each image is one contiguous, 1-KiB-padded range of the blob: a workgroup copies it to LDS with direct-to-LDS
+// loads (1 KiB per wave instruction).
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-inline int keys_padded(int nk) { return (nk + 3) / 4 * 4 + 4; }   // +inf padding: four keys are read at once
-inline size_t lds_off_bstart(int nk) { return size_t(keys_padded(nk)) * 4; }
-inline size_t lds_off_rank(int nk) { return lds_off_bstart(nk) + size_t(kBuckets + 4) * 2 + 8; }
-inline size_t lds_off_bins(int nk) { return round_up(lds_off_rank(nk) + size_t(nk + 1) * 8, 16); }
-inline size_t lds_image_bytes(int nk) { return round_up(lds_off_bins(nk) + size_t(nk) * 32, 16); }
+inline size_t keys_padded(int nk) { return round_up(size_t(nk), 4); }
+inline size_t common_bytes_for(int nk) { return size_t(kNB) * 16 + keys_padded(nk) * 4; }
+inline size_t lut_bytes() { return round_up(size_t(kLutCount) * 4, 16); }
+inline size_t lut4_bytes() { return size_t(kLutCount) * 16; }
+inline size_t img_bytes_for(int nk, bool precise) { return round_up(common_bytes_for(nk) + size_t(nk) * (precise ? 32 : 16), 1024); }
 
 float floor32(double x) {  // largest fp32 <= x
     float f = static_cast<float>(x);
@@ -79,12 +85,33 @@ float floor32(double x) {  // largest fp32 <= x
     return f;
 }
 
+// The bucket function, bit-identical on host and device (integer shift/add, one IEEE multiply, truncation).
+__host__ __device__ inline float approx_sqrt_bits(float rho) {
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(rho);
+#else
+    memcpy(&u, &rho, 4);
+#endif
+    if (static_cast<int32_t>(u) < 0) u = 0;          // negative values (and -0) sort below every key
+    u = (u >> 1) + kSqrtMagic;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float t; memcpy(&t, &u, 4); return t;
+#endif
+}
+__host__ __device__ inline int bucket_of(float rho, float bscale) {
+    const float v = approx_sqrt_bits(rho) * bscale;
+    return static_cast<int>(v < static_cast<float>(kNB - 1) ? v : static_cast<float>(kNB - 1));
+}
+
 }  // namespace
 
 extern "C" size_t pd_polar_tables_bytes(int n_d, int n_s1, int n_s2) {
     if (n_d < 2 || n_s1 < 2 || n_s2 < 2) return 0;
-    return sizeof(PolarHeader) + round_up(size_t(kLutCount) * 4, 16) + lds_image_bytes(n_d + n_s1 + n_s2) +
-           size_t(n_d + n_s1 + n_s2) * 32;
+    const int nk = n_d + n_s1 + n_s2;
+    return sizeof(PolarHeader) + lut_bytes() + lut4_bytes() + img_bytes_for(nk, false) + img_bytes_for(nk, true);
 }
 
 extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_d,
@@ -93,82 +120,113 @@ extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_
                                     void* host_blob, size_t blob_bytes) {
     PD_REQUIRE(x_d && y_d && x_s1 && y_s1 && x_s2 && y_s2 && host_blob, "pd_polar_tables_pack: null pointer");
     PD_REQUIRE(n_d >= 2 && n_s1 >= 2 && n_s2 >= 2, "pd_polar_tables_pack: each table needs >= 2 nodes");
-    PD_REQUIRE(n_d < 4096 && n_s1 < 4096 && n_s2 < 4096, "pd_polar_tables_pack: table too large");
+    PD_REQUIRE(n_d <= kMaxNodes && n_s1 <= kMaxNodes && n_s2 <= kMaxNodes,
+               "pd_polar_tables_pack: table too large (at most %d nodes each)", kMaxNodes);
     size_t need = pd_polar_tables_bytes(n_d, n_s1, n_s2);
     PD_REQUIRE(blob_bytes >= need, "pd_polar_tables_pack: blob too small (%zu < %zu)", blob_bytes, need);
     char* base = static_cast<char*>(host_blob);
     memset(base, 0, need);
+    const int nk = n_d + n_s1 + n_s2;
     PolarHeader h{};
     h.magic = kMagic; h.n_d = n_d; h.n_s1 = n_s1; h.n_s2 = n_s2;
     h.off_lut = sizeof(PolarHeader);
-    h.off_lds = h.off_lut + uint32_t(round_up(size_t(kLutCount) * 4, 16));
-    const int nk = n_d + n_s1 + n_s2;
-    PD_REQUIRE(lds_image_bytes(nk) <= 160 * 1024, "pd_polar_tables_pack: tables exceed the 160 KB LDS of a CU");
-    h.lds_bytes = uint32_t(lds_image_bytes(nk));
-    h.off_bins32 = h.off_lds + h.lds_bytes;
-    h.img_bins = uint32_t(lds_off_bins(nk));
+    h.off_lut4 = h.off_lut + uint32_t(lut_bytes());
+    h.off_img_fast = h.off_lut4 + uint32_t(lut4_bytes());
+    h.img_fast_bytes = uint32_t(img_bytes_for(nk, false));
+    h.off_img_precise = h.off_img_fast + h.img_fast_bytes;
+    h.img_precise_bytes = uint32_t(img_bytes_for(nk, true));
+    h.common_bytes = uint32_t(common_bytes_for(nk));
     h.total_bytes = uint32_t(need);
-    memcpy(base, &h, sizeof(h));
+    h.n_buckets = kNB;
+    PD_REQUIRE(h.img_precise_bytes <= 160 * 1024, "pd_polar_tables_pack: tables exceed the 160 KB LDS of a CU");
 
-    // AoLP LUT: phi = 0.5 * atan2(x2, x1), x1 = d1/2, x2 = d2/2 (xolp.py:30), fp64 -> fp32.
+    // AoLP LUTs: phi = 0.5 * atan2(x2, x1), x1 = d1/2, x2 = d2/2 (xolp.py:30), fp64 -> fp32; the float4 LUT adds
+    // cos/sin of the fp32 AoLP (torch evaluates them on the fp32 tensor, normals_vec.py:56-57), correctly rounded.
     float* lut = reinterpret_cast<float*>(base + h.off_lut);
+    float* lut4 = reinterpret_cast<float*>(base + h.off_lut4);
     for (int d2 = -255; d2 <= 255; ++d2)
-        for (int d1 = -255; d1 <= 255; ++d1)
-            lut[(d2 + 255) * kLutSide + (d1 + 255)] =
-                static_cast<float>(0.5 * atan2(d2 / 2.0, d1 / 2.0));
+        for (int d1 = -255; d1 <= 255; ++d1) {
+            const int i = (d2 + 255) * kLutSide + (d1 + 255);
+            const float phi = static_cast<float>(0.5 * atan2(d2 / 2.0, d1 / 2.0));
+            lut[i] = phi;
+            lut4[4 * i] = phi;
+            lut4[4 * i + 1] = static_cast<float>(cos(static_cast<double>(phi)));
+            lut4[4 * i + 2] = static_cast<float>(sin(static_cast<double>(phi)));
+            lut4[4 * i + 3] = 0.f;
+        }
 
-    const int nkp = keys_padded(nk);
-    char* img = base + h.off_lds;
-    float* mkeys = reinterpret_cast<float*>(img);
-    uint16_t* bstart = reinterpret_cast<uint16_t*>(img + lds_off_bstart(nk));
-    float* bscale = reinterpret_cast<float*>(img + lds_off_bstart(nk) + size_t(kBuckets + 4) * 2);
-    uint16_t* rank = reinterpret_cast<uint16_t*>(img + lds_off_rank(nk));
-    double* bins = reinterpret_cast<double*>(img + lds_off_bins(nk));
     const double* xs[3] = {x_d, x_s1, x_s2};
     const double* ys[3] = {y_d, y_s1, y_s2};
     const int ns[3] = {n_d, n_s1, n_s2};
-    std::vector<std::pair<float, int>> merged;   // (key, table)
-    merged.reserve(nk);
+    uint32_t* buckets = reinterpret_cast<uint32_t*>(base + h.off_img_fast);
+    float* keys = reinterpret_cast<float*>(base + h.off_img_fast + size_t(kNB) * 16);
+    float* fbins = reinterpret_cast<float*>(base + h.off_img_fast + h.common_bytes);
+    double* bins = reinterpret_cast<double*>(base + h.off_img_precise + h.common_bytes);
+    float kmax = 0.f;
     int o = 0;
     for (int t = 0; t < 3; ++t) {
         for (int i = 0; i < ns[t]; ++i) {
             PD_REQUIRE(i == 0 || xs[t][i] >= xs[t][i - 1], "pd_polar_tables_pack: x not ascending (table %d)", t);
             PD_REQUIRE(xs[t][i] >= 0.0, "pd_polar_tables_pack: negative node (table %d)", t);
-            merged.emplace_back(floor32(xs[t][i]), t);
+            keys[o + i] = floor32(xs[t][i]);
+            if (std::isfinite(keys[o + i])) kmax = std::max(kmax, keys[o + i]);
             if (i >= 1) {  // scipy _call_linear: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope*(x - x_lo) + y_lo
                 double* bin = bins + size_t(o + i) * 4;
-                bin[0] = xs[t][i - 1];
-                bin[1] = (ys[t][i] - ys[t][i - 1]) / (xs[t][i] - xs[t][i - 1]);
-                bin[2] = sin(ys[t][i - 1]);
-                bin[3] = cos(ys[t][i - 1]);
-                float* fb = reinterpret_cast<float*>(base + h.off_bins32) + size_t(o + i) * 8;
-                fb[0] = floor32(bin[0]); fb[1] = (float)(bin[0] - (double)fb[0]); fb[2] = (float)bin[1];
-                fb[3] = (float)bin[2]; fb[4] = (float)(bin[2] - (double)fb[3]);
-                fb[5] = (float)bin[3]; fb[6] = (float)(bin[3] - (double)fb[5]); fb[7] = 0.f;
+                const double x_lo = xs[t][i - 1], y_lo = ys[t][i - 1];
+                const double slope = (ys[t][i] - y_lo) / (xs[t][i] - x_lo);
+                bin[0] = x_lo; bin[1] = slope; bin[2] = sin(y_lo); bin[3] = cos(y_lo);
+                // fast bin: theta - j*pi/2 = slope*(rho - x_lo32) + c,  c = y_lo - slope*(x_lo - x_lo32) - j*pi/2
+                float* fb = fbins + size_t(o + i) * 4;
+                const float x32 = floor32(x_lo);
+                const int j = 0.5 * (y_lo + ys[t][i]) > M_PI / 4 ? 1 : 0;
+                const double c = y_lo - slope * (x_lo - static_cast<double>(x32)) - j * (M_PI / 2);
+                const float c_hi = static_cast<float>(c);
+                float c_lo = static_cast<float>(c - static_cast<double>(c_hi));
+                uint32_t lo_bits; memcpy(&lo_bits, &c_lo, 4);
+                lo_bits = (lo_bits & ~1u) | uint32_t(j);        // the quadrant rides in the last bit of a ~1e-9 term
+                memcpy(&c_lo, &lo_bits, 4);
+                fb[0] = x32; fb[1] = static_cast<float>(slope); fb[2] = c_hi; fb[3] = c_lo;
             }
         }
         o += ns[t];
     }
-    std::stable_sort(merged.begin(), merged.end(),
-                     [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
-    uint16_t cnt[3] = {0, 0, 0};
-    for (int p = 0; p <= nk; ++p) {
-        rank[4 * p] = cnt[0]; rank[4 * p + 1] = cnt[1]; rank[4 * p + 2] = cnt[2]; rank[4 * p + 3] = 0;
-        if (p < nk) { mkeys[p] = merged[p].first; ++cnt[merged[p].second]; }
+    PD_REQUIRE(kmax > 0.f, "pd_polar_tables_pack: all nodes are zero");
+    for (size_t p = size_t(nk); p < keys_padded(nk); ++p) keys[p] = INFINITY;
+    // bucket scale: the largest finite key lands in bucket kNB - 2, everything above it in kNB - 1
+    float bscale = static_cast<float>((kNB - 2) / static_cast<double>(approx_sqrt_bits(kmax)));
+    while (bucket_of(kmax, bscale) > kNB - 2) bscale = nextafterf(bscale, 0.f);
+    h.bscale = bscale;
+    memcpy(base, &h, sizeof(h));
+
+    std::vector<int> cnt(size_t(3) * kNB, 0);          // keys per (table, bucket)
+    std::vector<float> first(size_t(3) * kNB, INFINITY);
+    o = 0;
+    for (int t = 0; t < 3; ++t) {
+        for (int i = 0; i < ns[t]; ++i) {
+            const float k = keys[o + i];
+            const int b = std::isfinite(k) ? bucket_of(k, bscale) : kNB - 1;
+            if (cnt[size_t(t) * kNB + b]++ == 0) first[size_t(t) * kNB + b] = k;
+        }
+        o += ns[t];
     }
-    for (int p = nk; p < nkp; ++p) mkeys[p] = INFINITY;
-    // guided search: buckets uniform in sqrt(rho) (the tables are ~quadratic in theta at both ends)
-    const double smax = sqrt((double)merged[nk - 1].first);
-    PD_REQUIRE(smax > 0.0, "pd_polar_tables_pack: all nodes are zero");
-    int p = 0;
-    for (int bkt = 0; bkt <= kBuckets; ++bkt) {
-        const double edge = bkt * smax / kBuckets;
-        while (p < nk && sqrt((double)merged[p].first) < edge) ++p;
-        bstart[bkt] = (uint16_t)p;
+    int below[3] = {0, 0, 0};
+    for (int b = 0; b < kNB; ++b) {
+        uint32_t rec[4] = {0, 0, 0, 0};
+        for (int t = 0; t < 3; ++t) {
+            const int c = cnt[size_t(t) * kNB + b];
+            float key = c >= 1 ? first[size_t(t) * kNB + b] : INFINITY;
+            if (c >= 2) rec[3] |= 1u << 30;
+            // index = clip(below + (key < rho), 1, n - 1): fold the clip into base / key
+            const int lo = std::min(std::max(below[t], 1), ns[t] - 1);
+            const int hi = std::min(std::max(below[t] + (c >= 1 ? 1 : 0), 1), ns[t] - 1);
+            if (hi == lo) key = INFINITY;
+            memcpy(&rec[t], &key, 4);
+            rec[3] |= uint32_t(lo) << (10 * t);
+            below[t] += c;
+        }
+        memcpy(buckets + size_t(b) * 4, rec, 16);
     }
-    for (int bkt = kBuckets + 1; bkt < kBuckets + 4; ++bkt) bstart[bkt] = (uint16_t)nk;
-    bscale[0] = (float)(kBuckets / smax);
-    bscale[1] = 0.f;
+    memcpy(base + h.off_img_precise, base + h.off_img_fast, h.common_bytes);   // the precise image starts with the same part
     return PD_OK;
 }
 
@@ -206,37 +264,55 @@ extern "C" int pd_polar_tables_build(double n, void* host_blob, size_t blob_byte
 // ------------------------------------------------------------------ device side
 namespace {
 
-struct Tabs {  // LDS-resident view of the interpolation tables
-    const float* mkeys;
-    const uint16_t* bstart;
-    const uint2* rank;          // ushort4 packed in 8 bytes
-    const double* bins;         // [nk][4]: x_lo, slope, sin(y_lo), cos(y_lo)  (LDS when PRECISE, else global)
-    const float* fbins;         // [nk][8] fp32 image (LDS, fast path only)
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+// write-once output stream: nontemporal 16-byte stores (tools/membench2.hip: 6.0-6.6 TB/s vs 4.9-5.4 TB/s plain)
+template <bool NT>
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    const f4 v = {a, b, c, d};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
+    else *reinterpret_cast<f4*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ void store4i(int* p, int a, int b, int c, int d) {
+    const i4 v = {a, b, c, d};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<i4*>(p));
+    else *reinterpret_cast<i4*>(p) = v;
+}
+
+struct Tabs {  // view of the interpolation tables
+    const uint4* buckets;       // LDS
+    const float* keys;          // LDS
+    const float4* fbins;        // LDS (fast) -- [nk] x_lo32, slope32, c_hi, c_lo|j
+    const double* bins;         // [nk][4]: x_lo, slope, sin(y_lo), cos(y_lo); LDS when PRECISE, else global
     float bscale;
-    int nk, n_d, n_s1, n_s2;
+    int n_d, n_s1, n_s2;
 };
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void global_void_t;
+
+// The ~100 KB table image of a workgroup, L2 -> LDS by direct-to-LDS loads: one wave instruction moves 1 KiB
+// (wave-uniform LDS base + lane * 16), nothing passes through registers and all pieces of a wave are in flight
+// together (a copy loop through registers ran as a chain of L2 round trips: 7 us per launch).
 template <bool PRECISE>
 __device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char* smem, int nthreads, Tabs& t) {
     const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
-    uint4* dst = reinterpret_cast<uint4*>(smem);
-    const uint4* src = reinterpret_cast<const uint4*>(blob + h->off_lds);
-    const int ncommon = h->img_bins / 16, n16 = h->lds_bytes / 16;
-    for (int i = threadIdx.x; i < ncommon; i += nthreads) dst[i] = src[i];
-    const uint4* bsrc = PRECISE ? src + ncommon : reinterpret_cast<const uint4*>(blob + h->off_bins32);
-    for (int i = threadIdx.x; i < n16 - ncommon; i += nthreads) dst[ncommon + i] = bsrc[i];
     t.n_d = h->n_d; t.n_s1 = h->n_s1; t.n_s2 = h->n_s2;
-    t.nk = t.n_d + t.n_s1 + t.n_s2;
-    const int nkp = (t.nk + 3) / 4 * 4 + 4;
-    const int off_rank = nkp * 4 + (kBuckets + 4) * 2 + 8;
-    t.mkeys = reinterpret_cast<const float*>(smem);
-    t.bstart = reinterpret_cast<const uint16_t*>(smem + nkp * 4);
-    t.rank = reinterpret_cast<const uint2*>(smem + off_rank);
-    t.fbins = reinterpret_cast<const float*>(smem + h->img_bins);
-    t.bins = PRECISE ? reinterpret_cast<const double*>(smem + h->img_bins)
-                     : reinterpret_cast<const double*>(blob + h->off_lds + h->img_bins);
+    const char* src = blob + (PRECISE ? h->off_img_precise : h->off_img_fast);
+    const int npieces = static_cast<int>((PRECISE ? h->img_precise_bytes : h->img_fast_bytes) >> 10);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = nthreads >> 6;
+    for (int p = wave; p < npieces; p += nwaves)
+        __builtin_amdgcn_global_load_lds((global_void_t*)(src + (static_cast<size_t>(p) << 10) + lane * 16),
+                                         (lds_void_t*)(smem + (static_cast<size_t>(p) << 10)), 16, 0, 0);
+    t.buckets = reinterpret_cast<const uint4*>(smem);
+    t.keys = reinterpret_cast<const float*>(smem + size_t(kNB) * 16);
+    t.fbins = reinterpret_cast<const float4*>(smem + h->common_bytes);
+    t.bins = PRECISE ? reinterpret_cast<const double*>(smem + h->common_bytes)
+                     : reinterpret_cast<const double*>(blob + h->off_img_precise + h->common_bytes);
+    t.bscale = h->bscale;
     __syncthreads();
-    t.bscale = *reinterpret_cast<const float*>(smem + nkp * 4 + (kBuckets + 4) * 2);
 }
 
 // fp64 sin/cos: Cody-Waite with pi/2 = C1 + C2 + C3 (33 + 33 + 53 bits, fdlibm constants) and the
@@ -270,18 +346,24 @@ __device__ __forceinline__ void sincos_f64(double x, double& s, double& c) {
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// fp32 polynomial kernels on |r| <= pi/4 (+ a table step): ~1 ulp
+__device__ __forceinline__ void sincos_kernel_f32(float r, float& sn, float& cs) {
+    const float z = r * r;
+    float ps = fmaf(z, 2.7183114939898219e-06f, -1.9839334836096632e-04f);
+    ps = fmaf(z, ps, 8.3333095718939529e-03f);
+    sn = fmaf(r * z, fmaf(z, ps, -1.6666665459843126e-01f), r);
+    float pc = fmaf(z, 2.4390448796277409e-05f, -1.3887316255677255e-03f);
+    pc = fmaf(z, pc, 4.1666645683222281e-02f);
+    cs = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+}
+
 // fp32 sin/cos for |x| <= 4 (AoLP in [-pi/2, pi/2], AoLP + pi/2 in [0, pi]); ~1 ulp
 __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
     const float j = rintf(x * 0.63661977236758134f);
     float r = fmaf(-j, 1.5707962512969971f, x);       // pi/2 hi (24 bits)
     r = fmaf(-j, 7.5497894158615964e-08f, r);         // pi/2 lo
-    const float z = r * r;
-    float ps = fmaf(z, 2.7183114939898219e-06f, -1.9839334836096632e-04f);
-    ps = fmaf(z, ps, 8.3333095718939529e-03f);
-    const float sn = fmaf(r * z, fmaf(z, ps, -1.6666665459843126e-01f), r);
-    float pc = fmaf(z, 2.4390448796277409e-05f, -1.3887316255677255e-03f);
-    pc = fmaf(z, pc, 4.1666645683222281e-02f);
-    const float cs = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    float sn, cs;
+    sincos_kernel_f32(r, sn, cs);
     const int q = static_cast<int>(j) & 3;
     const float a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
     s = (q & 2) ? -a : a;
@@ -305,63 +387,71 @@ __device__ __forceinline__ void sincos_bin(const double* __restrict__ bin, doubl
     c = fma(bin[3], cd, -(bin[2] * sd));
 }
 
-// fp32 form of the same angle addition for the fast path: (rho - x_lo32) is exact (neighbouring floats), the
-// residuals of x_lo / sin / cos restore the bits the fp32 table entries drop; error ~1e-7 absolute.
-// Extrapolated rho falls back to the fp64 routine (bins read from global memory).
-__device__ __forceinline__ void sincos_bin_fast(const float* __restrict__ fb, const double* __restrict__ gbin,
-                                                float rho, float& s, float& c) {
-    const float4 a = *reinterpret_cast<const float4*>(fb);       // x_lo32, dx, slope, sin
-    const float4 b = *reinterpret_cast<const float4*>(fb + 4);   // sin residual, cos, cos residual
-    const float d = a.z * ((rho - a.x) - a.y);
-    if (fabsf(d) < 4.0e-3f) {
-        const float d2 = d * d;
-        const float sd = d * fmaf(d2, fmaf(d2, 8.3333338e-03f, -1.6666667e-01f), 1.0f);
-        const float cd = fmaf(d2, fmaf(d2, 4.1666668e-02f, -0.5f), 1.0f);
-        s = fmaf(a.w, cd, fmaf(b.y, sd, b.x));
-        c = fmaf(b.y, cd, fmaf(-a.w, sd, b.z));
+// Out of line: the fp64 evaluation for the (rare in real frames) pixels whose rho lies beyond a table.
+__device__ __noinline__ void sincos_bin_slow(const double* __restrict__ gbin, float rho, float& s, float& c) {
+    double sd, cd;
+    sincos_bin(gbin, static_cast<double>(rho), sd, cd);
+    s = static_cast<float>(sd);
+    c = static_cast<float>(cd);
+}
+
+// Fast path: r = theta - j*pi/2 in fp32 from the two-float bin constant ((rho - x_lo32) is exact or carries a
+// 6e-8 relative error on a term <= 1.6e-3), polynomial kernels, quadrant swap.  |err| ~1e-7.
+__device__ __forceinline__ void sincos_bin_fast(const float4 fb, const double* __restrict__ gbin, float rho, float& s, float& c) {
+    const float r = fmaf(fb.y, rho - fb.x, fb.z) + fb.w;
+    if (fabsf(r) < 0.79f) {
+        float sn, cs;
+        sincos_kernel_f32(r, sn, cs);
+        const bool j = (__float_as_uint(fb.w) & 1u) != 0;
+        s = j ? cs : sn;
+        c = j ? -sn : cs;
     } else {
-        double sd, cd;
-        sincos_bin(gbin, static_cast<double>(rho), sd, cd);
-        s = static_cast<float>(sd);
-        c = static_cast<float>(cd);
+        sincos_bin_slow(gbin, rho, s, c);
     }
 }
 
-// theta lookups + the three physical normals of one pixel (normals_vec.py:11-60, pre_encoders.py:99-113)
-template <bool PRECISE>
-__device__ __forceinline__ void normals9(float rho, float phi, const Tabs& t, float (&v)[9], int (&bi)[3]) {
-    const float kHalfPi = static_cast<float>(1.5707963267948966);
-    // pos = number of merged keys strictly below rho (searchsorted-left on the merged key array).
-    // A sqrt(rho) bucket table narrows the range to a few keys (+-1 bucket of slack covers the rounding of
-    // the fp32 sqrt), then an exact binary search finishes.
-    const float u = sqrtf(fmaxf(rho, 0.f)) * t.bscale;
-    const int bk = (int)fminf(u, (float)kBuckets);
-    int lo = t.bstart[max(bk - 1, 0)], hi = t.bstart[bk + 2];
-    if (hi - lo <= 4) {
-        // the usual case: at most four candidate keys -> four independent LDS reads instead of a dependent
-        // binary-search chain (keys at or beyond hi are > rho, the array is padded with +inf)
-        lo += (t.mkeys[lo] < rho) + (t.mkeys[lo + 1] < rho) + (t.mkeys[lo + 2] < rho) + (t.mkeys[lo + 3] < rho);
-    } else {
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (t.mkeys[mid] < rho) lo = mid + 1; else hi = mid;
-        }
+__device__ __forceinline__ int search_left(const float* __restrict__ keys, int n, float rho) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < rho) lo = mid + 1; else hi = mid;
     }
-    const uint2 rk = t.rank[lo];
-    const bool isnan_ = rho != rho;   // NaN sorts last (numpy)
-    bi[0] = isnan_ ? t.n_d - 1 : min(max((int)(rk.x & 0xffffu), 1), t.n_d - 1);
-    bi[1] = isnan_ ? t.n_s1 - 1 : min(max((int)(rk.x >> 16), 1), t.n_s1 - 1);
-    bi[2] = isnan_ ? t.n_s2 - 1 : min(max((int)(rk.y & 0xffffu), 1), t.n_s2 - 1);
+    return lo;
+}
+
+// The three scipy bin indices clip(searchsorted(x, rho, 'left'), 1, n-1) of one pixel: one 16-byte LDS read.
+// GENERIC: rho may be NaN (sorts last, numpy) -- Stokes mode (0/0) and caller-supplied XOLP tensors.
+template <bool GENERIC>
+__device__ __forceinline__ void lookup3(float rho, const Tabs& t, int (&bi)[3]) {
+    const uint4 rec = t.buckets[bucket_of(rho, t.bscale)];
+    bi[0] = static_cast<int>(rec.w & 1023u) + (__uint_as_float(rec.x) < rho ? 1 : 0);
+    bi[1] = static_cast<int>((rec.w >> 10) & 1023u) + (__uint_as_float(rec.y) < rho ? 1 : 0);
+    bi[2] = static_cast<int>((rec.w >> 20) & 1023u) + (__uint_as_float(rec.z) < rho ? 1 : 0);
+    if (rec.w >> 30) {   // two or more keys of one table in this bucket: exact binary searches
+        bi[0] = min(max(search_left(t.keys, t.n_d, rho), 1), t.n_d - 1);
+        bi[1] = min(max(search_left(t.keys + t.n_d, t.n_s1, rho), 1), t.n_s1 - 1);
+        bi[2] = min(max(search_left(t.keys + t.n_d + t.n_s1, t.n_s2, rho), 1), t.n_s2 - 1);
+    }
+    if (GENERIC && rho != rho) { bi[0] = t.n_d - 1; bi[1] = t.n_s1 - 1; bi[2] = t.n_s2 - 1; }
+}
+
+// theta lookups + the three physical normals of one pixel (normals_vec.py:11-60, pre_encoders.py:99-113).
+// PRECISE: fp64 theta trig, cos/sin(fl32(phi + pi/2)) evaluated like the reference.  Otherwise (cp, sp) =
+// cos/sin(phi) are given (LUT) or computed, and cos(phi + pi/2) = -sin(phi), sin(phi + pi/2) = cos(phi)
+// (within 1.2e-7 of the reference's evaluation at the rounded sum).
+template <bool PRECISE, bool GENERIC>
+__device__ __forceinline__ void normals9(float rho, float phi, float cp, float sp, const Tabs& t, float (&v)[9], int (&bi)[3]) {
+    lookup3<GENERIC>(rho, t, bi);
     const int i0 = bi[0], i1 = t.n_d + bi[1], i2 = t.n_d + t.n_s1 + bi[2];
-    float sp, cp;
-    sincos_f32(phi, sp, cp);             // torch.cos/sin on the fp32 AoLP
     if (PRECISE) {
+        const float kHalfPi = static_cast<float>(1.5707963267948966);
         const double x = static_cast<double>(rho);
         double sd, cd, s1, c1, s2, c2;
         sincos_bin(t.bins + 4 * i0, x, sd, cd);
         sincos_bin(t.bins + 4 * i1, x, s1, c1);
         sincos_bin(t.bins + 4 * i2, x, s2, c2);
         float sq, cq;
+        sincos_f32(phi, sp, cp);             // torch.cos/sin on the fp32 AoLP
         sincos_f32(phi + kHalfPi, sq, cq);   // phi + np.pi/2 evaluated in fp32 (pre_encoders.py:108-109)
         v[0] = static_cast<float>(static_cast<double>(cp) * sd);
         v[1] = static_cast<float>(static_cast<double>(sp) * sd);
@@ -374,21 +464,14 @@ __device__ __forceinline__ void normals9(float rho, float phi, const Tabs& t, fl
         v[8] = static_cast<float>(c2);
     } else {
         float sd, cd, s1, c1, s2, c2;
-        sincos_bin_fast(t.fbins + 8 * i0, t.bins + 4 * i0, rho, sd, cd);
-        sincos_bin_fast(t.fbins + 8 * i1, t.bins + 4 * i1, rho, s1, c1);
-        sincos_bin_fast(t.fbins + 8 * i2, t.bins + 4 * i2, rho, s2, c2);
-        // cos(phi + pi/2) = -sin(phi), sin(phi + pi/2) = cos(phi): within 2e-7 of the reference's fp32
-        // evaluation of cos/sin(fl32(phi + pi/2))
+        sincos_bin_fast(t.fbins[i0], t.bins + 4 * i0, rho, sd, cd);
+        sincos_bin_fast(t.fbins[i1], t.bins + 4 * i1, rho, s1, c1);
+        sincos_bin_fast(t.fbins[i2], t.bins + 4 * i2, rho, s2, c2);
         v[0] = cp * sd; v[1] = sp * sd; v[2] = cd;
         v[3] = -sp * s1; v[4] = cp * s1; v[5] = c1;
         v[6] = -sp * s2; v[7] = cp * s2; v[8] = c2;
     }
 }
-
-struct Px {
-    float rho, phi;
-    float d1, d2;    // I0 - I90, I45 - I135 (exact small integers)
-};
 
 // The reference's fp64 operation sequence, executed literally (IEEE sqrt / div, one rounding to fp32).
 // S = I0 + I45 + I90 + I135 (LS) or I0 + I90 (Stokes); all arguments are exact small integers.
@@ -442,20 +525,6 @@ __device__ __forceinline__ float rho_pixel(float S, float d1, float d2, float s4
     return rho;
 }
 
-template <int MODE>
-__device__ __forceinline__ Px xolp_pixel(float f0, float f45, float f90, float f135, const float* __restrict__ lut, bool ieee) {
-    Px p;
-    p.d1 = f0 - f90;
-    p.d2 = f45 - f135;
-    const float s4 = fmaf(p.d1, p.d1, p.d2 * p.d2);                      // <= 130050: exact in fp32
-    const float S = MODE == PD_POLAR_LS ? (f0 + f90) + (f45 + f135) : f0 + f90;
-    p.rho = rho_pixel<MODE>(S, p.d1, p.d2, s4, ieee);
-    // (d2 + 255) * 511 + (d1 + 255), exact in fp32
-    const unsigned idx = static_cast<unsigned>(static_cast<int>(fmaf(p.d2, 511.f, p.d1 + 130560.f)));
-    p.phi = lut[idx];
-    return p;
-}
-
 // (x - mean) / std with the correctly rounded quotient (Markstein: q = RN(a*y), r = a - q*b exactly, RN(q + r*y)
 // equals RN(a / b) when y = RN(1/b) and b's significand is not all ones; checked over every fp32 in [-4, 4] by
 // tests/test_polar_gpu.py).  Replaces the ten-instruction IEEE division sequence.
@@ -468,15 +537,20 @@ __device__ __forceinline__ float standardise(float x) {
     return fmaf(fmaf(-q, kStd, a), kInv, q);
 }
 
-constexpr int kThreads = 512;    // XOLP-only kernels: 4 workgroups per CU
-constexpr int kThreadsN = 768;   // kernels with the fp64 normals: one 12-wave workgroup per CU (3 waves/SIMD, <= 168 VGPRs);
-                                 // its 96 KB LDS image of the tables is staged once per CU
+// Output variants of the fused kernel
+constexpr int OUT_XOLP = 0;      // DoLP / AoLP (+ standardised, + d1/d2) only: no tables in LDS, one quad per thread
+constexpr int OUT_FAST = 1;      // + normals, fp32 path (default)
+constexpr int OUT_PRECISE = 2;   // + normals, fp64 theta trig (PD_POLAR_PRECISE_NORMALS)
 
-constexpr int kThreadsF = 1024;  // fast (fp32) normals: 112 VGPRs -> one 16-wave workgroup per CU (4 waves/SIMD)
+constexpr int kThreads = 512;    // XOLP-only kernels: 4 workgroups per CU
+constexpr int kThreadsP = 768;   // fp64 normals: one 12-wave workgroup per CU (3 waves/SIMD, <= 168 VGPRs)
 
 // Launch geometry: every index is 32-bit (the host splits a batch whose planes would exceed 2^32 bytes).
-// The output of one image is Hrows rows of wq_out quads (4 pixels); with a pitched output (Wout > W) a row is
-// an image row, otherwise the whole plane is one row.  A thread walks (image, row, quad) by a constant step.
+// One image is Hrows rows of wq_in quads (4 pixels) in and wq_out >= wq_in quads out; with a pitched output
+// (Wout > W) a row is an image row, otherwise the whole plane is one row.  A thread walks the OUTPUT quads
+// (image, row, quad) by a constant step, so that a wave's 64 quads are one 1-KiB-aligned segment of every
+// output plane (full 128-byte lines: walking the input quads instead left two partial lines per store and
+// cost 30 % on the 612 -> 640 case); lanes in the padding columns load nothing and store zeros.
 struct PolarGeo {
     int B, Hrows, wq_in, wq_out;
     int drow, dcq;                 // persistent-loop step (grid * block quads) as rows + quads
@@ -484,150 +558,199 @@ struct PolarGeo {
     int flags;
 };
 
-template <int MODE, bool NORMALS, bool PRECISE>
-__global__ __launch_bounds__(NORMALS ? (PRECISE ? kThreadsN : kThreadsF) : kThreads) void polar_kernel(
+struct QuadPos {
+    int b, cq;
+    unsigned row;
+};
+
+__device__ __forceinline__ void advance(QuadPos& q, const PolarGeo& g) {
+    q.cq += g.dcq;
+    q.row += static_cast<unsigned>(g.drow);
+    if (q.cq >= g.wq_out) { q.cq -= g.wq_out; ++q.row; }
+    if (q.row >= static_cast<unsigned>(g.Hrows)) {
+        if (q.row < 2u * static_cast<unsigned>(g.Hrows)) { q.row -= static_cast<unsigned>(g.Hrows); ++q.b; }
+        else { const unsigned k = q.row / static_cast<unsigned>(g.Hrows); q.row -= k * static_cast<unsigned>(g.Hrows); q.b += static_cast<int>(k); }
+    }
+}
+
+template <int MODE, int OUT, int NTH, bool NT>
+__global__ __launch_bounds__(NTH) void polar_kernel(
     const uint8_t* __restrict__ pol, const uint8_t* __restrict__ mask, float* __restrict__ xolp,
     float* __restrict__ xolp_std, float* __restrict__ normals, int* __restrict__ ints,
     const char* __restrict__ blob, const PolarGeo g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool NORMALS = OUT != OUT_XOLP;
+    constexpr bool PRECISE = OUT == OUT_PRECISE;
+    constexpr bool FAST = OUT == OUT_FAST;
     const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
     const float* lut = reinterpret_cast<const float*>(blob + h->off_lut);
-    constexpr int NTH = NORMALS ? (PRECISE ? kThreadsN : kThreadsF) : kThreads;
-    Tabs tabs;
-    if (NORMALS) stage_tables<PRECISE>(blob, smem, NTH, tabs);
+    const float4* lut4 = reinterpret_cast<const float4*>(blob + h->off_lut4);
     const bool ieee = (g.flags & PD_POLAR_IEEE_RHO) != 0;
 
-    const unsigned q0 = blockIdx.x * (unsigned)NTH + threadIdx.x;
-    unsigned row = q0 / (unsigned)g.wq_out;
-    int cq = (int)(q0 - row * (unsigned)g.wq_out);
-    int b = (int)(row / (unsigned)g.Hrows);
-    row -= (unsigned)b * (unsigned)g.Hrows;
+    // first quad of this thread; its planes are requested before the tables are staged
+    QuadPos q;
+    {
+        const unsigned q0 = blockIdx.x * static_cast<unsigned>(NTH) + threadIdx.x;
+        q.row = q0 / static_cast<unsigned>(g.wq_out);
+        q.cq = static_cast<int>(q0 - q.row * static_cast<unsigned>(g.wq_out));
+        q.b = static_cast<int>(q.row / static_cast<unsigned>(g.Hrows));
+        q.row -= static_cast<unsigned>(q.b) * static_cast<unsigned>(g.Hrows);
+    }
     const unsigned in_row = 4u * g.wq_in, out_row = 4u * g.wq_out;
+    uint32_t w0 = 0, w45 = 0, w90 = 0, w135 = 0;
+    if (q.b < g.B && q.cq < g.wq_in) {
+        const unsigned p4 = static_cast<unsigned>(q.b) * 4u * g.P + q.row * in_row + 4u * q.cq;
+        w0 = *reinterpret_cast<const uint32_t*>(pol + p4);
+        w45 = *reinterpret_cast<const uint32_t*>(pol + (p4 + g.P));
+        w90 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P));
+        w135 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P));
+    }
+    Tabs tabs;
+    if (NORMALS) stage_tables<PRECISE>(blob, smem, NTH, tabs);
 
-    while (b < g.B) {
-        const unsigned po = row * out_row + 4u * cq;     // first output pixel of the quad inside its plane
-        if (cq >= g.wq_in) {                             // right padding columns of a pitched output: zeros
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xolp) { *reinterpret_cast<float4*>(xolp + ((unsigned)b * 2u * g.Pout + po)) = z; *reinterpret_cast<float4*>(xolp + ((unsigned)b * 2u * g.Pout + g.Pout + po)) = z; }
-            if (xolp_std) { *reinterpret_cast<float4*>(xolp_std + ((unsigned)b * 2u * g.Pout + po)) = z; *reinterpret_cast<float4*>(xolp_std + ((unsigned)b * 2u * g.Pout + g.Pout + po)) = z; }
-            if (NORMALS && normals)
-                for (unsigned c = 0; c < 9; ++c) *reinterpret_cast<float4*>(normals + (((unsigned)b * 9u + c) * g.Pout + po)) = z;
-            if (ints)
-                for (unsigned c = 0; c < (NORMALS ? 5u : 2u); ++c) *reinterpret_cast<int4*>(ints + (((unsigned)b * 5u + c) * g.Pout + po)) = make_int4(0, 0, 0, 0);
-        } else {
-            const unsigned p4 = (unsigned)b * 4u * g.P + row * in_row + 4u * cq;   // first input pixel (plane 0)
-            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(pol + p4);
-            const uint32_t w45 = *reinterpret_cast<const uint32_t*>(pol + (p4 + g.P));
-            const uint32_t w90 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P));
-            const uint32_t w135 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P));
-            uint32_t wm = 0x01010101u;
-            if (MODE == PD_POLAR_STOKES && mask) wm = *reinterpret_cast<const uint32_t*>(mask + ((unsigned)b * g.P + row * in_row + 4u * cq));
+    while (q.b < g.B) {
+        const unsigned po = q.row * out_row + 4u * q.cq;     // first output pixel of the quad inside its plane
+        const unsigned pin = static_cast<unsigned>(q.b) * g.P + q.row * in_row + 4u * q.cq;
+        const int b = q.b;
+        const bool pad = q.cq >= g.wq_in;                    // padding columns of a pitched output
+        uint32_t wm = 0x01010101u;
+        if (MODE == PD_POLAR_STOKES && mask && !pad) wm = *reinterpret_cast<const uint32_t*>(mask + pin);
 
-            float o_rho[4], o_phi[4], o_n[9][4];
-            int o_i[5][4];
-            // With the normals the four pixels are processed in pairs (scheduling barrier between them):
-            // interleaving four fp64 trig chains quadruples the live registers.
+        // bytes -> differences, AoLP gathers (L2-resident LUTs) first, then the next quad's planes: the gathers
+        // are older in the memory queue, so waiting for them does not wait for the HBM loads behind them
+        float d1[4], d2[4], S[4], s4[4];
+        float4 L[4];
+        float o_phi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sh = 8 * j;
+            // v_cvt_f32_ubyteN: byte -> float in one instruction
+            const float f0 = static_cast<float>((w0 >> sh) & 0xffu), f45 = static_cast<float>((w45 >> sh) & 0xffu);
+            const float f90 = static_cast<float>((w90 >> sh) & 0xffu), f135 = static_cast<float>((w135 >> sh) & 0xffu);
+            d1[j] = f0 - f90;
+            d2[j] = f45 - f135;
+            s4[j] = fmaf(d1[j], d1[j], d2[j] * d2[j]);                      // <= 130050: exact in fp32
+            S[j] = MODE == PD_POLAR_LS ? (f0 + f90) + (f45 + f135) : f0 + f90;
+            // (d2 + 255) * 511 + (d1 + 255), exact in fp32
+            const unsigned idx = static_cast<unsigned>(static_cast<int>(fmaf(d2[j], 511.f, d1[j] + 130560.f)));
+            if (FAST) L[j] = lut4[idx];
+            else o_phi[j] = lut[idx];
+        }
+        advance(q, g);
+        __builtin_amdgcn_sched_barrier(0);
+        w0 = 0; w45 = 0; w90 = 0; w135 = 0;
+        if (q.b < g.B && q.cq < g.wq_in) {
+            const unsigned p4 = static_cast<unsigned>(q.b) * 4u * g.P + q.row * in_row + 4u * q.cq;
+            w0 = *reinterpret_cast<const uint32_t*>(pol + p4);
+            w45 = *reinterpret_cast<const uint32_t*>(pol + (p4 + g.P));
+            w90 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P));
+            w135 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        float o_rho[4], o_n[9][4];
+        int o_i[5][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (PRECISE && (j & 1) == 0) __builtin_amdgcn_sched_barrier(0);   // fp64 chains in pairs: register pressure
+            const bool on = MODE != PD_POLAR_STOKES || ((wm >> (8 * j)) & 0xffu) != 0;
+            float rho, phi, cp = 1.f, sp = 0.f;
+            if (FAST) { phi = L[j].x; cp = L[j].y; sp = L[j].z; }
+            else phi = o_phi[j];
+            if (MODE == PD_POLAR_STOKES && !on) {   // images are masked first (:117-121); outputs are zero outside
+                rho = 0.f; phi = 0.f; cp = 1.f; sp = 0.f;
+                o_i[0][j] = 0; o_i[1][j] = 0;
+            } else {
+                rho = rho_pixel<MODE>(S[j], d1[j], d2[j], s4[j], ieee);
+                o_i[0][j] = static_cast<int>(d1[j]);
+                o_i[1][j] = static_cast<int>(d2[j]);
+            }
+            o_rho[j] = rho;
+            o_phi[j] = phi;
+            if (NORMALS) {
+                int bi[3];
+                float v[9];
+                normals9<PRECISE, MODE == PD_POLAR_STOKES>(rho, phi, cp, sp, tabs, v, bi);
+                o_i[2][j] = bi[0]; o_i[3][j] = bi[1]; o_i[4][j] = bi[2];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) o_n[c][j] = on ? v[c] : 0.f;
+            }
+        }
+        if (pad) {   // all-zero planes gave rho = phi = 0 already; the normals of (0, 0) are (0, 0, 1)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (NORMALS && (j & 1) == 0) __builtin_amdgcn_sched_barrier(0);
-                const int sh = 8 * j;
-                const bool on = MODE != PD_POLAR_STOKES || ((wm >> sh) & 0xffu) != 0;
-                // v_cvt_f32_ubyteN: byte -> float in one instruction
-                float f0 = static_cast<float>((w0 >> sh) & 0xffu), f45 = static_cast<float>((w45 >> sh) & 0xffu);
-                float f90 = static_cast<float>((w90 >> sh) & 0xffu), f135 = static_cast<float>((w135 >> sh) & 0xffu);
-                Px p;
-                if (MODE == PD_POLAR_STOKES && !on) {   // images are masked first (:117-121); outputs are zero outside
-                    p.rho = 0.f; p.phi = 0.f; p.d1 = 0.f; p.d2 = 0.f;
-                } else {
-                    p = xolp_pixel<MODE>(f0, f45, f90, f135, lut, ieee);
-                }
-                o_rho[j] = p.rho;
-                o_phi[j] = p.phi;
-                o_i[0][j] = static_cast<int>(p.d1);
-                o_i[1][j] = static_cast<int>(p.d2);
                 if (NORMALS) {
-                    int bi[3];
-                    float v[9];
-                    normals9<PRECISE>(p.rho, p.phi, tabs, v, bi);
-                    o_i[2][j] = bi[0]; o_i[3][j] = bi[1]; o_i[4][j] = bi[2];
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) o_n[c][j] = on ? v[c] : 0.f;
+                    for (int c = 0; c < 9; ++c) o_n[c][j] = 0.f;
+                    o_i[2][j] = 0; o_i[3][j] = 0; o_i[4][j] = 0;
                 }
-            }
-            if (xolp) {
-                float* o = xolp + ((unsigned)b * 2u * g.Pout + po);
-                *reinterpret_cast<float4*>(o) = make_float4(o_rho[0], o_rho[1], o_rho[2], o_rho[3]);
-                *reinterpret_cast<float4*>(o + g.Pout) = make_float4(o_phi[0], o_phi[1], o_phi[2], o_phi[3]);
-            }
-            if (xolp_std) {
-                float* o = xolp_std + ((unsigned)b * 2u * g.Pout + po);
-                *reinterpret_cast<float4*>(o) = make_float4(standardise(o_rho[0]), standardise(o_rho[1]),
-                                                            standardise(o_rho[2]), standardise(o_rho[3]));
-                *reinterpret_cast<float4*>(o + g.Pout) = make_float4(standardise(o_phi[0]), standardise(o_phi[1]),
-                                                                     standardise(o_phi[2]), standardise(o_phi[3]));
-            }
-            if (NORMALS && normals) {
-                float* o = normals + ((unsigned)b * 9u * g.Pout + po);
-#pragma unroll
-                for (unsigned c = 0; c < 9; ++c)
-                    *reinterpret_cast<float4*>(o + c * g.Pout) = make_float4(o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
-            }
-            if (ints) {
-                int* o = ints + ((unsigned)b * 5u * g.Pout + po);
-                const unsigned nch = NORMALS ? 5 : 2;
-#pragma unroll
-                for (unsigned c = 0; c < 5; ++c)
-                    if (c < nch) *reinterpret_cast<int4*>(o + c * g.Pout) = make_int4(o_i[c][0], o_i[c][1], o_i[c][2], o_i[c][3]);
             }
         }
-        // next quad of this thread
-        cq += g.dcq;
-        row += (unsigned)g.drow;
-        if (cq >= g.wq_out) { cq -= g.wq_out; ++row; }
-        if (row >= (unsigned)g.Hrows) {
-            if (row < 2u * (unsigned)g.Hrows) { row -= (unsigned)g.Hrows; ++b; }
-            else { const unsigned k = row / (unsigned)g.Hrows; row -= k * (unsigned)g.Hrows; b += (int)k; }
+        if (xolp) {
+            float* o = xolp + (static_cast<unsigned>(b) * 2u * g.Pout + po);
+            store4<NT>(o, o_rho[0], o_rho[1], o_rho[2], o_rho[3]);
+            store4<NT>(o + g.Pout, o_phi[0], o_phi[1], o_phi[2], o_phi[3]);
+        }
+        if (xolp_std) {
+            float* o = xolp_std + (static_cast<unsigned>(b) * 2u * g.Pout + po);
+            float sr[4], sf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sr[j] = pad ? 0.f : standardise(o_rho[j]); sf[j] = pad ? 0.f : standardise(o_phi[j]); }
+            store4<NT>(o, sr[0], sr[1], sr[2], sr[3]);
+            store4<NT>(o + g.Pout, sf[0], sf[1], sf[2], sf[3]);
+        }
+        if (NORMALS && normals) {
+            float* o = normals + (static_cast<unsigned>(b) * 9u * g.Pout + po);
+#pragma unroll
+            for (unsigned c = 0; c < 9; ++c) store4<NT>(o + c * g.Pout, o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
+        }
+        if (ints) {
+            int* o = ints + (static_cast<unsigned>(b) * 5u * g.Pout + po);
+            const unsigned nch = NORMALS ? 5 : 2;
+#pragma unroll
+            for (unsigned c = 0; c < 5; ++c)
+                if (c < nch) store4i<NT>(o + c * g.Pout, o_i[c][0], o_i[c][1], o_i[c][2], o_i[c][3]);
         }
     }
+
 }
 
 // get_normals() on an existing fp32 XOLP tensor (pre_encoders.py:99-113): [B,2,H,W] -> [B,9,H,W]
-template <bool PRECISE>
-__global__ __launch_bounds__(PRECISE ? kThreadsN : kThreadsF) void normals_from_xolp_kernel(const float* __restrict__ xolp,
-                                                                     float* __restrict__ normals,
-                                                                     const char* __restrict__ blob, long P,
-                                                                     long quads_per_img, long total_quads) {
+template <bool PRECISE, int NTH>
+__global__ __launch_bounds__(NTH) void normals_from_xolp_kernel(const float* __restrict__ xolp, float* __restrict__ normals,
+                                                                const char* __restrict__ blob, long P,
+                                                                long quads_per_img, long total_quads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Tabs tabs;
-    constexpr int NTH = PRECISE ? kThreadsN : kThreadsF;
     stage_tables<PRECISE>(blob, smem, NTH, tabs);
     for (long q = blockIdx.x * (long)NTH + threadIdx.x; q < total_quads; q += (long)gridDim.x * NTH) {
         const long b = q / quads_per_img;
         const long p4 = (q - b * quads_per_img) * 4;
         const float4 r4 = *reinterpret_cast<const float4*>(xolp + (b * 2) * P + p4);
-        const float4 f4 = *reinterpret_cast<const float4*>(xolp + (b * 2 + 1) * P + p4);
-        const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, ff[4] = {f4.x, f4.y, f4.z, f4.w};
+        const float4 f4_ = *reinterpret_cast<const float4*>(xolp + (b * 2 + 1) * P + p4);
+        const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, ff[4] = {f4_.x, f4_.y, f4_.z, f4_.w};
         float o_n[9][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_sched_barrier(0);
+            if (PRECISE) __builtin_amdgcn_sched_barrier(0);
             float v[9]; int bi[3];
-            normals9<PRECISE>(rr[j], ff[j], tabs, v, bi);
+            float sp = 0.f, cp = 1.f;
+            if (!PRECISE) sincos_f32(ff[j], sp, cp);     // torch.cos/sin on the fp32 AoLP
+            normals9<PRECISE, true>(rr[j], ff[j], cp, sp, tabs, v, bi);
 #pragma unroll
             for (int c = 0; c < 9; ++c) o_n[c][j] = v[c];
         }
         float* o = normals + (b * 9) * P + p4;
 #pragma unroll
-        for (int c = 0; c < 9; ++c)
-            *reinterpret_cast<float4*>(o + c * P) = make_float4(o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
+        for (int c = 0; c < 9; ++c) store4<true>(o + c * P, o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
     }
 }
 
-// LDS image size implied by the blob size: blob = header + LUT + image(nk) + nk * 32 (monotone in nk)
-inline size_t lds_from_blob_bytes(size_t tables_bytes) {
-    const size_t fixed = sizeof(PolarHeader) + round_up(size_t(kLutCount) * 4, 16);
-    for (int nk = 6; nk < 3 * 4096; ++nk)
-        if (fixed + lds_image_bytes(nk) + size_t(nk) * 32 == tables_bytes) return lds_image_bytes(nk);
+// node count implied by the blob size (monotone in nk)
+inline int nk_from_blob_bytes(size_t tables_bytes) {
+    const size_t fixed = sizeof(PolarHeader) + lut_bytes() + lut4_bytes();
+    for (int nk = 6; nk <= 3 * kMaxNodes; ++nk)
+        if (fixed + img_bytes_for(nk, false) + img_bytes_for(nk, true) == tables_bytes) return nk;
     return 0;
 }
 
@@ -637,6 +760,21 @@ int set_lds_limit(K kernel, size_t lds) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return pd::fail(PD_ELAUNCH, "pd_polar: cannot reserve %zu bytes of LDS", lds);
     return PD_OK;
+}
+
+// workgroup size of the fast-normals kernel: 1024 = 4 waves per SIMD on one workgroup per CU (tuning knob:
+// PD_POLAR_THREADS = 256 | 512 | 1024)
+int fast_threads() {
+    static const int v = [] {
+        const char* e = getenv("PD_POLAR_THREADS");
+        const int t = e ? atoi(e) : 0;
+        return (t == 256 || t == 512 || t == 1024) ? t : 1024;
+    }();
+    return v;
+}
+bool plain_stores() {
+    static const bool v = [] { const char* e = getenv("PD_POLAR_PLAIN_STORES"); return e && e[0] == '1'; }();
+    return v;
 }
 
 }  // namespace
@@ -649,23 +787,24 @@ extern "C" int pd_polar_normals_from_xolp(const void* xolp, void* normals, const
     if (B == 0) return PD_OK;
     PD_REQUIRE(xolp && normals && tables, "pd_polar_normals_from_xolp: null pointer");
     PD_REQUIRE(pd::aligned16(xolp) && pd::aligned16(normals) && pd::aligned16(tables), "pd_polar_normals_from_xolp: unaligned");
-    PD_REQUIRE(tables_bytes >= sizeof(PolarHeader) + size_t(kLutCount) * 4, "pd_polar_normals_from_xolp: tables blob too small");
-    const size_t lds = lds_from_blob_bytes(tables_bytes);
-    PD_REQUIRE(lds > 0 && lds <= 160 * 1024, "pd_polar_normals_from_xolp: tables blob has an unexpected size");
-    const bool precise = (flags & PD_POLAR_FAST_NORMALS) == 0;
+    const int nk = nk_from_blob_bytes(tables_bytes);
+    PD_REQUIRE(nk > 0, "pd_polar_normals_from_xolp: tables blob has an unexpected size");
+    const bool precise = (flags & PD_POLAR_PRECISE_NORMALS) != 0;
+    const size_t lds = img_bytes_for(nk, precise);
     {
-        int rc = precise ? set_lds_limit(normals_from_xolp_kernel<true>, lds) : set_lds_limit(normals_from_xolp_kernel<false>, lds);
+        int rc = precise ? set_lds_limit(normals_from_xolp_kernel<true, kThreadsP>, lds)
+                         : set_lds_limit(normals_from_xolp_kernel<false, 1024>, lds);
         if (rc) return rc;
     }
     const long qpi = P / 4, total = qpi * B;
-    const int nth = precise ? kThreadsN : kThreadsF;
+    const int nth = precise ? kThreadsP : 1024;
     long blocks = (total + nth - 1) / nth;
     if (blocks > 256) blocks = 256;
     if (precise)
-        hipLaunchKernelGGL(normals_from_xolp_kernel<true>, dim3((unsigned)blocks), dim3(kThreadsN), lds, (hipStream_t)stream,
+        hipLaunchKernelGGL((normals_from_xolp_kernel<true, kThreadsP>), dim3((unsigned)blocks), dim3(kThreadsP), lds, (hipStream_t)stream,
                            (const float*)xolp, (float*)normals, (const char*)tables, P, qpi, total);
     else
-        hipLaunchKernelGGL(normals_from_xolp_kernel<false>, dim3((unsigned)blocks), dim3(kThreadsF), lds, (hipStream_t)stream,
+        hipLaunchKernelGGL((normals_from_xolp_kernel<false, 1024>), dim3((unsigned)blocks), dim3(1024), lds, (hipStream_t)stream,
                            (const float*)xolp, (float*)normals, (const char*)tables, P, qpi, total);
     return pd::check_launch("pd_polar_normals_from_xolp");
 }
@@ -682,7 +821,8 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
     PD_REQUIRE(Wout >= W, "pd_polar_fwd: output pitch %d < W %d", Wout, W);
     PD_REQUIRE(Wout == W ? P % 4 == 0 : (W % 4 == 0 && Wout % 4 == 0),
                "pd_polar_fwd: H*W (or W and the output pitch, when they differ) must be multiples of 4");
-    PD_REQUIRE(tables_bytes >= sizeof(PolarHeader) + size_t(kLutCount) * 4, "pd_polar_fwd: tables blob too small");
+    const int nk = nk_from_blob_bytes(tables_bytes);
+    PD_REQUIRE(nk > 0, "pd_polar_fwd: tables blob too small or of an unexpected size");
     PD_REQUIRE(pd::aligned16(pol) && pd::aligned16(xolp) && pd::aligned16(xolp_std) && pd::aligned16(normals) &&
                    pd::aligned16(ints) && pd::aligned16(tables) && (!mask || pd::aligned16(mask)),
                "pd_polar_fwd: pointers must be 16-byte aligned");
@@ -690,11 +830,11 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
     const long Pout = (long)H * Wout;
     const bool pitched = Wout != W;
     const bool need_normals = normals != nullptr || ints != nullptr;
-    const bool precise = (flags & PD_POLAR_FAST_NORMALS) == 0;
-    // LDS image size is fixed by the table node counts (96,232 bytes for the default 1000/625/375 nodes)
-    const size_t lds = need_normals ? lds_from_blob_bytes(tables_bytes) : 0;
-    PD_REQUIRE(!need_normals || (lds > 0 && lds <= 160 * 1024), "pd_polar_fwd: tables blob has an unexpected size");
-    const int nth = need_normals ? (precise ? kThreadsN : kThreadsF) : kThreads;
+    const bool precise = (flags & PD_POLAR_PRECISE_NORMALS) != 0;
+    // LDS image: 64 KB of bucket records + the keys + 16 (fast) or 32 (precise) bytes per bin
+    const size_t lds = need_normals ? img_bytes_for(nk, precise) : 0;
+    const bool nt = !plain_stores();
+    const int nth = need_normals ? (precise ? kThreadsP : (nt ? fast_threads() : 512)) : kThreads;
     // 32-bit addressing inside the kernel: at most 2^30 elements per output tensor and 2^31 quads per launch
     PD_REQUIRE(9 * Pout < (1L << 30), "pd_polar_fwd: image too large (%ld output pixels)", Pout);
     const long max_b = (1L << 30) / (9 * Pout);
@@ -708,7 +848,7 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
         g.P = (unsigned)P; g.Pout = (unsigned)Pout; g.flags = flags;
         const long total = (long)nb * (Pout / 4);
         long blocks = (total + nth - 1) / nth;
-        // with normals: persistent, one workgroup per CU (the 96 KB table image is staged once per CU);
+        // with normals: persistent, one workgroup per CU (the table image is staged once per CU);
         // XOLP only: no tables to amortise -> one quad per thread, hardware-scheduled (measured 1.4x faster)
         if (need_normals && blocks > 256) blocks = 256;
         const long step = blocks * nth;
@@ -727,11 +867,18 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
             return PD_OK;
         };
         if (mode == PD_POLAR_LS) {
-            if (!need_normals) rc = go(polar_kernel<PD_POLAR_LS, false, false>);
-            else rc = precise ? go(polar_kernel<PD_POLAR_LS, true, true>) : go(polar_kernel<PD_POLAR_LS, true, false>);
+            if (!need_normals) rc = nt ? go(polar_kernel<PD_POLAR_LS, OUT_XOLP, kThreads, true>) : go(polar_kernel<PD_POLAR_LS, OUT_XOLP, kThreads, false>);
+            else if (precise) rc = go(polar_kernel<PD_POLAR_LS, OUT_PRECISE, kThreadsP, true>);
+            else if (!nt) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, false>);
+            else if (nth == 256) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 256, true>);
+            else if (nth == 512) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, true>);
+            else rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true>);
         } else {
-            if (!need_normals) rc = go(polar_kernel<PD_POLAR_STOKES, false, false>);
-            else rc = precise ? go(polar_kernel<PD_POLAR_STOKES, true, true>) : go(polar_kernel<PD_POLAR_STOKES, true, false>);
+            if (!need_normals) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_XOLP, kThreads, true>);
+            else if (precise) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_PRECISE, kThreadsP, true>);
+            else if (nth == 256) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_FAST, 256, true>);
+            else if (nth == 512) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_FAST, 512, true>);
+            else rc = go(polar_kernel<PD_POLAR_STOKES, OUT_FAST, 1024, true>);
         }
     }
     if (rc) return rc;

@@ -66,13 +66,13 @@ def _device_tables(n, device_index):
 
 
 def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=None, out_width=None, out=None,
-                  precise=True, ieee_rho=False):
+                  precise=False, ieee_rho=False):
     """Run K1 on ``pol`` [B,4,H,W] uint8 (planes 0/45/90/135 deg) on the GPU.
 
     want: any of "xolp", "xolp_std", "normals", "ints".  Returns a dict of fp32 NCHW tensors
     ([B,2,H,W], [B,2,H,W], [B,9,H,W]) and the int32 [B,5,H,W] by-products.  out_width > W makes every
     output [.., H, out_width] with the extra right columns zero (612 -> 640 padding for the network).
-    precise=False selects PD_POLAR_FAST_NORMALS (fp32 normals within ~1e-7 of the default fp64 path);
+    precise=True selects PD_POLAR_PRECISE_NORMALS (fp64 theta trig; the default fp32 path is within ~3e-7 of it);
     ieee_rho=True selects PD_POLAR_IEEE_RHO (the literal fp64 sqrt/div sequence for every pixel: same bits, slower).
     """
     if not (isinstance(pol, torch.Tensor) and pol.is_cuda):
@@ -95,11 +95,11 @@ def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=No
     with torch.cuda.device(pol.device):
         check(lib.pd_polar_fwd(ptr(pol), ptr(mask), ptr(out.get("xolp")), ptr(out.get("xolp_std")),
                                ptr(out.get("normals")), ptr(out.get("ints")), ptr(tables), tables.numel(),
-                               B, H, W, Wout, mode, int(not precise) | (2 if ieee_rho else 0), stream_ptr()), "pd_polar_fwd")
+                               B, H, W, Wout, mode, int(bool(precise)) | (2 if ieee_rho else 0), stream_ptr()), "pd_polar_fwd")
     return out
 
 
-def normals_from_xolp(xolp, n=1.5, precise=True):
+def normals_from_xolp(xolp, n=1.5, precise=False):
     """ShallowNormalsEncoder.get_normals on the GPU: fp32 [B,2,H,W] (DoLP, AoLP) -> fp32 [B,9,H,W]."""
     if not (isinstance(xolp, torch.Tensor) and xolp.is_cuda):
         raise RuntimeError("normals_from_xolp needs a CUDA(HIP) tensor; there is no CPU fallback")
@@ -111,5 +111,5 @@ def normals_from_xolp(xolp, n=1.5, precise=True):
     out = torch.empty((B, 9, H, W), dtype=torch.float32, device=xolp.device)
     with torch.cuda.device(xolp.device):
         check(lib.pd_polar_normals_from_xolp(ptr(xolp), ptr(out), ptr(tables), tables.numel(), B, H, W,
-                                             int(not precise), stream_ptr()), "pd_polar_normals_from_xolp")
+                                             int(bool(precise)), stream_ptr()), "pd_polar_normals_from_xolp")
     return out

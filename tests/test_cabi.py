@@ -39,68 +39,109 @@ def test_table_blob_numpy_vs_oracle_tables():
 
 
 BUCKETS = 4096
+SQRT_MAGIC = 0x1fbd1df5
+LUT = 511 * 511
 
 
-def _blob_offsets(nk=2000, buckets=BUCKETS):
-    off_bstart = ((nk + 3) // 4 * 4 + 4) * 4        # keys padded with +inf: four are read at once
-    off_rank = off_bstart + (buckets + 4) * 2 + 8
-    off_bins = (off_rank + (nk + 1) * 8 + 15) // 16 * 16
-    return off_bstart, off_rank, off_bins
+def _header(blob):
+    h = np.frombuffer(blob[:64], dtype=np.uint32)
+    names = ("magic", "n_d", "n_s1", "n_s2", "off_lut", "off_lut4", "off_img_fast", "img_fast_bytes",
+             "off_img_precise", "img_precise_bytes", "common_bytes", "total_bytes")
+    d = {k: int(v) for k, v in zip(names, h[:12])}
+    d["bscale"] = np.frombuffer(blob[48:52], dtype=np.float32)[0]
+    d["n_buckets"] = int(h[13])
+    return d
+
+
+def _bucket_of(rho, bscale):
+    """The device's bucket function (csrc/polar.hip:bucket_of): integer shift/add, one fp32 multiply, truncation."""
+    u = np.asarray(rho, np.float32).view(np.uint32).copy()
+    u[u >= 0x80000000] = 0
+    t = ((u >> 1) + np.uint32(SQRT_MAGIC)).view(np.float32)
+    v = t * np.float32(bscale)
+    return np.minimum(v, np.float32(BUCKETS - 1)).astype(np.int64)
 
 
 def test_table_blob_layout_and_lut():
     blob = pdpolar.pack_tables(pdpolar.theta_tables_numpy(1.5)).numpy().tobytes()
-    hdr = np.frombuffer(blob[:32], dtype=np.uint32)
-    assert hdr[0] == 0x50444c34 and tuple(hdr[1:4]) == (1000, 625, 375)
-    off_lut, off_lds, lds_bytes, total = (int(v) for v in hdr[4:8])
-    assert total == len(blob) and lds_bytes <= 160 * 1024
-    lut = np.frombuffer(blob[off_lut:off_lut + 511 * 511 * 4], dtype=np.float32).reshape(511, 511)
+    h = _header(blob)
+    assert h["magic"] == 0x50444c35 and (h["n_d"], h["n_s1"], h["n_s2"]) == (1000, 625, 375)
+    assert h["total_bytes"] == len(blob) and h["n_buckets"] == BUCKETS
+    assert h["img_fast_bytes"] % 1024 == 0 and h["img_precise_bytes"] % 1024 == 0 and h["img_precise_bytes"] <= 160 * 1024
+    lut = np.frombuffer(blob[h["off_lut"]:h["off_lut"] + LUT * 4], dtype=np.float32).reshape(511, 511)
     d = np.arange(-255, 256, dtype=np.float64)
     ref = (0.5 * np.arctan2(d[:, None] / 2, d[None, :] / 2)).astype(np.float32)   # xolp.py:30
     np.testing.assert_array_equal(lut, ref)
     assert lut[255, 0] == np.float32(np.pi / 2)            # canonical branch: x2 == 0, x1 < 0 -> +pi/2
-    # merged keys are floor32 of the fp64 nodes, sorted; rank[p] = per-table counts among the first p keys,
-    # so rank[searchsorted(merged, v)] reproduces the three per-table searchsorted results for fp32 v
+    # float4 LUT of the fast normals: phi, cos(fl32 phi), sin(fl32 phi) correctly rounded, 0
+    lut4 = np.frombuffer(blob[h["off_lut4"]:h["off_lut4"] + LUT * 16], dtype=np.float32).reshape(511, 511, 4)
+    np.testing.assert_array_equal(lut4[..., 0], ref)
+    np.testing.assert_array_equal(lut4[..., 1], np.cos(ref.astype(np.float64)).astype(np.float32))
+    np.testing.assert_array_equal(lut4[..., 2], np.sin(ref.astype(np.float64)).astype(np.float32))
+    assert not lut4[..., 3].any()
+
+    # one-read search: idx_T = base_T + (key_T < rho) reproduces clip(searchsorted(x_T, rho, 'left'), 1, n_T - 1)
+    # for every fp32 rho whose bucket is not flagged; flagged buckets are few and take exact binary searches
     nk = 2000
-    img = blob[off_lds:off_lds + lds_bytes]
-    off_bstart, off_rank, off_bins = _blob_offsets(nk)
-    mkeys = np.frombuffer(img[:nk * 4], dtype=np.float32)
-    assert np.all(np.diff(mkeys) >= 0)
-    rank = np.frombuffer(img[off_rank:off_rank + (nk + 1) * 8], dtype=np.uint16).reshape(nk + 1, 4)
-    assert tuple(rank[0][:3]) == (0, 0, 0) and tuple(rank[nk][:3]) == (1000, 625, 375)
-    tabs = [opolar.theta_tables(1.5)[k][0] for k in ("diffuse", "spec1", "spec2")]
+    img = blob[h["off_img_fast"]:h["off_img_fast"] + h["img_fast_bytes"]]
+    assert h["common_bytes"] == BUCKETS * 16 + nk * 4
+    assert blob[h["off_img_precise"]:h["off_img_precise"] + h["common_bytes"]] == img[:h["common_bytes"]]
+    rec = np.frombuffer(img[:BUCKETS * 16], dtype=np.uint32).reshape(BUCKETS, 4)
+    keys_in = rec[:, :3].copy().view(np.float32)
+    keys = np.frombuffer(img[BUCKETS * 16:BUCKETS * 16 + nk * 4], dtype=np.float32)
+    names = ("diffuse", "spec1", "spec2")
+    tabs = [opolar.theta_tables(1.5)[k][0] for k in names]
+    ns = [len(t) for t in tabs]
+    o = 0
+    for t, n in zip(tabs, ns):       # keys = floor32 of the fp64 nodes
+        k32 = t.astype(np.float32)
+        k32 = np.where(k32.astype(np.float64) > t, np.nextafter(k32, np.float32(-np.inf)), k32)
+        np.testing.assert_array_equal(keys[o:o + n], k32)
+        o += n
     rng = np.random.default_rng(0)
-    q = np.concatenate([rng.random(5000).astype(np.float32) * 1.2, mkeys[::7], np.float32([0, 1, 2, 0.38461538])])
-    pos = np.searchsorted(mkeys, q, side="left")
+    q = np.concatenate([rng.random(20000).astype(np.float32) * 1.2, keys[::3], np.nextafter(keys[::5], np.float32(2)),
+                        np.float32([0, 1, 2, 0.38461538, 1e-7, 3e-6, 100.0, np.inf, -1.0, -0.0])])
+    b = _bucket_of(q, h["bscale"])
+    multi = (rec[b, 3] >> 30) != 0
+    assert multi.mean() < 0.02 and ((rec[:, 3] >> 30) != 0).sum() < 24
     for t in range(3):
-        np.testing.assert_array_equal(rank[pos, t], np.searchsorted(tabs[t], q.astype(np.float64), side="left"))
-    # sqrt(rho) bucket index: the true position always lies in [bstart[b-1], bstart[b+2]] for the device's b
-    nb = BUCKETS + 4
-    bstart = np.frombuffer(img[off_bstart:off_bstart + nb * 2], dtype=np.uint16).astype(int)
-    bscale = np.frombuffer(img[off_bstart + nb * 2:off_bstart + nb * 2 + 4], dtype=np.float32)[0]
-    assert np.all(np.diff(bstart) >= 0) and bstart[0] == 0 and bstart[BUCKETS + 1] == nk
-    b = np.minimum(np.sqrt(np.maximum(q, 0)).astype(np.float32) * bscale, BUCKETS).astype(int)
-    assert np.all(bstart[np.maximum(b - 1, 0)] <= pos) and np.all(pos <= bstart[b + 2])
-    span = bstart[3:] - bstart[:-3]
-    assert span.max() <= 32 and (span > 4).mean() < 0.01   # <= 4 candidate keys (one read each) almost everywhere
-    assert np.all(np.isinf(np.frombuffer(img[nk * 4:off_bstart], dtype=np.float32)))   # +inf key padding
-    bins = np.frombuffer(img[off_bins:off_bins + nk * 32], dtype=np.float64).reshape(nk, 4)
+        want = np.searchsorted(tabs[t], q.astype(np.float64), side="left").clip(1, ns[t] - 1)
+        got = ((rec[b, 3] >> (10 * t)) & 1023).astype(np.int64) + (keys_in[b, t] < q)
+        np.testing.assert_array_equal(got[~multi], want[~multi])
+    # the flagged region: rho within 5e-3 of the specular maximum plus slivers near zero
+    flagged = np.flatnonzero((rec[:, 3] >> 30) != 0)
+    grid = np.linspace(0, 1.05, 400001).astype(np.float32)
+    gb = _bucket_of(grid, h["bscale"])
+    bad = grid[np.isin(gb, flagged)]
+    assert np.all((bad > 0.995) | (bad < 0.02))
+    # bins: fast float4 (x_lo32, slope32, c_hi, c_lo|j) and precise fp64 (x_lo, slope, sin y_lo, cos y_lo)
     x, y = opolar.theta_tables(1.5)["diffuse"]
+    pimg = blob[h["off_img_precise"]:h["off_img_precise"] + h["img_precise_bytes"]]
+    bins = np.frombuffer(pimg[h["common_bytes"]:h["common_bytes"] + nk * 32], dtype=np.float64).reshape(nk, 4)
+    slope = (y[1:] - y[:-1]) / (x[1:] - x[:-1])
     np.testing.assert_array_equal(bins[1:1000, 0], x[:-1])
-    np.testing.assert_array_equal(bins[1:1000, 1], (y[1:] - y[:-1]) / (x[1:] - x[:-1]))
+    np.testing.assert_array_equal(bins[1:1000, 1], slope)
     np.testing.assert_allclose(bins[1:1000, 2], np.sin(y[:-1]), rtol=0, atol=2e-16)
     np.testing.assert_allclose(bins[1:1000, 3], np.cos(y[:-1]), rtol=0, atol=2e-16)
+    fb = np.frombuffer(img[h["common_bytes"]:h["common_bytes"] + nk * 16], dtype=np.float32).reshape(nk, 4)[1:1000]
+    j = (fb[:, 3].copy().view(np.uint32) & 1).astype(np.float64)
+    np.testing.assert_array_equal(j, (0.5 * (y[:-1] + y[1:]) > np.pi / 4).astype(np.float64))
+    # theta at the bin's upper node from the fast record == y_hi within 2e-7
+    rho_hi = keys[1:1000]
+    r = fb[:, 1].astype(np.float64) * (rho_hi - fb[:, 0]).astype(np.float64) + fb[:, 2] + fb[:, 3]
+    np.testing.assert_allclose(r + j * np.pi / 2, slope * (rho_hi.astype(np.float64) - x[:-1]) + y[:-1], rtol=0, atol=2e-7)
 
 
 def test_libm_tables_close_to_numpy_tables():
     a = pdpolar.pack_tables(pdpolar.theta_tables_numpy(1.5)).numpy()
     b = pdpolar.build_tables_libm(1.5).numpy()
     assert a.shape == b.shape
-    off = 64 + (511 * 511 * 4 + 15) // 16 * 16
-    np.testing.assert_array_equal(a[:off], b[:off])         # header + LUT identical
-    _, _, off_bins = _blob_offsets()
-    fa = np.frombuffer(a[off + off_bins:off + off_bins + 2000 * 32].tobytes(), dtype=np.float64).reshape(2000, 4)
-    fb = np.frombuffer(b[off + off_bins:off + off_bins + 2000 * 32].tobytes(), dtype=np.float64).reshape(2000, 4)
+    h = _header(a.tobytes())
+    off = h["off_img_fast"]
+    np.testing.assert_array_equal(a[:off], b[:off])         # header + LUTs identical
+    s = h["off_img_precise"] + h["common_bytes"]
+    fa = np.frombuffer(a[s:s + 2000 * 32].tobytes(), dtype=np.float64).reshape(2000, 4)
+    fb = np.frombuffer(b[s:s + 2000 * 32].tobytes(), dtype=np.float64).reshape(2000, 4)
     # x_lo and sin/cos(y_lo) within a few ulp (libm vs NumPy sin/cos); slopes amplify that near the flat ends
     np.testing.assert_allclose(fa[:, [0, 2, 3]], fb[:, [0, 2, 3]], rtol=1e-12, atol=1e-15)
 
