@@ -171,11 +171,26 @@ def main():
     # durations the instrumented steps run them serially on one stream)
     overlap, PF.USE_WGRAD_STREAM = PF.USE_WGRAD_STREAM, False
     ops.PROFILE = []
-    for _ in range(2):
+    from polardepth import polar as pdpolar
+    k1_step_events, k1_real = [], pdpolar.polar_forward
+
+    def k1_timed(*a, **kw):           # K1 inside the step: HIP events around the launch, on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = k1_real(*a, **kw)
+        e1.record()
+        k1_step_events.append((e0, e1))
+        return out
+
+    pdpolar.polar_forward = k1_timed
+    for _ in range(4):
         train_step(tr, batch)
     torch.cuda.synchronize()
+    pdpolar.polar_forward = k1_real
     prof, ops.PROFILE = ops.PROFILE, None
     PF.USE_WGRAD_STREAM = overlap
+    INSTR_STEPS = 4
+    k1_in_step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in k1_step_events)[len(k1_step_events) // 2]
     by_kernel = {}
     for name, flops, e0, e1, _shape in prof:
         k = by_kernel.setdefault(name, [0.0, 0.0, 0])
@@ -183,7 +198,7 @@ def main():
     dom = max(by_kernel.items(), key=lambda kv: kv[1][1])
     dname, (dflops, dtime, dcount) = dom
     achieved = dflops / dtime / 1e12
-    step_conv_time = sum(v[1] for v in by_kernel.values()) / 2
+    step_conv_time = sum(v[1] for v in by_kernel.values()) / INSTR_STEPS
     # HBM traffic per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, gfx950
     # FETCH_SIZE x2 correction) cannot run inside this process -- the committed summary of those passes is quoted
     traffic, traffic_src = None, None
@@ -197,9 +212,9 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                 "algorithmic_flops_per_launch": round(dflops / dcount),
-                "launches_per_step": dcount // 2, "avg_launch_ms": round(dtime / dcount * 1e3, 4),
+                "launches_per_step": dcount // INSTR_STEPS, "avg_launch_ms": round(dtime / dcount * 1e3, 4),
                 "all_conv_kernels_ms_per_step": round(step_conv_time * 1e3, 2),
-                "all_conv_kernels_TFLOPs": round(sum(v[0] for v in by_kernel.values()) / 2 /
+                "all_conv_kernels_TFLOPs": round(sum(v[0] for v in by_kernel.values()) / INSTR_STEPS /
                                                  max(step_conv_time, 1e-9) / 1e12, 2)}
 
     # ---- second half of the metric ("XOLP-kernel GB/s"): K1 exactly as the step calls it (512x612 planes in,
@@ -207,7 +222,6 @@ def main():
     # = 4 B read + (8 + 36) B written per frame pixel.  Every launch works on another of
     # K1_SETS buffer sets (3 x 248 MB: beyond the 256 MB Infinity Cache), as in the step, where 79 ms of other
     # traffic separate two K1 launches; the cache-resident figure (one set) is reported beside it.
-    from polardepth import polar as pdpolar
     K1_SETS = 3
     pol = batch[("pol", 0, 0)]
     pols = [pol] + [pol.roll(7 * i, dims=3).contiguous() for i in range(1, K1_SETS)]
@@ -226,12 +240,18 @@ def main():
     k1_ms = time_k1(K1_SETS)
     k1_ms_warm = time_k1(1)
     k1_bytes = args.batch * H * FRAME_W * 48
-    xolp_kernel = {"kernel": "polar_kernel<LS,fast normals,1024,nt>", "bound": "hbm",
-                   "achieved": round(k1_bytes / k1_ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
-                   "frac": round(k1_bytes / k1_ms / 1e6 / 8000.0, 4), "algorithmic_bytes_per_launch": k1_bytes,
-                   "avg_launch_ms": round(k1_ms, 4), "buffer_sets": K1_SETS,
-                   "cache_resident_GBps": round(k1_bytes / k1_ms_warm / 1e6, 1),
-                   "streaming_ceiling_note": "same access shape with trivial compute: 5.6-5.9 TB/s (tools/membench2.hip)"}
+    # `achieved` is the launch INSIDE the training step (what a rocprof trace of this command shows): the step streams
+    # gigabytes between two K1 launches, so K1 starts with its LUT / table image evicted and the caches holding the
+    # predecessor's lines; back to back on rotating buffers (HBM-resident data, warm LUT) the same kernel is faster.
+    xolp_kernel = {"kernel": "polar_kernel<LS,fast normals,1024,nt,hot>", "bound": "hbm",
+                   "achieved": round(k1_bytes / k1_in_step_ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                   "frac": round(k1_bytes / k1_in_step_ms / 1e6 / 8000.0, 4), "algorithmic_bytes_per_launch": k1_bytes,
+                   "avg_launch_ms": round(k1_in_step_ms, 4), "where": "inside the train step (HIP events, median of 4 steps)",
+                   "back_to_back": {"buffer_sets": K1_SETS, "avg_launch_ms": round(k1_ms, 4),
+                                    "GBps": round(k1_bytes / k1_ms / 1e6, 1), "frac": round(k1_bytes / k1_ms / 1e6 / 8000.0, 4),
+                                    "cache_resident_GBps": round(k1_bytes / k1_ms_warm / 1e6, 1)},
+                   "streaming_ceiling_note": "same access shape, trivial compute, B=16: 4.9-5.0 TB/s back to back, "
+                                             "3.7 TB/s after a cache-replacing predecessor (tools/membench2.hip d)"}
     del pols, k1_outs
 
     result = {

@@ -201,9 +201,10 @@ int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int act, void* s
 /* Gradient of ReflectionPad2d(1): dxp [N,H+2,W+2,C] -> dx [N,H,W,C]  (layers.py:372). */
 int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, int C, void* stream);
 /* torch.optim.Adam step (trainer.py:238,442) over one flat fp32 buffer; grads are pre-multiplied
- * by grad_scale (1/world_size after the RCCL sum). */
-int pd_adam_step(void* p, const void* g, void* m, void* v, long n, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, long step, float grad_scale, void* stream);
+ * by grad_scale (1/world_size after the RCCL sum).  zero_grad != 0 also clears g in the same pass
+ * (trainer.py:436 zero_grad of the NEXT iteration, without a separate 85 MB memset). */
+int pd_adam_step(void* p, void* g, void* m, void* v, long n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, long step, float grad_scale, int zero_grad, void* stream);
 
 /* ------------------------------------------------------------------------- K5
  * Multi-scale supervised loss (trainer.py:1126-1150,1241-1265,1298-1309; layers.py:62-71,452-465).

@@ -479,7 +479,17 @@ __global__ __launch_bounds__(EW_T) void reflect_fold_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------- fused Adam over a flat buffer
-__global__ __launch_bounds__(EW_T) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+// Parameters, moments and (ZERO_G) the cleared gradient leave with nontemporal stores: 340 MB that nothing reads
+// before the next step's kernels have streamed gigabytes -- left dirty in the caches, the kernel that follows
+// (K1 of the next step) pays for their write-back (measured: 50 -> 87 us, tools/k1_instep_probe.py).
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+    const adam_f4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<adam_f4*>(p));
+}
+
+template <bool ZERO_G>
+__global__ __launch_bounds__(EW_T) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1,
                                                     float bc2_sqrt, float grad_scale) {
@@ -495,13 +505,15 @@ __global__ __launch_bounds__(EW_T) void adam_kernel(float* __restrict__ p, const
                 // torch.optim.Adam: p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
                 P[j] -= (lr / bc1) * (M[j] / (sqrtf(V[j]) / bc2_sqrt + eps));
             }
-            st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
+            st4_nt(p + i, pp); st4_nt(m + i, mm); st4_nt(v + i, vv);
+            if (ZERO_G) st4_nt(g + i, make_float4(0.f, 0.f, 0.f, 0.f));
         } else {
             for (long j = i; j < n; ++j) {
                 float gr = g[j] * grad_scale + wd * p[j];
                 m[j] = beta1 * m[j] + (1.f - beta1) * gr;
                 v[j] = beta2 * v[j] + (1.f - beta2) * gr * gr;
                 p[j] -= (lr / bc1) * (m[j] / (sqrtf(v[j]) / bc2_sqrt + eps));
+                if (ZERO_G) g[j] = 0.f;
             }
         }
     }
@@ -698,16 +710,19 @@ extern "C" int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, i
     return pd::check_launch("pd_reflect_fold");
 }
 
-extern "C" int pd_adam_step(void* p, const void* g, void* m, void* v, long n, float lr, float beta1, float beta2,
-                            float eps, float weight_decay, long step, float grad_scale, void* stream) {
+extern "C" int pd_adam_step(void* p, void* g, void* m, void* v, long n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, long step, float grad_scale, int zero_grad, void* stream) {
     PD_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "pd_adam_step: bad arguments");
     PD_REQUIRE(pd::aligned16(p) && pd::aligned16(g) && pd::aligned16(m) && pd::aligned16(v), "pd_adam_step: unaligned");
     if (n == 0) return PD_OK;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid((n + 3) / 4)), dim3(EW_T), 0, (hipStream_t)stream, (float*)p,
-                       (const float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
-                       grad_scale);
+    if (zero_grad)
+        hipLaunchKernelGGL(adam_kernel<true>, dim3(ew_grid((n + 3) / 4)), dim3(EW_T), 0, (hipStream_t)stream, (float*)p,
+                           (float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, dim3(ew_grid((n + 3) / 4)), dim3(EW_T), 0, (hipStream_t)stream, (float*)p,
+                           (float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
     return pd::check_launch("pd_adam_step");
 }
 

@@ -388,11 +388,12 @@ __device__ __forceinline__ void sincos_bin(const double* __restrict__ bin, doubl
 }
 
 // Out of line: the fp64 evaluation for the (rare in real frames) pixels whose rho lies beyond a table.
-__device__ __noinline__ void sincos_bin_slow(const double* __restrict__ gbin, float rho, float& s, float& c) {
+// (returns by value: reference outputs of a non-inlined function live in scratch memory, and the caller's reloads
+// -- on the hot path, behind every table -- wait for every older load of the wave)
+__device__ __noinline__ float2 sincos_bin_slow(const double* __restrict__ gbin, float rho) {
     double sd, cd;
     sincos_bin(gbin, static_cast<double>(rho), sd, cd);
-    s = static_cast<float>(sd);
-    c = static_cast<float>(cd);
+    return make_float2(static_cast<float>(sd), static_cast<float>(cd));
 }
 
 // Fast path: r = theta - j*pi/2 in fp32 from the two-float bin constant ((rho - x_lo32) is exact or carries a
@@ -406,7 +407,9 @@ __device__ __forceinline__ void sincos_bin_fast(const float4 fb, const double* _
         s = j ? cs : sn;
         c = j ? -sn : cs;
     } else {
-        sincos_bin_slow(gbin, rho, s, c);
+        const float2 sc = sincos_bin_slow(gbin, rho);
+        s = sc.x;
+        c = sc.y;
     }
 }
 
@@ -543,7 +546,7 @@ constexpr int OUT_FAST = 1;      // + normals, fp32 path (default)
 constexpr int OUT_PRECISE = 2;   // + normals, fp64 theta trig (PD_POLAR_PRECISE_NORMALS)
 
 constexpr int kThreads = 512;    // XOLP-only kernels: 4 workgroups per CU
-constexpr int kThreadsP = 768;   // fp64 normals: one 12-wave workgroup per CU (3 waves/SIMD, <= 168 VGPRs)
+constexpr int kThreadsP = 512;   // fp64 normals: one 8-wave workgroup per CU (2 waves/SIMD, <= 256 VGPRs: no spills)
 
 // Launch geometry: every index is 32-bit (the host splits a batch whose planes would exceed 2^32 bytes).
 // One image is Hrows rows of wq_in quads (4 pixels) in and wq_out >= wq_in quads out; with a pitched output
@@ -573,7 +576,9 @@ __device__ __forceinline__ void advance(QuadPos& q, const PolarGeo& g) {
     }
 }
 
-template <int MODE, int OUT, int NTH, bool NT>
+// HOT: the training step's output set (xolp + normals, nothing else) known at compile time -- no pointer tests
+// around the stores, and a store count the compiler can put into its s_waitcnt vmcnt(N).
+template <int MODE, int OUT, int NTH, bool NT, bool HOT = false>
 __global__ __launch_bounds__(NTH) void polar_kernel(
     const uint8_t* __restrict__ pol, const uint8_t* __restrict__ mask, float* __restrict__ xolp,
     float* __restrict__ xolp_std, float* __restrict__ normals, int* __restrict__ ints,
@@ -586,6 +591,44 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
     const float* lut = reinterpret_cast<const float*>(blob + h->off_lut);
     const float4* lut4 = reinterpret_cast<const float4*>(blob + h->off_lut4);
     const bool ieee = (g.flags & PD_POLAR_IEEE_RHO) != 0;
+    const bool w_xolp = HOT || xolp != nullptr, w_std = !HOT && xolp_std != nullptr;
+    const bool w_normals = HOT || normals != nullptr, w_ints = !HOT && ints != nullptr;
+
+    // Software pipeline, two quads deep: while quad i is computed, the AoLP gathers of quad i+1 and the plane loads
+    // of quad i+2 are in flight.  Inside the training step the LUT is never cache-resident when K1 starts (the
+    // step streams gigabytes between two launches) and different image regions need different LUT lines, so a
+    // wave meets HBM-latency gathers in every iteration: issued one iteration ahead they cost nothing
+    // (tools/membench2.hip d, tools/k1_instep_probe.py).  Queue order per iteration: gathers(i+1), loads(i+2),
+    // stores(i) -- nothing waits for a store.  The gathers are unconditional (quads past the end and padding
+    // lanes read the centre entry): a conditional load would be waited for at the join.
+    struct Words { uint32_t w0, w45, w90, w135; };
+    const unsigned in_row = 4u * g.wq_in, out_row = 4u * g.wq_out;
+    auto load_words = [&](const QuadPos& p) -> Words {
+        Words w = {0u, 0u, 0u, 0u};
+        if (p.b < g.B && p.cq < g.wq_in) {
+            const unsigned p4 = static_cast<unsigned>(p.b) * 4u * g.P + p.row * in_row + 4u * p.cq;
+            w.w0 = *reinterpret_cast<const uint32_t*>(pol + p4);
+            w.w45 = *reinterpret_cast<const uint32_t*>(pol + (p4 + g.P));
+            w.w90 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P));
+            w.w135 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P));
+        }
+        return w;
+    };
+    struct Gather { float phi[4], cp[4], sp[4]; };
+    auto gather = [&](const Words& w) -> Gather {
+        Gather G;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sh = 8 * j;
+            const float e1 = static_cast<float>((w.w0 >> sh) & 0xffu) - static_cast<float>((w.w90 >> sh) & 0xffu);
+            const float e2 = static_cast<float>((w.w45 >> sh) & 0xffu) - static_cast<float>((w.w135 >> sh) & 0xffu);
+            // (d2 + 255) * 511 + (d1 + 255), exact in fp32
+            const unsigned idx = static_cast<unsigned>(static_cast<int>(fmaf(e2, 511.f, e1 + 130560.f)));
+            if (FAST) { const float4 L = lut4[idx]; G.phi[j] = L.x; G.cp[j] = L.y; G.sp[j] = L.z; }
+            else { G.phi[j] = lut[idx]; G.cp[j] = 1.f; G.sp[j] = 0.f; }
+        }
+        return G;
+    };
 
     // first quad of this thread; its planes are requested before the tables are staged
     QuadPos q;
@@ -596,17 +639,13 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
         q.b = static_cast<int>(q.row / static_cast<unsigned>(g.Hrows));
         q.row -= static_cast<unsigned>(q.b) * static_cast<unsigned>(g.Hrows);
     }
-    const unsigned in_row = 4u * g.wq_in, out_row = 4u * g.wq_out;
-    uint32_t w0 = 0, w45 = 0, w90 = 0, w135 = 0;
-    if (q.b < g.B && q.cq < g.wq_in) {
-        const unsigned p4 = static_cast<unsigned>(q.b) * 4u * g.P + q.row * in_row + 4u * q.cq;
-        w0 = *reinterpret_cast<const uint32_t*>(pol + p4);
-        w45 = *reinterpret_cast<const uint32_t*>(pol + (p4 + g.P));
-        w90 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P));
-        w135 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P));
-    }
+    Words wc = load_words(q);
+    QuadPos qn = q;
+    advance(qn, g);
+    Words wn = load_words(qn);
     Tabs tabs;
     if (NORMALS) stage_tables<PRECISE>(blob, smem, NTH, tabs);
+    Gather Gc = gather(wc);
 
     while (q.b < g.B) {
         const unsigned po = q.row * out_row + 4u * q.cq;     // first output pixel of the quad inside its plane
@@ -616,37 +655,25 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
         uint32_t wm = 0x01010101u;
         if (MODE == PD_POLAR_STOKES && mask && !pad) wm = *reinterpret_cast<const uint32_t*>(mask + pin);
 
-        // bytes -> differences, AoLP gathers (L2-resident LUTs) first, then the next quad's planes: the gathers
-        // are older in the memory queue, so waiting for them does not wait for the HBM loads behind them
-        float d1[4], d2[4], S[4], s4[4];
-        float4 L[4];
-        float o_phi[4];
+        const Gather Gn = gather(wn);
+        __builtin_amdgcn_sched_barrier(0);
+        QuadPos qnn = qn;
+        advance(qnn, g);
+        const Words wnn = load_words(qnn);
+        __builtin_amdgcn_sched_barrier(0);
+
+        float d1[4], d2[4], S[4], s4[4], o_phi[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int sh = 8 * j;
             // v_cvt_f32_ubyteN: byte -> float in one instruction
-            const float f0 = static_cast<float>((w0 >> sh) & 0xffu), f45 = static_cast<float>((w45 >> sh) & 0xffu);
-            const float f90 = static_cast<float>((w90 >> sh) & 0xffu), f135 = static_cast<float>((w135 >> sh) & 0xffu);
+            const float f0 = static_cast<float>((wc.w0 >> sh) & 0xffu), f45 = static_cast<float>((wc.w45 >> sh) & 0xffu);
+            const float f90 = static_cast<float>((wc.w90 >> sh) & 0xffu), f135 = static_cast<float>((wc.w135 >> sh) & 0xffu);
             d1[j] = f0 - f90;
             d2[j] = f45 - f135;
             s4[j] = fmaf(d1[j], d1[j], d2[j] * d2[j]);                      // <= 130050: exact in fp32
             S[j] = MODE == PD_POLAR_LS ? (f0 + f90) + (f45 + f135) : f0 + f90;
-            // (d2 + 255) * 511 + (d1 + 255), exact in fp32
-            const unsigned idx = static_cast<unsigned>(static_cast<int>(fmaf(d2[j], 511.f, d1[j] + 130560.f)));
-            if (FAST) L[j] = lut4[idx];
-            else o_phi[j] = lut[idx];
         }
-        advance(q, g);
-        __builtin_amdgcn_sched_barrier(0);
-        w0 = 0; w45 = 0; w90 = 0; w135 = 0;
-        if (q.b < g.B && q.cq < g.wq_in) {
-            const unsigned p4 = static_cast<unsigned>(q.b) * 4u * g.P + q.row * in_row + 4u * q.cq;
-            w0 = *reinterpret_cast<const uint32_t*>(pol + p4);
-            w45 = *reinterpret_cast<const uint32_t*>(pol + (p4 + g.P));
-            w90 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P));
-            w135 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P));
-        }
-        __builtin_amdgcn_sched_barrier(0);
 
         float o_rho[4], o_n[9][4];
         int o_i[5][4];
@@ -654,9 +681,7 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
         for (int j = 0; j < 4; ++j) {
             if (PRECISE && (j & 1) == 0) __builtin_amdgcn_sched_barrier(0);   // fp64 chains in pairs: register pressure
             const bool on = MODE != PD_POLAR_STOKES || ((wm >> (8 * j)) & 0xffu) != 0;
-            float rho, phi, cp = 1.f, sp = 0.f;
-            if (FAST) { phi = L[j].x; cp = L[j].y; sp = L[j].z; }
-            else phi = o_phi[j];
+            float rho, phi = Gc.phi[j], cp = Gc.cp[j], sp = Gc.sp[j];
             if (MODE == PD_POLAR_STOKES && !on) {   // images are masked first (:117-121); outputs are zero outside
                 rho = 0.f; phi = 0.f; cp = 1.f; sp = 0.f;
                 o_i[0][j] = 0; o_i[1][j] = 0;
@@ -686,12 +711,12 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
                 }
             }
         }
-        if (xolp) {
+        if (w_xolp) {
             float* o = xolp + (static_cast<unsigned>(b) * 2u * g.Pout + po);
             store4<NT>(o, o_rho[0], o_rho[1], o_rho[2], o_rho[3]);
             store4<NT>(o + g.Pout, o_phi[0], o_phi[1], o_phi[2], o_phi[3]);
         }
-        if (xolp_std) {
+        if (w_std) {
             float* o = xolp_std + (static_cast<unsigned>(b) * 2u * g.Pout + po);
             float sr[4], sf[4];
 #pragma unroll
@@ -699,20 +724,20 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
             store4<NT>(o, sr[0], sr[1], sr[2], sr[3]);
             store4<NT>(o + g.Pout, sf[0], sf[1], sf[2], sf[3]);
         }
-        if (NORMALS && normals) {
+        if (NORMALS && w_normals) {
             float* o = normals + (static_cast<unsigned>(b) * 9u * g.Pout + po);
 #pragma unroll
             for (unsigned c = 0; c < 9; ++c) store4<NT>(o + c * g.Pout, o_n[c][0], o_n[c][1], o_n[c][2], o_n[c][3]);
         }
-        if (ints) {
+        if (w_ints) {
             int* o = ints + (static_cast<unsigned>(b) * 5u * g.Pout + po);
             const unsigned nch = NORMALS ? 5 : 2;
 #pragma unroll
             for (unsigned c = 0; c < 5; ++c)
                 if (c < nch) store4i<NT>(o + c * g.Pout, o_i[c][0], o_i[c][1], o_i[c][2], o_i[c][3]);
         }
+        q = qn; wc = wn; Gc = Gn; qn = qnn; wn = wnn;
     }
-
 }
 
 // get_normals() on an existing fp32 XOLP tensor (pre_encoders.py:99-113): [B,2,H,W] -> [B,9,H,W]
@@ -872,6 +897,7 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
             else if (!nt) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, false>);
             else if (nth == 256) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 256, true>);
             else if (nth == 512) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, true>);
+            else if (xolp && normals && !xolp_std && !ints) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true>);
             else rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true>);
         } else {
             if (!need_normals) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_XOLP, kThreads, true>);

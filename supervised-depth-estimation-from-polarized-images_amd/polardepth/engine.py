@@ -38,6 +38,7 @@ class ParamStore:
         self.n_used = offs[self.n_used_params] if self.n_used_params < len(offs) else total
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad_is_zero = True      # set by FusedAdam.step (which clears the gradient in the same pass), reset by backward
         self.offsets = {}
         for (name, p), off in zip(self.entries, offs):
             self.offsets[name] = (off, p.numel())
@@ -62,9 +63,12 @@ class ParamStore:
         pv.copy_(src.to(self.flat.device))
         p.data = pv
         p.grad = gv
+        p._pd_store = self            # functional.grad_buf marks the gradient buffer as written
 
     def zero_grad(self):
-        self.grad.zero_()
+        if not self.grad_is_zero:
+            self.grad.zero_()
+            self.grad_is_zero = True
 
     def used_params(self):
         return [p for _, p in self.entries[:self.n_used_params]]
@@ -73,9 +77,13 @@ class ParamStore:
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr) semantics over a ParamStore, one kernel per step."""
 
-    def __init__(self, store, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, reducer=None):
+    def __init__(self, store, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, reducer=None,
+                 zero_grad_in_step=True):
         self.store = store
         self.reducer = reducer
+        # step() clears the used gradient range in the pass that consumed it, so that the next zero_grad() is free
+        # (unlike torch.optim.Adam, p.grad reads zero after step(); PD_ADAM_KEEP_GRAD=1 keeps torch's behaviour)
+        self.zero_grad_in_step = zero_grad_in_step and os.environ.get("PD_ADAM_KEEP_GRAD") != "1"
         params = [p for _, p in store.entries]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.exp_avg = torch.zeros_like(store.flat)
@@ -102,7 +110,11 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = g["betas"]
         check(lib.pd_adam_step(ptr(self.store.flat), ptr(self.store.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n,
                                float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
-                               self.step_count, float(self.grad_scale), stream_ptr()), "pd_adam_step")
+                               self.step_count, float(self.grad_scale), int(self.zero_grad_in_step), stream_ptr()),
+              "pd_adam_step")
+        if self.zero_grad_in_step:
+            # (the tail behind n_used -- parameters that never receive gradients, e.g. ResNet layer3/4/fc -- is never read)
+            self.store.grad_is_zero = True
 
     # ---- checkpoint interop with torch.optim.Adam ("adam.pth", trainer.py:1614-1617)
     def state_dict(self):

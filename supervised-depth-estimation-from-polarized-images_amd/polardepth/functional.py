@@ -93,6 +93,9 @@ def grad_buf(p):
     """The tensor that receives the gradient of parameter p (allocated zeroed on first use)."""
     if p.grad is None:
         p.grad = torch.zeros_like(p)          # preserve_format: channels_last weights stay channels_last
+    store = getattr(p, "_pd_store", None)
+    if store is not None:
+        store.grad_is_zero = False            # the next zero_grad() has something to clear (unless Adam clears it)
     return p.grad
 
 

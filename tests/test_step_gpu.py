@@ -125,7 +125,9 @@ def test_one_training_step_matches_oracle(tmp_path):
     # Adam first step: every used parameter with a non-negligible gradient moves by ~lr against its sign
     off, n = tr.store.offsets["mono_depth.decoder.0.conv.conv.weight"]
     delta = (tr.store.flat[off:off + n] - before[off:off + n]).cpu()
-    g = tr.store.grad[off:off + n].cpu()
+    # (FusedAdam.step clears the gradient buffer in the pass that consumes it: use the copy taken before the step)
+    g = gpu_grads["mono_depth.decoder.0.conv.conv.weight"].permute(0, 2, 3, 1).reshape(-1)   # storage order of the flat buffer
+    assert tr.store.grad[off:off + n].abs().max().item() == 0 and tr.store.grad_is_zero
     big = g.abs() > 1e-6
     assert torch.allclose(delta[big], -1e-4 * torch.sign(g[big]), atol=2e-6)
 

@@ -159,6 +159,48 @@ __global__ void planes4_pitch(const uint8_t* in, float* out, int B, int H, int W
     }
 }
 
+
+__global__ void sum4(const f4* a, float* out, long n) {
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc += a[i];
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = 1.f;
+}
+__global__ void axpy4(f4* a, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a[i] = a[i] + 1.f;
+}
+
+
+// K1-shaped stream + one data-dependent 4-byte gather per pixel from a 1 MB table (the AoLP LUT's access shape)
+template <int NP, bool NT>
+__global__ void planes4_pitch_lut(const uint8_t* in, float* out, const float* lut, int B, int H, int W, int Wout) {
+    const long wq_in = W / 4, wq = Wout / 4;
+    const long P = (long)H * W, Pout = (long)H * Wout, total = (long)B * H * wq;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const long r = q / wq, cq = q - r * wq, b = r / H, row = r - b * H;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (cq < wq_in) {
+            const uint8_t* pb = in + b * 4 * P + row * W + 4 * cq;
+            uint32_t w0 = ld1<false>(pb), w1 = ld1<false>(pb + P), w2 = ld1<false>(pb + 2 * P), w3 = ld1<false>(pb + 3 * P);
+            float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d1 = (int)((w0 >> (8 * j)) & 255) - (int)((w2 >> (8 * j)) & 255), d2 = (int)((w1 >> (8 * j)) & 255) - (int)((w3 >> (8 * j)) & 255);
+                g[j] = lut[(d2 + 255) * 511 + d1 + 255];
+            }
+            v = (f4){g[0], g[1], g[2], g[3]};
+        }
+        float* o = out + b * NP * Pout + row * Wout + 4 * cq;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) st4<NT>(o + c * Pout, v);
+    }
+}
+__global__ void fill_pattern(uint8_t* p, long n) {   // smooth planes + noise: |d1|, |d2| within ~ +-60 like real frames
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15;
+        p[i] = (uint8_t)(100 + (int)(40.f * __sinf((float)(i % 612) * 0.02f + (float)(i / 313344) * 1.3f)) + (int)(h & 7));
+    }
+}
+
 template <typename F> float timeit(F f, int it = 10) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     f(); CK(hipDeviceSynchronize());
@@ -173,6 +215,56 @@ int main(int argc, char** argv) {
     CK(hipMemset(ca, 1, ncopy * 16));
     float ms;
     const long nq = B * P / 4;
+
+    if (argc > 1 && argv[1][0] == 'd') {
+        // Who pays for a predecessor's dirty cache lines?  Time the K1-shaped stream (B = 16) right after a kernel
+        // that wrote `mb` MB with plain or nontemporal stores.
+        printf("---- K1-shaped stream (B=16, 612->640, nt stores, grid 256 x 1024) after a dirtying predecessor\n");
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int mb : {0, 256, 800}) for (int kind = 0; kind < 4; ++kind) {
+            if (mb == 0 && kind) continue;
+            float tot = 0.f; const int it = 12;
+            const char* names[4] = {"plain fill", "nt fill   ", "read only ", "read+write"};
+            for (int i = 0; i < it + 2; ++i) {
+                const long n16 = (long)mb * 1000000 / 16;
+                if (mb) {
+                    if (kind == 0) hipLaunchKernelGGL(fill4<false>, dim3(4096), dim3(256), 0, 0, ca, n16);
+                    if (kind == 1) hipLaunchKernelGGL(fill4<true>, dim3(4096), dim3(256), 0, 0, ca, n16);
+                    if (kind == 2) hipLaunchKernelGGL(sum4, dim3(4096), dim3(256), 0, 0, ca, (float*)cb, n16);
+                    if (kind == 3) hipLaunchKernelGGL(axpy4, dim3(4096), dim3(256), 0, 0, ca, n16);
+                }
+                float* o = out + (long)(i % 3) * 16 * 11 * 512 * 640;          // rotate three output sets
+                const uint8_t* ii = in + (long)(i % 3) * 16 * 4 * P;
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL((planes4_pitch<11, true, false>), dim3(256), dim3(1024), 0, 0, ii, o, 16, 512, 612, 640);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (i >= 2) tot += ms;
+            }
+            printf("predecessor %s %3d MB: stream kernel %.1f us  (%.0f GB/s algorithmic)\n", names[kind], mb, tot / it * 1e3, 16 * P * 48 / (tot / it) / 1e6);
+        }
+        float* lut; CK(hipMalloc(&lut, 511 * 511 * 4)); CK(hipMemset(lut, 0, 511 * 511 * 4));
+        hipLaunchKernelGGL(fill_pattern, dim3(4096), dim3(256), 0, 0, in, B * 4 * P); CK(hipDeviceSynchronize());
+        for (int nb : {16}) for (int kind = 0; kind < 5; ++kind) for (int mb : {0, 300, 800}) {
+            if ((mb == 0) != (kind == 0)) continue;
+            float tot = 0.f; const int it = 12;
+            const char* names[5] = {"nothing", "plain fill", "nt fill", "read only", "read + nt write"};
+            for (int i = 0; i < it + 2; ++i) {
+                const long n16 = (long)mb * 1000000 / 16;
+                if (kind == 1) hipLaunchKernelGGL(fill4<false>, dim3(4096), dim3(256), 0, 0, ca, n16);
+                if (kind == 2) hipLaunchKernelGGL(fill4<true>, dim3(4096), dim3(256), 0, 0, ca, n16);
+                if (kind == 3) hipLaunchKernelGGL(sum4, dim3(4096), dim3(256), 0, 0, ca, (float*)cb, n16);
+                if (kind == 4) hipLaunchKernelGGL(copy4<true>, dim3(4096), dim3(256), 0, 0, ca, cb, n16 / 2);
+                float* o = out + (long)(i % 2) * 64 * 11 * 512 * 640;
+                const uint8_t* ii = in + (long)(i % 2) * 64 * 4 * P;
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL((planes4_pitch_lut<11, true>), dim3(256), dim3(1024), 0, 0, ii, o, lut, nb, 512, 612, 640);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (i >= 2) tot += ms;
+            }
+            printf("stream + LUT gather, B=%d, after %s of %3d MB: %.1f us  (%.0f GB/s algorithmic)\n", nb, names[kind], mb, tot / it * 1e3, nb * P * 48 / (tot / it) / 1e6);
+        }
+        return 0;
+    }
     if (argc > 1) {
     printf("---- chunked / pitched variants\n");
     for (int bs : {256, 512, 1024}) {
