@@ -4,20 +4,54 @@
 called at trainer.py:276-303).  When ``data_path`` holds a HAMMER tree
 (``<scene>/<modality>/{rgb,pol00,pol01,pol10,pol11,_gt,<depth_modality>,_instance}/%06d.png`` + ``intrinsics.txt``,
 indoor_dataset.py:118-190, hammer_dataset.py:59-169) the items are decoded from disk with PIL (LANCZOS resize =
-the reference's Image.ANTIALIAS, nearest for depth / instance masks, 16-bit depth in mm -> m); otherwise seeded
-synthetic HAMMER-shaped items with the same keys, dtypes and shapes are served.
+the reference's Image.ANTIALIAS, nearest for depth / instance masks, 16-bit depth in mm -> m).  Seeded synthetic
+HAMMER-shaped items with the same keys, dtypes and shapes are served ONLY for the literal ``data_path ==
+"synthetic"`` (bench.py and the tests pass it); any other path that is missing, or holds no complete frame of the
+requested scenes, raises FileNotFoundError like the reference fails on a wrong ``--data_path``.
 
 Difference to the reference by design: the four polarizer grays are handed over raw as ``("pol", 0, 0)`` uint8
 [4,H,W] (order 0/45/90/135 deg = pol00, pol01, pol10, pol11, indoor_dataset.py:435-439) and DoLP/AoLP/normals are
 computed on the device by K1, instead of the per-pixel ``lstsq`` in the DataLoader workers (:430-442).
-Colour jitter (:414-418) needs torchvision, which is not installed here: ``color_aug`` equals ``color``.
+Colour augmentation (indoor_dataset.py:92-106, 226-233, 300, 404-407): with probability 0.5 a training item's
+``color_aug`` pyramid is the ColorJitter(brightness, contrast, saturation in [0.8, 1.2], hue in [-0.1, 0.1]) of
+its ``color`` pyramid -- torchvision 0.8.2's PIL path restated on PIL.ImageEnhance (torchvision is not installed).
 """
 import glob
 import os
+import random
 
 import numpy as np
 import torch
 from torch.utils.data import Dataset
+
+
+SYNTHETIC = "synthetic"
+
+
+def color_jitter_params(brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.8, 1.2), hue=(-0.1, 0.1), rng=random):
+    """torchvision 0.8.2 ``ColorJitter.get_params``: one factor per property, applied in a random order."""
+    ops_ = [("brightness", rng.uniform(*brightness)), ("contrast", rng.uniform(*contrast)),
+            ("saturation", rng.uniform(*saturation)), ("hue", rng.uniform(*hue))]
+    rng.shuffle(ops_)
+    return ops_
+
+
+def apply_color_jitter(img, params):
+    """torchvision.transforms.functional_pil adjust_brightness / _contrast / _saturation / _hue on a PIL RGB image."""
+    from PIL import Image, ImageEnhance
+    for name, f in params:
+        if name == "brightness":
+            img = ImageEnhance.Brightness(img).enhance(f)
+        elif name == "contrast":
+            img = ImageEnhance.Contrast(img).enhance(f)
+        elif name == "saturation":
+            img = ImageEnhance.Color(img).enhance(f)
+        else:
+            h, s_, v = img.convert("HSV").split()
+            nh = np.array(h, dtype=np.uint8)
+            nh += np.uint8(int(f * 255) & 0xff)  # np.uint8(hue_factor * 255) of torchvision: truncation + uint8 wrap-around
+            img = Image.merge("HSV", (Image.fromarray(nh, "L"), s_, v)).convert("RGB")
+    return img
 
 
 class HAMMER_Dataset(Dataset):
@@ -30,10 +64,22 @@ class HAMMER_Dataset(Dataset):
         self.raw_pol = (os.environ.get("PD_DEVICE_RESIZE") == "1") if raw_pol is None else bool(raw_pol)
         self.data_path, self.modality, self.depth_modality, self.img_ext = data_path, modality, depth_modality, img_ext
         self.height, self.width, self.num_scales = height, width, num_scales
-        self.filenames = list(filenames) if filenames else ["synthetic_scene"]
         self.is_train = is_train
-        self.frames = self._discover(filenames) if data_path and os.path.isdir(str(data_path)) else []
-        self.items = len(self.frames) if self.frames else len(self.filenames) * items_per_scene
+        self.synthetic = str(data_path) == SYNTHETIC
+        if self.synthetic:
+            self.filenames = list(filenames) if filenames else ["synthetic_scene"]
+            self.frames = []
+            self.items = len(self.filenames) * items_per_scene
+        else:
+            if not (data_path and os.path.isdir(str(data_path))):
+                raise FileNotFoundError(f"HAMMER data_path {data_path!r} is not a directory (pass the literal "
+                                        f"{SYNTHETIC!r} for seeded synthetic items)")
+            self.filenames = list(filenames or [])
+            self.frames = self._discover(self.filenames)
+            if self.filenames and not self.frames:
+                raise FileNotFoundError(f"no complete HAMMER frame (rgb, pol00/01/10/11, _gt, {depth_modality}) under "
+                                        f"{data_path!r} for scenes {self.filenames[:3]}...")
+            self.items = len(self.frames)
 
     # ---- real HAMMER tree -------------------------------------------------------------------------------
     def _discover(self, scenes):
@@ -57,10 +103,14 @@ class HAMMER_Dataset(Dataset):
         color = Image.open(os.path.join(folder, "rgb", name)).convert("RGB")
         full_w, full_h = color.size
         prev = color
+        do_color_aug = self.is_train and random.random() > 0.5                     # indoor_dataset.py:300
+        jitter = color_jitter_params() if do_color_aug else None                   # :404-405, one draw per item
         for s in range(self.num_scales):          # successive LANCZOS resizes (indoor_dataset.py:192-215)
             prev = prev.resize((W >> s, H >> s), Image.LANCZOS)
             inputs[("color", 0, s)] = to_t(prev)
-            inputs[("color_aug", 0, s)] = inputs[("color", 0, s)]
+            blank = inputs[("color", 0, s)].sum() == 0                             # :222-225 blank frames stay blank
+            inputs[("color_aug", 0, s)] = to_t(apply_color_jitter(prev, jitter)) if (do_color_aug and not blank) \
+                else inputs[("color", 0, s)]
         pol_imgs = [Image.open(os.path.join(folder, d, name)).convert("L")
                     for d in ("pol00", "pol01", "pol10", "pol11")]                # 0, 45, 90, 135 degrees
         planes = [np.asarray(im if self.raw_pol else im.resize((W, H), Image.LANCZOS)) for im in pol_imgs]
@@ -97,9 +147,9 @@ class HAMMER_Dataset(Dataset):
         return self.items
 
     def __getitem__(self, index):
-        if self.frames:
-            return self._load_item(*self.frames[index])
-        return self._synthetic_item(index)
+        if self.synthetic:
+            return self._synthetic_item(index)
+        return self._load_item(*self.frames[index])
 
     # ---- synthetic items --------------------------------------------------------------------------------
     def _synthetic_item(self, index):

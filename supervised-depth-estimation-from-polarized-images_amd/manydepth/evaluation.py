@@ -7,8 +7,8 @@ import torch
 from torch.utils.data import DataLoader
 
 from manydepth import datasets, networks
-from manydepth.layers import compute_depth_errors_numpy
 from manydepth.utils import readlines
+from polardepth import ops
 from polardepth import polar as pdpolar
 from polardepth._lib import lib, check, ptr, stream_ptr
 
@@ -19,6 +19,13 @@ _MATERIAL_GREY = {"box": 20, "bottle": 40, "can": 60, "cup": 80, "remote": 100, 
 class Evaluation:
     def __init__(self, load_weights_folder=None, data_path=None, height=320, width=480, batch_size=12,
                  augment_xolp=True, augment_normals=True, num_workers=0, joint_attention=None):
+        """The reference hard-codes its machine's paths (evaluation.py:27-31); here they are arguments, falling back to
+        $PD_EVAL_DATA_PATH / $PD_EVAL_WEIGHTS.  ``data_path="synthetic"`` serves seeded synthetic items; anything else
+        must be a HAMMER tree (FileNotFoundError otherwise, like the reference on a wrong path)."""
+        data_path = data_path if data_path is not None else os.environ.get("PD_EVAL_DATA_PATH")
+        load_weights_folder = load_weights_folder if load_weights_folder is not None else os.environ.get("PD_EVAL_WEIGHTS")
+        if data_path is None:
+            raise FileNotFoundError("Evaluation needs data_path (or $PD_EVAL_DATA_PATH): a HAMMER test tree, or 'synthetic'")
         if not torch.cuda.is_available():
             raise RuntimeError("Evaluation needs the MI355X: there is no CPU fallback")
         self.height, self.width, self.batch_size = height, width, batch_size
@@ -37,8 +44,17 @@ class Evaluation:
         self.models["mono_depth"] = networks.DepthDecoder(self.models["rgb_encoder"].num_ch_enc, self.scales)
         for m in self.models.values():
             m.to(self.device).eval()
-        split = os.path.join("splits", "HAMMER_unseen", "test_files.txt")
-        files = readlines(split) if os.path.exists(split) else []
+        # evaluation.py:96 reads ../splits (cwd = manydepth/); the repository root works too
+        files = None
+        for root in ("splits", os.path.join("..", "splits")):
+            split = os.path.join(root, "HAMMER_unseen", "test_files.txt")
+            if os.path.exists(split):
+                files = readlines(split)
+                break
+        if files is None:
+            if str(data_path) != datasets.SYNTHETIC:
+                raise FileNotFoundError("splits/HAMMER_unseen/test_files.txt not found (evaluation.py:96)")
+            files = []
         ds = datasets.HAMMER_Dataset(data_path, files, height, width, [0], 4, is_train=False)
         self.test_loader = DataLoader(ds, batch_size, False, num_workers=num_workers, drop_last=True)
 
@@ -68,22 +84,25 @@ class Evaluation:
         return depth.clamp(self.min_depth, self.max_depth)
 
     def test(self):
-        gts, preds, masks = [], [], []
+        """evaluation.py:120-288: mean over images of the 7 masked depth metrics, for the whole frame and per material
+        class (instance-mask grey values :242-264).  The per-image reductions run on the device (pd_depth_metrics);
+        11 x 8 numbers per batch leave the GPU instead of every depth map."""
+        objects = ["all"] + list(_MATERIAL_GREY)
+        sums = {o: torch.zeros(7, dtype=torch.float64, device=self.device) for o in objects}
+        counts = {o: torch.zeros((), dtype=torch.float64, device=self.device) for o in objects}
         for inputs in self.test_loader:
             inputs = {k: v.to(self.device) for k, v in inputs.items()}
-            preds.append(self.predict(inputs).cpu()); gts.append(inputs["depth_gt"].cpu()); masks.append(inputs[("mask", 0, 0)].cpu())
+            depth = self.predict(inputs)
+            for o in objects:
+                m = ops.depth_metrics(inputs["depth_gt"], depth, self.min_depth, self.max_depth,
+                                      mask=None if o == "all" else inputs[("mask", 0, 0)],
+                                      mask_value=_MATERIAL_GREY.get(o, 0))
+                valid = m[:, 7] > 0
+                sums[o] += (m[:, :7].double() * valid[:, None]).sum(0)
+                counts[o] += valid.sum()
         results = {}
-        for obj in ["all"] + list(_MATERIAL_GREY):
-            errs = []
-            for g, p, m in zip(gts, preds, masks):
-                for b in range(g.shape[0]):
-                    gt, pr = g[b, 0].numpy(), p[b, 0].numpy()
-                    mask = (gt > self.min_depth) & (gt < self.max_depth)
-                    if obj != "all":
-                        mask &= m[b, 0].numpy() == _MATERIAL_GREY[obj]
-                    if mask.any():
-                        errs.append(compute_depth_errors_numpy(gt[mask], pr[mask]))
-            if errs:
-                results[obj] = np.array(errs).mean(0)
-                print(obj, ("&{: 8.5f}  " * 7).format(*results[obj].tolist()))
+        for o in objects:
+            if counts[o].item() > 0:
+                results[o] = (sums[o] / counts[o]).cpu().numpy()
+                print(o, ("&{: 8.5f}  " * 7).format(*results[o].tolist()))
         return results

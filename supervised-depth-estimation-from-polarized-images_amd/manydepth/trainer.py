@@ -135,12 +135,17 @@ class Trainer:
             raise NotImplementedError("only --dataset HAMMER is on the hot path")
         self.dataset = datasets.HAMMER_Dataset
 
-        def _split(split, which):
+        def _split(split, which, data_path):
             path = os.path.join("splits", split, f"{which}_files.txt")
-            return readlines(path) if os.path.exists(path) else []
-        train_files = [self.opt.overfit_scene] if self.opt.overfit else _split(self.opt.split, "train")
-        val_files = [self.opt.overfit_scene] if self.opt.overfit else _split(self.opt.split, "val")
-        test_files = _split(self.opt.eval_split, "test")
+            if os.path.exists(path):
+                return readlines(path)
+            if str(data_path) == datasets.SYNTHETIC:      # seeded synthetic items need no scene list
+                return []
+            raise FileNotFoundError(f"{path} not found (run from the repository root, trainer.py:261-263; "
+                                    f"--data_path {datasets.SYNTHETIC} serves synthetic items)")
+        train_files = [self.opt.overfit_scene] if self.opt.overfit else _split(self.opt.split, "train", self.data_path)
+        val_files = [self.opt.overfit_scene] if self.opt.overfit else _split(self.opt.split, "val", self.data_path)
+        test_files = _split(self.opt.eval_split, "test", self.data_path_val)
         mk = lambda path, files, tr: self.dataset(path, files, self.opt.height, self.opt.width, [0], 4, is_train=tr,
                                                   img_ext='.png', offset=self.opt.offset, modality=self.opt.modality,
                                                   supervised_depth=True, supervised_depth_only=True,
@@ -204,14 +209,19 @@ class Trainer:
         for self.epoch in range(first_epoch, self.opt.num_epochs):
             self.run_epoch()
             if (self.epoch + 1) % self.opt.save_frequency == 0:
-                self.save_model()
+                self.save_model(epoch_complete=True)     # rank 0 writes, every rank waits (no torn files under torchrun)
                 self.test()
 
     def run_epoch(self):
         self.set_train()
         if self.distributed and hasattr(self.train_loader.sampler, "set_epoch"):
             self.train_loader.sampler.set_epoch(self.epoch)
+        # a checkpoint written in the middle of an epoch resumes in that epoch, behind the batches already consumed
+        skip = getattr(self, "resume_batch", 0) if self.epoch == getattr(self, "resume_epoch", -1) else 0
+        self.resume_batch = 0
         for batch_idx, inputs in enumerate(self.train_loader):
+            if batch_idx < skip:
+                continue
             before_op_time = time.time()
             self.model_optimizer.zero_grad()
             outputs, losses, mono_outputs = self.process_batch(inputs, is_train=True)
@@ -226,8 +236,7 @@ class Trainer:
                     self.compute_depth_losses(inputs, outputs, losses)
                 self.log("train", inputs, outputs, losses)
                 self.val()
-                if self.rank == 0:
-                    self.save_model()
+                self.save_model(epoch_complete=False, batch_idx=batch_idx)
             self.step += 1
         self.model_lr_scheduler.step()
 
@@ -404,9 +413,10 @@ class Trainer:
         writer = self.writers[mode]
         for l, v in losses.items():
             try:
-                writer.add_scalar("{}".format(l), float(v), self.step)
-            except Exception:
-                pass
+                value = float(v)
+            except (TypeError, ValueError):      # non-scalar entries (images, per-pixel maps) are not logged by this build
+                continue
+            writer.add_scalar("{}".format(l), value, self.step)
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:1586-1691)
     def save_opts(self):
@@ -415,17 +425,28 @@ class Trainer:
         with open(os.path.join(models_dir, 'opt.json'), 'w') as f:
             json.dump(self.opt.__dict__.copy(), f, indent=2)
 
-    def save_model(self):
+    def save_model(self, epoch_complete=True, batch_idx=-1):
+        """trainer.py:1597-1617 layout (<model>.pth + adam.pth) plus trainer_state.pth.  Only rank 0 writes; every file
+        goes through a temporary name + os.replace, and all ranks meet at a barrier afterwards."""
         save_folder = os.path.join(self.log_path, "models", "weights_{}".format(self.epoch))
-        os.makedirs(save_folder, exist_ok=True)
-        for model_name, model in self.models.items():
-            sd = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
-            torch.save(sd, os.path.join(save_folder, "{}.pth".format(model_name)))
-        torch.save(self.model_optimizer.state_dict(), os.path.join(save_folder, "adam.pth"))
-        # resume state (not in the reference, which restarts epoch/step/LR schedule on load)
-        torch.save({"epoch": self.epoch, "step": self.step, "lr_scheduler": self.model_lr_scheduler.state_dict(),
-                    "dropout_seed": PF.DropoutState.seed, "dropout_offset": PF.DropoutState.offset},
-                   os.path.join(save_folder, "trainer_state.pth"))
+        if self.rank == 0:
+            os.makedirs(save_folder, exist_ok=True)
+
+            def _save(obj, name):
+                tmp = os.path.join(save_folder, name + ".tmp")
+                torch.save(obj, tmp)
+                os.replace(tmp, os.path.join(save_folder, name))
+            for model_name, model in self.models.items():
+                _save({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}, "{}.pth".format(model_name))
+            _save(self.model_optimizer.state_dict(), "adam.pth")
+            # resume state (not in the reference, which restarts epoch/step/LR schedule on load; SURVEY.md §8f rank 3).
+            # run_epoch saves on its logging steps BEFORE self.step += 1 and before lr_scheduler.step(): such a
+            # checkpoint is marked incomplete and resumes inside the same epoch.
+            _save({"epoch": self.epoch, "step": self.step, "epoch_complete": bool(epoch_complete),
+                   "batch_idx": int(batch_idx), "lr_scheduler": self.model_lr_scheduler.state_dict(),
+                   "dropout_seed": PF.DropoutState.seed, "dropout_offset": PF.DropoutState.offset}, "trainer_state.pth")
+        if self.distributed:
+            torch.distributed.barrier()
 
     def _load_into(self, name, path, strict=False):
         model_dict = self.models[name].state_dict()
@@ -452,11 +473,15 @@ class Trainer:
         if os.path.isfile(opt_path):
             try:
                 self.model_optimizer.load_state_dict(torch.load(opt_path, map_location=self.device))
-            except (ValueError, KeyError):
-                print("Can't load Adam - using random")
+            except (ValueError, KeyError, RuntimeError) as e:
+                print("Can't load Adam - using random ({})".format(e))
         state_path = os.path.join(folder, "trainer_state.pth")
         if os.path.isfile(state_path) and getattr(self.opt, "resume_state", True):
             st = torch.load(state_path, map_location="cpu")
-            self.resume_epoch, self.resume_step = int(st["epoch"]) + 1, int(st["step"])
+            if st.get("epoch_complete", True):       # written by train() after run_epoch (scheduler already stepped)
+                self.resume_epoch, self.resume_step, self.resume_batch = int(st["epoch"]) + 1, int(st["step"]), 0
+            else:                                    # written inside run_epoch: same epoch, next batch, next step
+                self.resume_epoch, self.resume_step = int(st["epoch"]), int(st["step"]) + 1
+                self.resume_batch = int(st.get("batch_idx", -1)) + 1
             self.model_lr_scheduler.load_state_dict(st["lr_scheduler"])
             PF.DropoutState.seed, PF.DropoutState.offset = int(st["dropout_seed"]), int(st["dropout_offset"])

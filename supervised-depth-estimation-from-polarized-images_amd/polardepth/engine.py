@@ -34,11 +34,16 @@ class ParamStore:
         for _, p in self.entries:
             offs.append(total)
             total += (p.numel() + align - 1) // align * align
+        self.models = models
         self.numel = total
         self.n_used = offs[self.n_used_params] if self.n_used_params < len(offs) else total
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(total, dtype=torch.float32, device=device)
-        self.grad_is_zero = True      # set by FusedAdam.step (which clears the gradient in the same pass), reset by backward
+        # FusedAdam.step clears the gradient in the pass that consumes it; zero_grad() then has nothing to do unless
+        # something wrote since: our kernels (functional.grad_buf resets the flag) or a torch in-place op on a
+        # .grad view (bumps the version counter of the shared storage)
+        self.grad_is_zero = True
+        self._zero_version = self.grad._version
         self.offsets = {}
         for (name, p), off in zip(self.entries, offs):
             self.offsets[name] = (off, p.numel())
@@ -66,9 +71,13 @@ class ParamStore:
         p._pd_store = self            # functional.grad_buf marks the gradient buffer as written
 
     def zero_grad(self):
-        if not self.grad_is_zero:
+        if not (self.grad_is_zero and self.grad._version == self._zero_version):
             self.grad.zero_()
-            self.grad_is_zero = True
+        self.mark_zeroed()
+
+    def mark_zeroed(self):
+        self.grad_is_zero = True
+        self._zero_version = self.grad._version
 
     def used_params(self):
         return [p for _, p in self.entries[:self.n_used_params]]
@@ -114,37 +123,73 @@ class FusedAdam(torch.optim.Optimizer):
               "pd_adam_step")
         if self.zero_grad_in_step:
             # (the tail behind n_used -- parameters that never receive gradients, e.g. ResNet layer3/4/fc -- is never read)
-            self.store.grad_is_zero = True
+            self.store.mark_zeroed()
 
-    # ---- checkpoint interop with torch.optim.Adam ("adam.pth", trainer.py:1614-1617)
+    # ---- checkpoint interop with torch.optim.Adam ("adam.pth", trainer.py:1614-1617, 1681-1691)
+    # torch numbers the parameters in the order they were handed to the optimizer: the reference's
+    # ``parameters_to_train`` = normals_encoder, xolp_encoder, joint_encoder, rgb_encoder, mono_depth, each in
+    # ``model.parameters()`` order (trainer.py:194-219) -- NOT the backward-completion order of the flat buffer.
+    REFERENCE_MODEL_ORDER = ("normals_encoder", "xolp_encoder", "joint_encoder", "rgb_encoder", "mono_depth")
+
+    def reference_order(self):
+        """Parameter names in the reference optimizer's index order (models missing from this run are skipped)."""
+        by_model = {}
+        for name, _ in self.store.entries:
+            by_model.setdefault(name.split(".", 1)[0], []).append(name)
+        names = []
+        for m in list(self.REFERENCE_MODEL_ORDER) + [k for k in by_model if k not in self.REFERENCE_MODEL_ORDER]:
+            if m in by_model:
+                if m in getattr(self.store, "models", {}):      # model.parameters() order
+                    names += [f"{m}.{pn}" for pn, _ in self.store.models[m].named_parameters()]
+                else:
+                    names += by_model[m]
+        return names
+
     def state_dict(self):
-        state, ids = {}, []
-        for i, (name, p) in enumerate(self.store.entries):
-            ids.append(i)
-            if i < self.store.n_used_params and self.step_count > 0:
+        names = self.reference_order()
+        entries = dict(self.store.entries)
+        used = {n for n, _ in self.store.entries[:self.store.n_used_params]}
+        state = {}
+        for i, name in enumerate(names):
+            if name in used and self.step_count > 0:
                 off, n = self.store.offsets[name]
+                p = entries[name]
                 state[i] = {"step": torch.tensor(float(self.step_count)),
                             "exp_avg": self.store._view(self.exp_avg, p, off).clone(),
                             "exp_avg_sq": self.store._view(self.exp_avg_sq, p, off).clone()}
-        g = dict(self.param_groups[0]); g["params"] = ids
-        return {"state": state, "param_groups": [g], "pd_order": [n for n, _ in self.store.entries]}
+        g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        g["params"] = list(range(len(names)))
+        return {"state": state, "param_groups": [g], "pd_order": names}
 
     def load_state_dict(self, sd):
+        """Accepts this build's files and a plain ``torch.optim.Adam`` state of the reference (no ``pd_order``: its
+        indices follow ``parameters_to_train``).  Shapes are validated before anything is copied; a mismatch raises
+        ValueError, which Trainer.load_model answers like the reference does ("Can't load Adam - using random")."""
         g = sd["param_groups"][0]
-        for k in ("lr", "betas", "eps", "weight_decay"):
-            if k in g:
-                self.param_groups[0][k] = g[k]
-        names = sd.get("pd_order", [n for n, _ in self.store.entries])
-        steps = []
+        names = sd.get("pd_order") or self.reference_order()
+        if len(g.get("params", names)) != len(names):
+            raise ValueError(f"adam.pth holds {len(g['params'])} parameters, this model has {len(names)}")
+        entries = dict(self.store.entries)
+        todo, steps = [], []
         for i, st in sd["state"].items():
             name = names[int(i)]
             if name not in self.store.offsets:
-                continue
+                raise ValueError(f"adam.pth: unknown parameter {name!r}")
+            p = entries[name]
+            for k in ("exp_avg", "exp_avg_sq"):
+                if tuple(st[k].shape) != tuple(p.shape):
+                    raise ValueError(f"adam.pth: {k} of parameter {int(i)} has shape {tuple(st[k].shape)}, "
+                                     f"{name} needs {tuple(p.shape)} (parameter order mismatch?)")
+            todo.append((name, p, st))
+            steps.append(int(float(st["step"])))
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            if k in g:
+                self.param_groups[0][k] = g[k]
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for name, p, st in todo:
             off, n = self.store.offsets[name]
-            p = dict(self.store.entries)[name]
             self.store._view(self.exp_avg, p, off).copy_(st["exp_avg"])
             self.store._view(self.exp_avg_sq, p, off).copy_(st["exp_avg_sq"])
-            steps.append(int(float(st["step"])))
         self.step_count = max(steps) if steps else 0
 
 

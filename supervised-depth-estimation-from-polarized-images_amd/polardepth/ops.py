@@ -133,7 +133,9 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    key = device.index
+    """Scratch of the split reductions, one buffer per (device, stream): weight-gradient kernels run on a side
+    stream next to main-stream users of the same scratch (gemm_tn in the materialised-score attention backward)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

@@ -5,7 +5,7 @@ Runs only in the build container (needs /root/reference, which never travels to
 the GPU box).  The outputs are data only (.npz of inputs + expected outputs);
 no reference source text is stored.  Re-run with:
 
-    python tests/golden/make_golden.py [group ...]      # groups: polar nets loss
+    python tests/golden/make_golden.py [group ...]      # groups: polar stokes nets loss options
 
 How the reference is imported:
   * polarisation.xolp, manydepth.layers, manydepth.normals_vec import directly;
@@ -13,7 +13,10 @@ How the reference is imported:
     under an empty stub parent package (their __init__ pulls torchvision, which
     is not installed here);
   * manydepth.trainer imports once tensorboard / kornia / roma / datasets /
-    networks / dpt are stubbed; Trainer.compute_losses is then called unbound.
+    networks / dpt are stubbed; Trainer.compute_losses is then called unbound;
+  * ppp_code/physical_normals_channels.py and polarisation/xolp_and_normals.py (stand-alone scripts guarded by
+    __main__) import once `cv2` is an empty stub module and matplotlib.use("TkAgg") is a no-op: their functions
+    are pure NumPy / SciPy.
 Everything is seeded; all modules are run with pretrained=False / seeded init.
 """
 import importlib.util
@@ -113,6 +116,69 @@ def make_polar():
     np.savez_compressed(os.path.join(OUT, "g3_normals.npz"), xolp64=xolp64.numpy(), normals=normals.numpy(),
                         xolp_std=xstd.numpy())
     print("polar goldens written")
+
+
+# ------------------------------------------------------------------ group: stokes (A2 + the numpy twins of A3-A5)
+def _script_module(modname, relpath):
+    """Import a stand-alone reference script whose top level needs cv2 / a Tk matplotlib backend."""
+    import matplotlib
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    real_use = matplotlib.use
+    matplotlib.use = lambda *a, **k: None
+    try:
+        return _load_by_path(modname, relpath)
+    finally:
+        matplotlib.use = real_use
+
+
+def make_stokes():
+    _ref_imports()
+    ppp = _script_module("ref_physical_normals_channels", "ppp_code/physical_normals_channels.py")
+    # xolp_and_normals imports `pol_split_and_save` from its own directory
+    sys.path.insert(0, os.path.join(REF, "polarisation"))
+    xn = _script_module("ref_xolp_and_normals", "polarisation/xolp_and_normals.py")
+    rng = np.random.default_rng(7)
+    angles = np.array([0, 45, 90, 135]) * np.pi / 180
+    H, W = 24, 40
+    rnd = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    rnd[0, :6] = 0                                   # s0 = 0, s1 = s2 = 0  -> 0/0
+    rnd[1, :6, 0] = 0; rnd[1, :6, 2] = 0             # s0 = 0, s2 != 0      -> x/0
+    rnd[2, :6] = 255
+    rnd[3, :6, 1] = rnd[3, :6, 3]                    # s2 = 0: branch cut rows
+    yy, xx = np.mgrid[0:H, 0:W]
+    iun = 110 + 50 * np.sin(xx / 7.0) * np.cos(yy / 5.0)
+    rho_t = 0.03 + 0.3 * (0.5 + 0.5 * np.sin(xx / 4.0 + yy / 9.0)) ** 2
+    phi_t = (np.pi / 2) * np.sin(xx / 11.0 - yy / 5.0)
+    phys = np.stack([iun * (1 + rho_t * np.cos(2 * a - 2 * phi_t)) for a in angles], axis=2)
+    phys = np.clip(np.rint(phys + rng.normal(0, 1.5, phys.shape)), 0, 255).astype(np.uint8)
+    g7 = {}
+    for name, img in (("rnd", rnd), ("phys", phys)):
+        mask = rng.random((H, W)) > 0.2
+        mask[:4, :6] = True                          # keep the degenerate pixels inside the mask
+        # the script masks the images first (physical_normals_channels.py:117-121), then calls the functions
+        images = np.zeros((H, W, 4))
+        for c in range(4):
+            images[:, :, c][mask] = img[:, :, c][mask]
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            rho2, phi2, Iun2 = ppp.PolarisationImage_channel(images, angles, mask)
+            th_d = ppp.rho_diffuse_channel(rho2, 1.5)
+            th_s1, th_s2 = ppp.rho_spec_channel(rho2, 1.5)
+            N_d = ppp.calc_normals_channel(phi2, th_d, mask)
+            N_s1 = ppp.calc_normals_channel(phi2 + np.pi / 2, th_s1, mask)
+            N_s2 = ppp.calc_normals_channel(phi2 + np.pi / 2, th_s2, mask)
+            # polarisation/xolp_and_normals.py twins (LS-fit XOLP + unmasked fp64 normals, :13-98)
+            Iun_ls, rho_ls, phi_ls = xn.Iun_and_xolp(img.astype(np.float64), angles)
+            t1, t2 = xn.rho_spec(rho_ls, 1.5)
+            td = xn.rho_diffuse(rho_ls, 1.5)
+            Nn_d = xn.calc_normals(phi_ls, td)
+            Nn_s1 = xn.calc_normals(phi_ls + np.pi / 2, t1)
+        g7.update({name + "_img": img, name + "_mask": mask, name + "_rho": rho2, name + "_phi": phi2,
+                   name + "_Iun": Iun2, name + "_theta_d": th_d, name + "_theta_s1": th_s1, name + "_theta_s2": th_s2,
+                   name + "_N_d": N_d, name + "_N_s1": N_s1, name + "_N_s2": N_s2,
+                   name + "_ls_rho": rho_ls, name + "_ls_phi": phi_ls, name + "_ls_theta_d": td,
+                   name + "_ls_theta_s1": t1, name + "_ls_theta_s2": t2, name + "_ls_N_d": Nn_d, name + "_ls_N_s1": Nn_s1})
+    np.savez_compressed(os.path.join(OUT, "g7_stokes.npz"), **g7)
+    print("stokes goldens written")
 
 
 # ------------------------------------------------------------------ group: nets
@@ -319,7 +385,7 @@ def make_options():
     print("options golden written:", len(defaults), "flags")
 
 
-GROUPS = {"polar": make_polar, "nets": make_nets, "loss": make_loss, "options": make_options}
+GROUPS = {"polar": make_polar, "stokes": make_stokes, "nets": make_nets, "loss": make_loss, "options": make_options}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

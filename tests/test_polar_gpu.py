@@ -201,3 +201,36 @@ def test_batch_is_split_when_planes_exceed_32bit_offsets():
     strip = pol[1:2, :, 4000:4004, 1000:1064].cpu().numpy()
     xolp, _, _, _ = opolar.polar_forward(np.ascontiguousarray(strip))
     assert torch.equal(both["xolp"][1, :, 4000:4004, 1000:1064].cpu(), xolp[0])
+
+
+@pytest.mark.parametrize("precise", [False, True])
+def test_stokes_mode_matches_the_reference_script_fixture(golden_dir, precise):
+    """K1 in PD_POLAR_STOKES mode vs fixture g7 = outputs of the reference's own PolarisationImage_channel /
+    rho_*_channel / calc_normals_channel (ppp_code/physical_normals_channels.py:15-83), incl. s0 = 0 pixels."""
+    g = np.load(os.path.join(golden_dir, "g7_stokes.npz"))
+    for name in ("rnd", "phys"):
+        img, mask = g[name + "_img"], g[name + "_mask"]
+        pol = torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0)[None])).cuda()
+        got = pdpolar.polar_forward(pol, mode=pdpolar.MODE_STOKES, mask=torch.from_numpy(mask[None]).cuda(),
+                                    want=("xolp", "normals", "ints"), precise=precise)
+        x = got["xolp"].cpu().numpy()[0]
+        with np.errstate(over="ignore"):
+            exp_rho, exp_phi = g[name + "_rho"].astype(np.float32), g[name + "_phi"].astype(np.float32)
+        np.testing.assert_array_equal(x[0], exp_rho)          # bit-exact incl. the NaN (0/0) and inf (x/0) pixels
+        np.testing.assert_array_equal(x[1], exp_phi)
+        # index maps == searchsorted of the reference's fp64 rho rounded to fp32 (what the kernel interpolates)
+        ints = got["ints"].cpu().numpy()[0]
+        with np.errstate(invalid="ignore"):
+            _, idx_d = opolar.rho_diffuse(exp_rho, return_idx=True)
+            _, _, i1, i2 = opolar.rho_spec(exp_rho, return_idx=True)
+        np.testing.assert_array_equal(ints[2][mask], idx_d[mask])
+        np.testing.assert_array_equal(ints[3][mask], i1[mask])
+        np.testing.assert_array_equal(ints[4][mask], i2[mask])
+        # normals: the script is all-fp64 on the fp64 rho; the kernel works on fl32(rho) -> the steepest table slope
+        # (~70 rad per unit rho) turns the 6e-8 relative rounding of rho into <= 5e-6; bounded rho only
+        n = got["normals"].cpu().numpy()[0]
+        assert np.all(n[:, ~mask] == 0)
+        fin = mask & np.isfinite(g[name + "_rho"]) & (g[name + "_rho"] < 0.99)
+        for k, key in enumerate(("_N_d", "_N_s1", "_N_s2")):
+            ref = np.moveaxis(g[name + key], -1, 0)
+            np.testing.assert_allclose(n[3 * k:3 * k + 3][:, fin], ref[:, fin], rtol=0, atol=5e-6)

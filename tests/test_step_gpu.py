@@ -246,3 +246,86 @@ def test_raw_planes_are_resized_on_the_device_like_pillow(tmp_path):
         o2, l2, _ = tr.process_batch(b2)
     assert torch.equal(b1[("xolp", 0, 0)], b2[("xolp", 0, 0)])
     assert torch.equal(o1[("disp", 0)], o2[("disp", 0)]) and torch.equal(l1["loss"], l2["loss"])
+
+
+def test_reference_format_checkpoint_loads_and_continues_like_torch_adam(tmp_path):
+    """A checkpoint folder as the REFERENCE writes it (trainer.py:1597-1617): per-model state_dicts of the reference's
+    modules (here: the oracle restatement, same keys) and adam.pth = torch.optim.Adam(parameters_to_train) -- no
+    pd_order, parameters numbered normals, xolp, joint, rgb, mono.  The Trainer loads it and its next step equals the
+    step torch.optim.Adam takes from that state on the same gradients."""
+    from manydepth.trainer import Trainer
+    from oracle import nets as onets
+    from polardepth import synthetic
+    torch.manual_seed(0)
+    ref = onets.build_models(True, True, 0.0)
+    for m in ref.values():
+        fill_state_dict(m)
+    ref_order = ["normals_encoder", "xolp_encoder", "joint_encoder", "rgb_encoder", "mono_depth"]
+    params = [p for n in ref_order for p in ref[n].parameters()]
+    names = [f"{n}.{pn}" for n in ref_order for pn, _ in ref[n].named_parameters()]
+    used = [not (n.startswith("rgb_encoder.encoder.") and n.split(".")[2] in ("layer3", "layer4", "fc")) for n in names]
+    topt = torch.optim.Adam(params, 1e-4)
+    g = torch.Generator().manual_seed(1)
+    for p, u in zip(params, used):
+        if u:
+            p.grad = 1e-2 * torch.randn(p.shape, generator=g)
+    topt.step()                                   # the state the reference would have saved after its first step
+    folder = tmp_path / "ref_ckpt"
+    folder.mkdir()
+    for n, m in ref.items():
+        torch.save(m.state_dict(), folder / f"{n}.pth")
+    torch.save(topt.state_dict(), folder / "adam.pth")
+
+    tr = Trainer(_opts(tmp_path, ["--dropout_rate", "0", "--load_weights_folder", str(folder), "--models_to_load",
+                                  *ref_order]))
+    assert tr.model_optimizer.step_count == 1
+    for n, m in ref.items():                      # weights arrived
+        for k, v in m.state_dict().items():
+            assert torch.equal(tr.models[n].state_dict()[k].cpu(), v), (n, k)
+    # one more step on both sides with the same gradients (taken from the GPU backward)
+    batch = synthetic.make_batch(2, 64, 96, frame_w=92, device="cuda", seed=9)
+    tr.set_train()
+    tr.model_optimizer.zero_grad()
+    _, losses, _ = tr.process_batch(dict(batch), is_train=True)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    mine = dict((f"{mn}.{pn}", p) for mn in tr.models for pn, p in tr.models[mn].named_parameters())
+    for n, p, u in zip(names, params, used):
+        p.grad = mine[n].grad.detach().cpu().clone() if u else None
+    tr.model_optimizer.step()
+    topt.step()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p, u in zip(names, params, used):
+        if u:
+            worst = max(worst, (mine[n].detach().cpu() - p.detach()).abs().max().item())
+    assert worst < 2e-7, worst                    # second Adam step from the reference's moments: same update (fp32 rounding)
+
+
+def test_evaluation_runs_on_the_device_with_per_material_metrics(tmp_path, capsys):
+    """manydepth.evaluation.Evaluation (evaluation.py:120-288): forward in eval mode + per-material metrics reduced by
+    pd_depth_metrics; the device numbers equal the reference's NumPy loop (compute_depth_errors_numpy) on the same
+    predictions."""
+    from manydepth.evaluation import Evaluation, _MATERIAL_GREY
+    from manydepth.layers import compute_depth_errors_numpy
+    with pytest.raises(FileNotFoundError):
+        Evaluation(data_path=str(tmp_path / "missing"))
+    ev = Evaluation(data_path="synthetic", height=64, width=96, batch_size=4)
+    ev.load_mono_model()
+    res = ev.test()
+    assert "all" in res and res["all"].shape == (7,) and np.isfinite(res["all"]).all()
+    errs = {o: [] for o in ["all"] + list(_MATERIAL_GREY)}
+    for inputs in ev.test_loader:
+        inputs = {k: v.cuda() for k, v in inputs.items()}
+        pred = ev.predict(inputs).cpu().numpy()
+        gt, mk = inputs["depth_gt"].cpu().numpy(), inputs[("mask", 0, 0)].cpu().numpy()
+        for b in range(gt.shape[0]):
+            for o in errs:
+                m = (gt[b, 0] > 0.1) & (gt[b, 0] < 2.0)
+                if o != "all":
+                    m &= mk[b, 0] == _MATERIAL_GREY[o]
+                if m.any():
+                    errs[o].append(compute_depth_errors_numpy(gt[b, 0][m], pred[b, 0][m]))
+    for o, e in errs.items():
+        if e:
+            np.testing.assert_allclose(res[o], np.array(e).mean(0), rtol=2e-5, atol=1e-6)
