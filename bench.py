@@ -64,8 +64,8 @@ def train_step(tr, batch):
     return losses["loss"]
 
 
-def cpu_baseline(sample_batch=2, steps=1):
-    """Oracle train step (fwd + loss + bwd + Adam) on the host cores; bounded sample of the same workload."""
+def _oracle_step_factory(sample_batch):
+    """One oracle train step (fwd + loss + bwd + Adam) of the same 3-encoder 512x640 workload as a closure."""
     import numpy as np
     from oracle import nets as onets, losses as ol, polar as opolar
     torch.manual_seed(0)
@@ -85,8 +85,8 @@ def cpu_baseline(sample_batch=2, steps=1):
     K = torch.eye(4)[None].repeat(sample_batch, 1, 1)
     K[:, 0, 0] = K[:, 1, 1] = 0.65 * W; K[:, 0, 2] = W / 2; K[:, 1, 2] = H / 2
     inputs["depth"] = gt; inputs[("K", 0)] = K
-    t0 = time.perf_counter()
-    for _ in range(steps):
+
+    def step():
         opt.zero_grad()
         xolp, _, _, _ = opolar.polar_forward(pol)                       # DataLoader-side XOLP of the reference
         xolp = torch.nn.functional.pad(xolp, (0, W - FRAME_W))
@@ -96,11 +96,54 @@ def cpu_baseline(sample_batch=2, steps=1):
         L = ol.compute_losses(inputs, outs, normals_loss_weight=0.35)
         L["loss"].backward()
         opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_batch * steps / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{steps} step(s) of the same 3-encoder 512x640 train step at batch {sample_batch} "
-                      f"(oracle/: PyTorch-CPU + NumPy restatement, {dt:.1f} s)"}
+    return step
+
+
+def _median_time(fn, warmup, reps):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def cpu_baseline():
+    """CPU baseline per BASELINE.md §2 on this box's host cores, bounded: the oracle train step on all cores (warm-up
+    1, median of 3, batch 2) and on one thread (the reference pins OMP/MKL_NUM_THREADS=1, trainer.py:9-11; one step at
+    batch 1), and the per-frame K1 paths of the reference on one 512x612 frame (warm-up 2, median of 5): closed-form
+    fp64 XOLP, the literal lstsq XOLP (xolp.py:20) and the SciPy-table normals (normals_vec.py:11-60)."""
+    import numpy as np
+    from oracle import polar as opolar
+    cores = torch.get_num_threads()
+    step = _oracle_step_factory(2)
+    t_all = _median_time(step, 1, 3)
+    torch.set_num_threads(1)
+    try:
+        step1 = _oracle_step_factory(1)
+        t_one = _median_time(step1, 0, 1)
+    finally:
+        torch.set_num_threads(cores)
+    rng = np.random.default_rng(1)
+    frame = rng.integers(0, 256, (H, FRAME_W, 4), dtype=np.uint8)
+    P = H * FRAME_W
+    t_closed = _median_time(lambda: opolar.iun_and_xolp(frame), 2, 5)
+    t_lstsq = _median_time(lambda: opolar.iun_and_xolp_lstsq(frame), 1, 3)
+    xolp = torch.from_numpy(opolar.xolp_planes(np.ascontiguousarray(np.moveaxis(frame, -1, 0)[None]))[0])
+    t_norm = _median_time(lambda: opolar.get_normals(xolp).float(), 2, 5)
+    return {"value": round(2 / t_all, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ (PyTorch-CPU + NumPy/SciPy restatement of the reference) train step of the same 3-encoder "
+                      f"512x640 workload at batch 2: warm-up 1, median of 3 = {t_all:.1f} s/step on {cores} threads",
+            "one_thread": {"value": round(1 / t_one, 4), "unit": "images/s", "cores": 1,
+                           "sample": f"same step at batch 1, torch.set_num_threads(1), one step = {t_one:.1f} s"},
+            "k1_per_frame_1thread": {
+                "frame": "512x612 uint8 x 4",
+                "xolp_closed_form_fp64_ms": round(t_closed * 1e3, 1), "xolp_closed_form_GBps_12Bpx": round(P * 12 / t_closed / 1e9, 3),
+                "xolp_lstsq_ms": round(t_lstsq * 1e3, 1),
+                "normals_scipy_ms": round(t_norm * 1e3, 1),
+                "xolp_plus_normals_GBps_48Bpx": round(P * 48 / (t_closed + t_norm) / 1e9, 3)}}
 
 
 def main():

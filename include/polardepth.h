@@ -229,6 +229,11 @@ int pd_smooth_bwd(const void* disp, const void* img, const void* mean, const voi
 int pd_loss_finalize(const void* sup_part, const int* sup_rows, const void* sm_part, const int* sm_rows,
                      const int* dims, const int* scale_ids, int S, int part_stride, float w_normals,
                      float w_smooth, void* sums, void* vals, void* stream);
+/* vals from given sums [S][5] fp64 (sum|.|m, sum(2-cos)m, sum m, smooth_x, smooth_y): the division step of
+ * pd_loss_finalize alone, for data-parallel runs that all-reduce the three masked sums per scale first
+ * (trainer.py:1247,1308 normalise by the mask count of the whole batch). */
+int pd_loss_from_sums(const void* sums, const int* dims, const int* scale_ids, int S, float w_normals,
+                      float w_smooth, void* vals, void* stream);
 int pd_loss_weights(const void* gvals, const int* scale_ids, int S, float w_normals, float w_smooth, void* wts,
                     void* stream);
 

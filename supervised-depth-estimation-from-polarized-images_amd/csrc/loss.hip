@@ -424,6 +424,26 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     vals[0] = (float)(total / m.S);
 }
 
+// vals from given sums (S x 5 doubles): the second half of loss_finalize_kernel, for sums that were exchanged
+// between data-parallel ranks in between (global mask normalisation, trainer.py:1247,1308 over the global batch)
+__global__ void loss_from_sums_kernel(const double* __restrict__ sums, const LossMeta m, float w_normals,
+                                      float w_smooth, float* __restrict__ vals) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double total = 0.0;
+    for (int s = 0; s < m.S; ++s) {
+        const double* a = sums + s * 5;
+        const int N = m.N[s], h = m.h[s], w = m.w[s];
+        const double l1 = a[0] / a[2], ln = a[1] / a[2];
+        const double smooth = a[3] / ((double)N * h * (w - 1)) + a[4] / ((double)N * (h - 1) * w);
+        const double ls = l1 + (double)w_normals * ln + (double)w_smooth * smooth / (double)(1 << m.scale_id[s]);
+        vals[1 + 3 * s] = (float)ls;
+        vals[2 + 3 * s] = (float)l1;
+        vals[3 + 3 * s] = (float)ln;
+        total += ls;
+    }
+    vals[0] = (float)(total / m.S);
+}
+
 // per-scale weights (w_L1, w_LN, w_sm) from the upstream gradient of vals
 __global__ void loss_weights_kernel(const float* __restrict__ gvals, const LossMeta m, float w_normals, float w_smooth,
                                     float* __restrict__ wts) {
@@ -525,6 +545,19 @@ extern "C" int pd_loss_finalize(const void* sup_part, const int* sup_rows, const
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)sup_part,
                        (const float*)sm_part, m, part_stride, w_normals, w_smooth, (double*)sums, (float*)vals);
     return pd::check_launch("pd_loss_finalize");
+}
+
+extern "C" int pd_loss_from_sums(const void* sums, const int* dims, const int* scale_ids, int S, float w_normals,
+                                 float w_smooth, void* vals, void* stream) {
+    PD_REQUIRE(sums && dims && scale_ids && vals && S > 0 && S <= 8, "pd_loss_from_sums: bad arguments");
+    LossMeta m{};
+    m.S = S;
+    for (int s = 0; s < S; ++s) {
+        m.N[s] = dims[3 * s]; m.h[s] = dims[3 * s + 1]; m.w[s] = dims[3 * s + 2]; m.scale_id[s] = scale_ids[s];
+    }
+    hipLaunchKernelGGL(loss_from_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)sums, m,
+                       w_normals, w_smooth, (float*)vals);
+    return pd::check_launch("pd_loss_from_sums");
 }
 
 extern "C" int pd_loss_weights(const void* gvals, const int* scale_ids, int S, float w_normals, float w_smooth,

@@ -172,8 +172,12 @@ class Trainer:
             self.ssim = SSIM()
         self.depth_metric_names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
         self.depth_metric_names_mono = [n.replace("/", "_mono/", 1) for n in self.depth_metric_names]
+        # PD_GLOBAL_LOSS_NORM=1 (or opt.global_loss_norm): mask-normalise over the global batch like the reference's
+        # single process; default = per replica (standard DDP semantics, no exchange on the loss path)
+        global_norm = self.distributed and (bool(getattr(self.opt, "global_loss_norm", False))
+                                            or os.environ.get("PD_GLOBAL_LOSS_NORM") == "1")
         self.loss_cfg = PF.LossCfg(self.opt.scales, self.opt.min_depth, self.opt.max_depth, self.opt.normals_loss_weight,
-                                   self.opt.disparity_smoothness, self.opt.height, self.opt.width)
+                                   self.opt.disparity_smoothness, self.opt.height, self.opt.width, global_norm=global_norm)
         self.epoch, self.step = 0, 0
         self.start_time = time.time()
         if self.rank == 0:

@@ -64,6 +64,7 @@ SIGNATURES = {
     "pd_smooth_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pd_smooth_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_loss_finalize": (_i, [_vp, _ip, _vp, _ip, _ip, _ip, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "pd_loss_from_sums": (_i, [_vp, _ip, _ip, _i, _f, _f, _vp, _vp]),
     "pd_loss_weights": (_i, [_vp, _ip, _i, _f, _f, _vp, _vp]),
     "pd_softmax_rows_fwd": (_i, [_vp, _l, _l, _f, _vp]),
     "pd_softmax_rows_bwd": (_i, [_vp, _vp, _l, _l, _f, _vp]),

@@ -568,11 +568,34 @@ def self_attention(q, k, v):
 
 # ------------------------------------------------------------------ multi-scale loss
 class LossCfg:
-    def __init__(self, scales, min_depth, max_depth, normals_loss_weight, disparity_smoothness, height, width):
+    def __init__(self, scales, min_depth, max_depth, normals_loss_weight, disparity_smoothness, height, width,
+                 global_norm=False, group=None):
         self.scales = list(scales)
         self.min_depth, self.max_depth = float(min_depth), float(max_depth)
         self.w_normals, self.w_smooth = float(normals_loss_weight), float(disparity_smoothness)
         self.H, self.W = int(height), int(width)
+        # data parallel: normalise the masked L1 / normals terms by the mask count of the GLOBAL batch, as the
+        # reference's single process does (trainer.py:1247,1308), instead of per replica
+        self.global_norm, self.group = bool(global_norm), group
+
+
+def exchange_loss_sums(sums, group=None):
+    """All-reduce the three masked sums per scale (sum|d|m, sum(2-cos)m, sum m) over the data-parallel ranks.
+
+    sums: fp64 [S*5] of this rank (pd_loss_finalize).  Returns (sums_value, sums_bwd): the first carries the global
+    masked sums (the loss value every rank reports); the second carries sum m / world instead, so that the usual
+    1/world averaging of the gradients yields exactly d/dtheta of (sum_r num_r) / (sum_r den_r).  The smoothness
+    sums stay local (its mean over equal-sized replicas is what the gradient averaging already computes)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    v = sums.view(-1, 5).clone()
+    if world > 1 or dist.is_initialized():
+        red = v[:, :3].contiguous()
+        dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
+        v[:, :3] = red
+    b = v.clone()
+    b[:, 2] = v[:, 2] / world
+    return v.reshape(-1), b.reshape(-1)
 
 
 def _iarr(vals):
@@ -620,6 +643,10 @@ class MultiScaleLossFn(torch.autograd.Function):
         check(lib.pd_loss_finalize(ptr(sup_part), _iarr(sup_rows), ptr(sm_part), _iarr(sm_rows), _iarr(dims),
                                    _iarr(cfg.scales), S, stride, cfg.w_normals, cfg.w_smooth, ptr(sums), ptr(vals), st),
               "pd_loss_finalize")
+        if cfg.global_norm:       # 3 x S doubles over RCCL, then the division again on the exchanged sums
+            sums_val, sums = exchange_loss_sums(sums, cfg.group)
+            check(lib.pd_loss_from_sums(ptr(sums_val), _iarr(dims), _iarr(cfg.scales), S, cfg.w_normals, cfg.w_smooth,
+                                        ptr(vals), st), "pd_loss_from_sums")
         ctx.cfg, ctx.S = cfg, S
         ctx.save_for_backward(gt, K, sums, *disps, *colors, *depths, *means)
         ctx.mark_non_differentiable(*depths)

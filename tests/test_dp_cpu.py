@@ -69,3 +69,66 @@ def test_reducer_is_noop_single_process():
     for p in store.used_params():
         p._pd_grad_ready()
     red.finish()
+
+
+def _worker_real_models(rank, world, port, ret):
+    """The reducer over the REAL parameter store of the five models (CPU tensors): buckets follow backward completion
+    (decoder first), the unused ResNet tail is neither reduced nor counted, the reduced flat gradient equals the sum
+    over ranks, and exchange_loss_sums yields the global mask normalisation (trainer.py:1247,1308)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from manydepth import networks
+        from polardepth.engine import ParamStore, GradReducer
+        from polardepth.functional import exchange_loss_sums
+        torch.manual_seed(0)
+        models = {"rgb_encoder": networks.ShallowResnetEncoder(18, False), "xolp_encoder": networks.ShallowEncoder('XOLP', 2, 0.1),
+                  "normals_encoder": networks.ShallowNormalsEncoder(9, 0.1), "joint_encoder": networks.JointEncoder(0.1, True, True),
+                  "mono_depth": networks.DepthDecoder(np.array([64, 64, 128, 256, 512]), range(4))}
+        order = ["rgb_encoder", "xolp_encoder", "normals_encoder", "joint_encoder", "mono_depth"]
+        unused = lambda m, p: m == "rgb_encoder" and p.split(".")[1] in ("layer3", "layer4", "fc")
+        store = ParamStore(models, order=order, unused=unused, device=torch.device("cpu"))
+        red = GradReducer(store)                       # 16 MB buckets
+        assert 85e6 < store.n_used * 4 < 86e6 and 5 <= len(red.buckets) <= 9      # 85 MB in <= 16 MB buckets cut at parameter boundaries
+        first = [n for n, _ in store.entries[:3]]
+        assert all(n.startswith("mono_depth.") for n in first)           # decoder gradients complete first
+        assert red.buckets[-1][1] == store.n_used
+        # backward order: mark parameters ready front to back; early buckets must fire before the last one is complete
+        g = torch.Generator().manual_seed(100 + rank)
+        store.grad[:store.n_used].copy_(torch.randn(store.n_used, generator=g))
+        tail_before = store.grad[store.n_used:].clone()
+        local = store.grad[:store.n_used].clone()
+        fired = []
+        for i, p in enumerate(store.used_params()):
+            p._pd_grad_ready()
+            fired.append(sum(red.launched))
+        assert fired[len(fired) // 3] >= 1 and fired[-1] == len(red.buckets)
+        red.finish()
+        other = torch.randn(store.n_used, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+        assert torch.allclose(store.grad[:store.n_used], local + other, rtol=0, atol=1e-6)
+        assert torch.equal(store.grad[store.n_used:], tail_before)       # unused ResNet layers: never touched
+        # loss scalar exchange: rank r holds (sum|d|m, sum(2-cos)m, sum m, sx, sy) per scale
+        S = 4
+        sums = torch.tensor([[10.0 * (rank + 1) + s, 3.0 * (rank + 1) + s, 100.0 * (rank + 1) + 7 * s, 5.0 + rank, 6.0 + rank]
+                             for s in range(S)], dtype=torch.float64).reshape(-1)
+        val, bwd = exchange_loss_sums(sums)
+        v, b = val.view(S, 5), bwd.view(S, 5)
+        for s in range(S):
+            assert v[s, 0].item() == 10.0 * 3 + 2 * s and v[s, 2].item() == 100.0 * 3 + 14 * s     # global sums
+            assert v[s, 3].item() == 5.0 + rank and b[s, 3].item() == 5.0 + rank                   # smoothness stays local
+            assert b[s, 2].item() == v[s, 2].item() / world                                        # gradient denominator
+            # mean over ranks of num_r / (den_global / world) == sum_r num_r / den_global
+            num_r = [10.0 * (r + 1) + s for r in range(world)]
+            assert abs(sum(n / b[s, 2].item() for n in num_r) / world - sum(num_r) / v[s, 2].item()) < 1e-15
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_over_the_real_five_model_store_and_loss_scalar_exchange():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker_real_models, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}

@@ -1,0 +1,36 @@
+"""Data-parallel path on ONE MI355X: PD_DIST_TEST=1 initialises torch.distributed with world size 1 on RCCL, so a
+real training step runs the bucketed all-reduce on the comm stream with the weight-gradient side stream joined --
+everything an N-rank run does except having peers.  Its parameters after two steps must be bit-equal to the plain
+single-process run (an all-reduce over one rank is the identity), also with the global mask normalisation of the
+loss switched on (the exchanged sums of one rank are its own)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HELPER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_step_helper.py")
+
+
+def _run(tmp_path, name, **env):
+    out = tmp_path / f"{name}.pt"
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    e["MASTER_PORT"] = str(29500 + (os.getpid() + len(name)) % 400)
+    r = subprocess.run([sys.executable, HELPER, str(out)], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return torch.load(out)
+
+
+def test_world1_rccl_step_is_bit_equal_to_the_plain_step(tmp_path):
+    plain = _run(tmp_path, "plain", PD_DIST_TEST=0)
+    dist1 = _run(tmp_path, "dist", PD_DIST_TEST=1)
+    glob1 = _run(tmp_path, "glob", PD_DIST_TEST=1, PD_GLOBAL_LOSS_NORM=1)
+    assert not plain["distributed"] and not plain["reducer_active"]
+    assert dist1["distributed"] and dist1["reducer_active"] and dist1["buckets"] >= 5 and not dist1["global_norm"]
+    assert glob1["global_norm"]
+    assert torch.isfinite(plain["losses"]).all()
+    assert torch.equal(plain["losses"], dist1["losses"]) and torch.equal(plain["flat"], dist1["flat"])
+    assert torch.equal(plain["losses"], glob1["losses"]) and torch.equal(plain["flat"], glob1["flat"])
