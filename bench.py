@@ -156,9 +156,16 @@ def main():
     ap.add_argument("--attention", action="store_true",
                     help="BASELINE configs[4] variant (single-head attention at the joint-encoder merge, fp32); "
                          "not the headline workload")
+    ap.add_argument("--bf16", action="store_true",
+                    help="with --attention: the attention block on the bf16 matrix cores (configs[4] as specified: "
+                         "v_mfma_f32_32x32x16_bf16, fp32 softmax statistics and accumulators); the JSON line then carries "
+                         "an `attention` object graded against the bf16 MFMA peak")
     args = ap.parse_args()
     if args.attention:
         os.environ["PD_JOINT_ATTENTION"] = "1"
+    if args.bf16:
+        assert args.attention, "--bf16 selects the bf16 attention kernels: use it with --attention"
+        os.environ["PD_ATTENTION_BF16"] = "1"
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -297,6 +304,33 @@ def main():
                                              "3.7 TB/s after a cache-replacing predecessor (tools/membench2.hip d)"}
     del pols, k1_outs
 
+    attention = None
+    if args.attention:
+        # the attention kernels alone at the step's size (16 x 5120 tokens, C = 128): HIP events, algorithmic FLOPs
+        # 4 N T^2 C forward, 10 N T^2 C backward (five products), against the matrix peak of the operand type
+        Tn, Cn = (H // 8) * (W // 8), 128
+        qa, ka, va = (torch.randn(args.batch, Cn, H // 8, W // 8, device="cuda").contiguous(memory_format=torch.channels_last)
+                      .requires_grad_(True) for _ in range(3))
+        PF.self_attention(qa, ka, va).sum().backward()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        reps = 5
+        ev[0].record()
+        outs = [PF.self_attention(qa, ka, va) for _ in range(reps)]
+        ev[1].record()
+        for o_ in outs:
+            o_.backward(torch.ones_like(o_))
+        ev[2].record()
+        torch.cuda.synchronize()
+        t_f, t_b = ev[0].elapsed_time(ev[1]) / reps, ev[1].elapsed_time(ev[2]) / reps
+        fl = args.batch * Tn * Tn * Cn
+        peak = 2500.0 if args.bf16 else FP32_MFMA_PEAK_TF
+        attention = {"dtype": "bf16 operands, fp32 softmax/accumulate" if args.bf16 else "f32",
+                     "kernels": "attn_*_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if args.bf16 else "attn_*_kernel (v_mfma_f32_32x32x2_f32)",
+                     "tokens": Tn, "fwd_ms": round(t_f, 3), "bwd_ms": round(t_b, 3),
+                     "fwd_TFLOPs": round(4 * fl / t_f / 1e9, 1), "bwd_TFLOPs": round(10 * fl / t_b / 1e9, 1),
+                     "peak_TFLOPs": peak, "fwd_frac": round(4 * fl / t_f / 1e9 / peak, 4),
+                     "bwd_frac": round(10 * fl / t_b / 1e9 / peak, 4)}
+
     result = {
         "metric": "train images/sec (512x612, 3-encoder)", "value": round(args.batch * world * args.steps / dt, 3),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -311,6 +345,11 @@ def main():
         "final_loss": round(loss_val, 6), "host_enqueue_ms_per_step": None if t_host is None else round(t_host * 1e3, 2),
         "roofline": roofline, "xolp_kernel": xolp_kernel,
     }
+    if attention is not None:
+        result["attention"] = attention
+        if args.bf16:
+            result["dtype"] = "f32 (network) + bf16 attention operands"
+            result["config"]["workload"] += " on the bf16 matrix cores"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.attention:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -41,6 +41,7 @@ class DropoutState:
 _WGRAD_STREAMS = {}
 USE_WGRAD_STREAM = os.environ.get("PD_WGRAD_STREAM", "1") == "1"
 USE_FLASH_ATTENTION = os.environ.get("PD_FLASH_ATTENTION", "1") != "0"   # fused attention kernels (config 5)
+USE_BF16_ATTENTION = os.environ.get("PD_ATTENTION_BF16", "0") == "1"     # ... on the bf16 matrix cores (configs[4] as specified)
 USE_BN_FOLDING = os.environ.get("PD_BN_FOLDING", "1") != "0"   # inference: BatchNorm folded into the conv epilogue
 USE_DISP_HEADS = os.environ.get("PD_DISP_HEADS", "1") != "0"     # direct kernels for the 1-channel disparity heads
 USE_S2D_STEMS = os.environ.get("PD_S2D_STEMS", "1") == "1"
@@ -542,7 +543,9 @@ class FlashAttentionFn(torch.autograd.Function):
         scale = 1.0 / (C ** 0.5)
         o = ops.empty_nhwc(N, C, H, W, q.device)
         lse = torch.empty((N, T), dtype=torch.float32, device=q.device)
-        check(lib.pd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), N, T, C, scale, stream_ptr()), "pd_attn_fwd")
+        ctx.bf16 = USE_BF16_ATTENTION
+        fwd = lib.pd_attn_bf16_fwd if ctx.bf16 else lib.pd_attn_fwd
+        check(fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), N, T, C, scale, stream_ptr()), "pd_attn_fwd")
         ctx.scale = scale
         ctx.save_for_backward(q, k, v, o, lse)
         return o
@@ -555,8 +558,9 @@ class FlashAttentionFn(torch.autograd.Function):
         do = ops.as_nhwc(do)
         dq, dk, dv = (ops.empty_nhwc(N, C, H, W, do.device) for _ in range(3))
         delta = torch.empty_like(lse)
-        check(lib.pd_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                              N, T, C, ctx.scale, stream_ptr()), "pd_attn_bwd")
+        bwd = lib.pd_attn_bf16_bwd if ctx.bf16 else lib.pd_attn_bwd
+        check(bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                  N, T, C, ctx.scale, stream_ptr()), "pd_attn_bwd")
         return dq, dk, dv
 
 

@@ -184,3 +184,45 @@ def test_attention_variant_matches_oracle():
         _close(pm.grad, pr.grad, GRAD_TOL, kname)
     for a, b in zip(cins, ins):
         _close(a.grad, b.grad, GRAD_TOL, "input grad")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12), (1, 64, 80)])
+def test_bf16_attention_matches_fp32_attention_within_bf16_tolerance(shape):
+    """configs[4] as specified: the fused attention on v_mfma_f32_32x32x16_bf16 (csrc/attention_bf16.hip).  Operands are
+    rounded to bf16 (8-bit mantissa, 2^-9 relative), softmax statistics and accumulators stay fp32.  Tolerance, of
+    the tensor's own scale: forward 1e-2, gradients 2e-2 (the fp32 kernels: 2e-5 / 5e-4); the log-sum-exp statistic
+    (fp32 arithmetic on scores of bf16-rounded operands: |score| * 2^-8) 2e-2 absolute.  Reference: fp64 softmax
+    attention in torch."""
+    from polardepth import functional as PF
+    from polardepth._lib import lib, check, ptr, stream_ptr
+    N, Hh, Ww = shape
+    g = torch.Generator().manual_seed(21)
+    q, k, v = (torch.randn(N, 128, Hh, Ww, generator=g) for _ in range(3))
+    if Hh * Ww > 1000:          # make the softmax peaky on the big case: a few keys carry most of the mass
+        q = q * 2.0
+    qc, kc, vc = (t.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) for t in (q, k, v))
+    old = PF.USE_BF16_ATTENTION
+    PF.USE_BF16_ATTENTION = True
+    try:
+        o = PF.self_attention(qc, kc, vc)
+        assert o.grad_fn.__class__.__name__.startswith("FlashAttentionFn")
+        w = torch.randn(N, 128, Hh, Ww, generator=g)
+        (o * w.cuda()).sum().backward()
+    finally:
+        PF.USE_BF16_ATTENTION = old
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    tok = lambda t: t.flatten(2).transpose(1, 2)
+    scores = tok(qr) @ tok(kr).transpose(1, 2) / 128 ** 0.5
+    ref = (torch.softmax(scores, -1) @ tok(vr)).transpose(1, 2).reshape(N, 128, Hh, Ww)
+    (ref * w.double()).sum().backward()
+    _close(o, ref.detach().float(), 1e-2, "bf16 attention fwd")
+    for name, a, b in (("dq", qc, qr), ("dk", kc, kr), ("dv", vc, vr)):
+        _close(a.grad, b.grad.float(), 2e-2, "bf16 attention " + name)
+    # lse from the kernel directly
+    T_ = Hh * Ww
+    o2 = torch.empty_like(qc.detach())
+    lse = torch.empty((N, T_), device="cuda")
+    check(lib.pd_attn_bf16_fwd(ptr(qc.detach()), ptr(kc.detach()), ptr(vc.detach()), ptr(o2), ptr(lse), N, T_, 128,
+                               1.0 / 128 ** 0.5, stream_ptr()), "pd_attn_bf16_fwd")
+    assert (lse.cpu().double() - torch.logsumexp(scores.detach(), -1)).abs().max().item() < 2e-2
+    assert torch.equal(o2, o.detach())
