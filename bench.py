@@ -52,7 +52,8 @@ def build_trainer(batch, height, width, log_dir):
         "--disparity_smoothness", "1e-3", "--depth_supervision_only", "True", "--depth_supervision", "True",
         "--normals_loss_weight", "0.35", "--augment_xolp", "--augment_normals", "--learning_rate", "1e-4",
         "--weights_init", "scratch", "--num_workers", "0", "--log_dir", log_dir, "--data_path", "synthetic",
-        "--data_path_val", "synthetic", "--model_name", "bench"])
+        "--data_path_val", "synthetic", "--model_name", "bench"] +
+        (["--dropout_rate", os.environ["PD_BENCH_DROPOUT"]] if "PD_BENCH_DROPOUT" in os.environ else []))   # tuning aid only
     return Trainer(opts)
 
 

@@ -154,8 +154,9 @@ int pd_weight_transpose(const void* w, void* wt, int Cout, int T, int Cin, void*
  * Memory-bound kernels fused around the convolutions (NHWC fp32, 16 bytes per lane).
  *
  * pd_bn_fwd_finalize: BatchNorm2d statistics.  training != 0: reduces the conv epilogue partials
- *   [R][C][2] in fp64 (acc_ws: 2*C doubles that must be ZERO on entry and are left zero by the call -- a
- *   long-lived accumulator per stream saves a memset per layer; same contract in pd_bn_bwd_finalize),
+ *   [R][C][2] in fp64 (acc_ws: 2*C + 1 doubles -- the sums and an arrival ticket -- that must be ZERO on entry
+ *   and are left zero by the call: a long-lived accumulator per stream saves a memset per layer; the workgroup
+ *   that arrives last finalises, so the whole call is ONE launch; same contract in pd_bn_bwd_finalize),
  *   updates running_mean/var with torch semantics
  *   (momentum, unbiased variance) and emits scale = gamma*invstd, shift = beta - mean*scale plus
  *   the saved mean / invstd; training == 0: coefficients from the running statistics.
@@ -187,8 +188,9 @@ int pd_chain_bwd_apply(const void* dy, long ld_dy, const void* x, const void* ou
                        int pool, float drop_p, uint64_t seed, uint64_t offset, int relu_post, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) of the ResNet stem (resnet_encoder.py:814) and its gradient. */
-int pd_maxpool3s2_fwd(const void* x, void* y, int N, int H, int W, int C, void* stream);
-int pd_maxpool3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+/* idx (optional in fwd): uint8 [N,Ho,Wo,C] window position (dh*3+dw) of the first maximum, consumed by bwd. */
+int pd_maxpool3s2_fwd(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream);
+int pd_maxpool3s2_bwd(const void* idx, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
 
 /* Decoder glue: out[N,2H,2W,Ca+Cs] = cat(bilinear_x2(a), skip)  (layers.py:446-449 upsample,
  * depth_decoder.py:64-67 cat) and the gradient of the upsampled part (gather form). */

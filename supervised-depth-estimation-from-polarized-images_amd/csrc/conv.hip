@@ -96,8 +96,25 @@ __device__ __forceinline__ bool tap_in(int rh, int rw, int kh, int kw, int H, in
     return ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
 }
 
-template <int BM, int BN, int WM, int WN, bool VEC, int MODE>
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+
+// One direct-to-LDS piece (1 KiB per wave: LDS address = M0 + 16 * lane), issued from inline asm: told about a pending
+// LDS-DMA, hipcc drains vmcnt before EVERY fragment read (ds_read) of the loop, which serialises the prefetch;
+// unseen, the piece stays in flight across the MFMAs and is retired by the explicit dma_wait() before the barrier.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, const void* lds_wave_base, unsigned voff) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(m0v), "v"(voff), "s"(r) : "memory");     // (m0 is reserved: nothing else in this kernel uses it)
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// DMA (vector path only): the A and B chunks go global -> LDS directly (buffer_load_dwordx4 ... lds: 1 KiB = eight
+// 128-byte tile rows per wave instruction, lane l -> row l/8, physical slot l%8), no staging registers and no
+// ds_write pass.  The LDS image stays the XOR-swizzled one the fragment reads expect: a thread loads the LOGICAL
+// slot (l%8) ^ ((row/2)%8) of its row -- the swizzle moves to the source address (same for all of its rows).
+template <int BM, int BN, int WM, int WN, bool VEC, int MODE, bool DMA = false>
 __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(!DMA || VEC, "direct-to-LDS staging needs the 16-byte gather path");
     constexpr int WAVES_N = BN / WN;
     // MFMA shape: 32x32x2 tiles, or 16x16x4 tiles for the 16-wide block tile (layers with <= 16 output channels
     // would leave half of a 32-wide tile empty; both shapes have the same flops per cycle)
@@ -110,9 +127,12 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int A_SC_ITERS = BM / 8;            // scalar elements per thread per chunk (A)
     constexpr int B_SC_ITERS = BN / 8;
 
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDT];
-    __shared__ int rowinfo[VEC ? 1 : BM][3];      // scalar path: element offset of the image (or -1), rh, rw
+    // one LDS object (a second __shared__ array next to a direct-to-LDS destination makes hipcc drain vmcnt before
+    // every fragment read): A tiles, B tiles, then the scalar path's row table
+    __shared__ __attribute__((aligned(16))) float smem_all[2 * BM * LDT + 2 * BN * LDT + (VEC ? 0 : BM * 3)];
+    float (*As)[BM][LDT] = reinterpret_cast<float (*)[BM][LDT]>(smem_all);
+    float (*Bs)[BN][LDT] = reinterpret_cast<float (*)[BN][LDT]>(smem_all + 2 * BM * LDT);
+    int (*rowinfo)[3] = reinterpret_cast<int (*)[3]>(smem_all + 2 * BM * LDT + 2 * BN * LDT);   // scalar path: element offset of the image (or -1), rh, rw
     float (*red)[WN][2] = reinterpret_cast<float (*)[WN][2]>(&As[0][0][0]);   // epilogue scratch, aliases As
 
     // XCD-aware mapping: consecutive logical tiles (which share input halos / the A tile) land
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
         __syncthreads();
     }
     // tap of this thread's k column, advanced by BK per chunk (no divisions in the loop)
-    int tk = VEC ? 4 * (tid & 7) : (tid & 31);
+    int tk = VEC ? (DMA ? 4 * ((tid & 7) ^ ((tid >> 4) & 7)) : 4 * (tid & 7)) : (tid & 31);
     int tkh, tkw, tc, tapoff;
     {
         const int tap = tk / a.C;
@@ -192,27 +212,33 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     float4 pa[VEC ? A_VEC_ITERS : 1], pb[VEC ? B_VEC_ITERS : 1];
     float sa[VEC ? 1 : A_SC_ITERS], sb[VEC ? 1 : B_SC_ITERS];
 
-    auto load_chunk = [&]() {   // loads the chunk the tap state points at, then advances it
+    auto load_chunk = [&](int dst) {   // loads the chunk the tap state points at (DMA: into LDS buffer dst), then advances it
         const bool kv = tk < a.K;
         if (VEC) {
 #pragma unroll
             for (int i = 0; i < A_VEC_ITERS; ++i) {
+                unsigned off;
                 if (lin) {
                     const int ih = MODE == MODE_TRANSPOSED ? rh[i] - tkh : rh[i] + tkh;
                     const int iw = MODE == MODE_TRANSPOSED ? rwc[i] - tkw : rwc[i] + tkw;
                     const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & kv;
-                    pa[i] = buf_ld4(rx, ok ? (unsigned)(rb[i] + tapoff) * 4u : OOB);
+                    off = ok ? (unsigned)(rb[i] + tapoff) * 4u : OOB;
                 } else {
                     int ih, iw;
                     const bool ok = tap_in<MODE>(rh[i], rwc[i], tkh, tkw, a.H, a.W, a.sshift, ih, iw) & kv & (rb[i] >= 0);
-                    const unsigned off = (unsigned)(rb[i] + ih * (int)a.sH + iw * (int)a.sW + tc) * 4u;
-                    pa[i] = buf_ld4(rx, ok ? off : OOB);
+                    off = ok ? (unsigned)(rb[i] + ih * (int)a.sH + iw * (int)a.sW + tc) * 4u : OOB;
                 }
+                if (DMA) dma16(rx, &As[dst][8 * wave + 32 * i][0], off);
+                else pa[i] = buf_ld4(rx, off);
             }
 #pragma unroll
             for (int i = 0; i < B_VEC_ITERS; ++i) {
                 const int nl = (tid >> 3) + 32 * i, nr = n0 + nl;
-                if (BN % 32 == 0 || nl < BN) pb[i] = buf_ld4(rw_, (kv & (nr < a.Co)) ? (unsigned)(nr * a.K + tk) * 4u : OOB);
+                const unsigned off = (kv & (nr < a.Co)) ? (unsigned)(nr * a.K + tk) * 4u : OOB;
+                if (BN % 32 == 0 || 8 * wave + 32 * i < BN) {        // (wave-uniform: a wave covers eight rows)
+                    if (DMA) dma16(rw_, &Bs[dst][8 * wave + 32 * i][0], off);
+                    else if (BN % 32 == 0 || nl < BN) pb[i] = buf_ld4(rw_, off);
+                }
             }
         } else {
 #pragma unroll
@@ -235,6 +261,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
         advance_tap();
     };
     auto store_chunk = [&](int buf) {
+        if (DMA) return;                 // the chunk is already on its way into LDS
         if (VEC) {
             const int pc = tid & 7;
 #pragma unroll
@@ -262,8 +289,9 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < ACCN; ++r) acc[i][j][r] = 0.f;
 
-    load_chunk();
+    load_chunk(0);
     store_chunk(0);
+    if (DMA) dma_wait();
     __syncthreads();
     // Fragment reads: lane -> (row = lane % MT, slot group = lane / MT).  One ds_read_b128 hands a lane four
     // consecutive k; MFMA number c of a group contracts component c of every lane, i.e. k = 4*slot + c over the
@@ -272,7 +300,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     const int frow = lane % MT, fh = lane / MT;
     for (int q = 0; q < nchunks; ++q) {
         const int buf = q & 1;
-        if (q + 1 < nchunks) load_chunk();
+        if (q + 1 < nchunks) load_chunk(buf ^ 1);
 #pragma unroll
         for (int g = 0; g < BK / (4 * SG); ++g) {
             float4 fa[TM], fb[TN];
@@ -300,6 +328,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
                 }
         }
         if (q + 1 < nchunks) store_chunk(buf ^ 1);
+        if (DMA) dma_wait();
         __syncthreads();
     }
 
@@ -382,7 +411,13 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
     const long nblk = (long)a.mtiles * a.ntiles;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
 #define PD_LAUNCH(V, MD) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, V, MD>), grid, block, 0, st, a)
-    if (vec) {
+#define PD_LAUNCH_DMA(MD) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, MD, true>), grid, block, 0, st, a)
+    static const bool dma = !(getenv("PD_CONV_DMA") && getenv("PD_CONV_DMA")[0] == '0');   // direct-to-LDS staging (default on)
+    if (vec && dma) {
+        if (a.mode == MODE_ZERO) PD_LAUNCH_DMA(MODE_ZERO);
+        else if (a.mode == MODE_REFLECT) PD_LAUNCH_DMA(MODE_REFLECT);
+        else PD_LAUNCH_DMA(MODE_TRANSPOSED);
+    } else if (vec) {
         if (a.mode == MODE_ZERO) PD_LAUNCH(true, MODE_ZERO);
         else if (a.mode == MODE_REFLECT) PD_LAUNCH(true, MODE_REFLECT);
         else PD_LAUNCH(true, MODE_TRANSPOSED);
@@ -392,6 +427,7 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
         else PD_LAUNCH(false, MODE_TRANSPOSED);
     }
 #undef PD_LAUNCH
+#undef PD_LAUNCH_DMA
     return pd::check_launch("pd_conv2d");
 }
 

@@ -15,6 +15,12 @@ constexpr int EW_T = 256;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// write-once streams (activations / gradients larger than the caches, optimizer state): nontemporal stores
+typedef float ew_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+    const ew_f4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<ew_f4*>(p));
+}
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 
 // ---------------------------------------------------------------- Philox4x32-10 (dropout masks)
@@ -40,10 +46,13 @@ __device__ __forceinline__ float4 dropout_scale(long q, uint64_t seed, uint64_t 
     return make_float4(r.x >= thr ? s : 0.f, r.y >= thr ? s : 0.f, r.z >= thr ? s : 0.f, r.w >= thr ? s : 0.f);
 }
 
-// ---------------------------------------------------------------- column reductions for BN
-// partial [R][C][2] fp32 -> acc [C][2] fp64 (atomics; a handful per workgroup)
-__global__ __launch_bounds__(EW_T) void colsum_kernel(const float* __restrict__ part, double* __restrict__ acc,
-                                                      long R, int C, int rows_per_block) {
+// ---------------------------------------------------------------- BatchNorm statistics: column sums + finalisation
+// partial [R][C][2] fp32 -> acc [C][2] fp64 (a handful of fp64 atomics per workgroup), then the workgroup that
+// arrives LAST (agent-scope ticket, release before / acquire after: cdna_hip_programming.md Guideline 16) turns the
+// sums into the layer's coefficients and leaves acc and the ticket zero for the next call.  One launch per
+// BatchNorm and direction instead of two (176 -> 88 per step).
+__device__ __forceinline__ void colsum_block(const float* __restrict__ part, double* __restrict__ acc, long R, int C,
+                                             int rows_per_block) {
     // thread -> (channel pair slot, row lane): 32 channels x 8 row lanes
     const int cgroups = (C + 31) / 32;
     const int cg = blockIdx.x % cgroups;
@@ -70,19 +79,39 @@ __global__ __launch_bounds__(EW_T) void colsum_kernel(const float* __restrict__ 
     }
 }
 
+// true in every thread of exactly one workgroup: the one whose ticket is the last.  The ticket word lives behind
+// the sums (acc[2C], as an unsigned) and is left zero.
+__device__ __forceinline__ bool last_block_arrives(double* acc, int C) {
+    __shared__ unsigned ticket_s;
+    unsigned* ticket = reinterpret_cast<unsigned*>(acc + 2 * C);
+    __syncthreads();                                   // this workgroup's atomics have been issued
+    if (threadIdx.x == 0) {
+        __threadfence();                               // release: they are performed before the ticket is taken
+        ticket_s = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool last = ticket_s == gridDim.x - 1;
+    if (last) {
+        if (threadIdx.x == 0) { __threadfence(); *ticket = 0u; }     // acquire; reset for the next call
+        __syncthreads();
+    }
+    return last;
+}
+__device__ __forceinline__ double acc_take(double* p) {             // read a finished sum past the L1 and clear it
+    const double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
 // training-mode statistics -> affine coefficients (+ running stats update, torch semantics)
-__global__ void bn_fwd_finalize_kernel(double* __restrict__ acc, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float* __restrict__ rmean,
-                                       float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
-                                       float* __restrict__ smean, float* __restrict__ sinvstd, int C, double count,
-                                       float momentum, float eps, int training) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__device__ __forceinline__ void bn_fwd_finalize_channel(int c, double s, double ss, const float* gamma, const float* beta,
+                                                        float* rmean, float* rvar, float* scale, float* shift,
+                                                        float* smean, float* sinvstd, double count, float momentum,
+                                                        float eps, int training) {
     float mean, invstd;
     if (training) {
-        const double m = acc[2 * c] / count;
-        double var = acc[2 * c + 1] / count - m * m;
-        acc[2 * c] = 0.0; acc[2 * c + 1] = 0.0;       // leave the accumulator clean for the next call
+        const double m = s / count;
+        double var = ss / count - m * m;
         if (var < 0.0) var = 0.0;
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -102,18 +131,43 @@ __global__ void bn_fwd_finalize_kernel(double* __restrict__ acc, const float* __
     if (smean) { smean[c] = mean; sinvstd[c] = invstd; }
 }
 
-// backward: acc = (sum g, sum g*xhat) -> dgamma, dbeta, coef = (mean g, mean g*xhat)
-__global__ void bn_bwd_finalize_kernel(double* __restrict__ acc, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef, int C, double count,
-                                       int accumulate) {
+__global__ __launch_bounds__(EW_T) void bn_fwd_stats_kernel(const float* __restrict__ part, double* __restrict__ acc, long R,
+                                                            int C, int rows_per_block, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, float* __restrict__ scale,
+                                                            float* __restrict__ shift, float* __restrict__ smean,
+                                                            float* __restrict__ sinvstd, double count, float momentum,
+                                                            float eps) {
+    colsum_block(part, acc, R, C, rows_per_block);
+    if (!last_block_arrives(acc, C)) return;
+    for (int c = threadIdx.x; c < C; c += EW_T) {
+        const double s = acc_take(acc + 2 * c), ss = acc_take(acc + 2 * c + 1);
+        bn_fwd_finalize_channel(c, s, ss, gamma, beta, rmean, rvar, scale, shift, smean, sinvstd, count, momentum, eps, 1);
+    }
+}
+
+// eval mode (running statistics): no sums
+__global__ void bn_fwd_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ smean, float* __restrict__ sinvstd, int C, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double sg = acc[2 * c], sgx = acc[2 * c + 1];
-    acc[2 * c] = 0.0; acc[2 * c + 1] = 0.0;           // leave the accumulator clean for the next call
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sgx;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sg;
-    coef[c] = (float)(sg / count);
-    coef[C + c] = (float)(sgx / count);
+    if (c < C) bn_fwd_finalize_channel(c, 0.0, 0.0, gamma, beta, rmean, rvar, scale, shift, smean, sinvstd, 1.0, 0.f, eps, 0);
+}
+
+// backward: acc = (sum g, sum g*xhat) -> dgamma, dbeta, coef = (mean g, mean g*xhat)
+__global__ __launch_bounds__(EW_T) void bn_bwd_stats_kernel(const float* __restrict__ part, double* __restrict__ acc, long R,
+                                                            int C, int rows_per_block, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ coef,
+                                                            double count, int accumulate) {
+    colsum_block(part, acc, R, C, rows_per_block);
+    if (!last_block_arrives(acc, C)) return;
+    for (int c = threadIdx.x; c < C; c += EW_T) {
+        const double sg = acc_take(acc + 2 * c), sgx = acc_take(acc + 2 * c + 1);
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sgx;
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sg;
+        coef[c] = (float)(sg / count);
+        coef[C + c] = (float)(sgx / count);
+    }
 }
 
 // ---------------------------------------------------------------- BN-apply chain
@@ -179,7 +233,7 @@ __global__ __launch_bounds__(EW_T) void chain_fwd_kernel(const ChainArgs a) {
         if (a.drop_p > 0.f) v = mul4(v, dropout_scale(i, a.seed, a.offset, a.drop_p));
         if (a.res) v = add4(v, ld4(a.res + (size_t)pix * a.ld_res + c4));
         if (a.relu_post) v = relu4(v);
-        st4(a.out + (size_t)pix * a.ld_out + c4, v);
+        st4_nt(a.out + (size_t)pix * a.ld_out + c4, v);
     }
 }
 
@@ -256,7 +310,7 @@ __global__ __launch_bounds__(EW_T) void chain_bwd_kernel(const ChainArgs a) {
             } else {
                 d = mul4(g, s);
             }
-            st4(a.dx + (size_t)pix * a.C + c4, d);
+            st4_nt(a.dx + (size_t)pix * a.C + c4, d);
         }
     }
     if (!APPLY) {
@@ -293,8 +347,11 @@ __global__ __launch_bounds__(EW_T) void relu_mask_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------- 3x3 stride-2 pad-1 max pool
+// idx (optional): per output element the window position dh*3+dw of its first maximum in scan order (torch
+// max_pool2d_with_indices), one byte per channel -- the backward pass then needs no second look at x.
 __global__ __launch_bounds__(EW_T) void maxpool3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                            int N, int H, int W, int C, int Ho, int Wo) {
+                                                            uint32_t* __restrict__ idx, int N, int H, int W, int C, int Ho,
+                                                            int Wo) {
     const int cq = C >> 2;
     const long total = (long)N * Ho * Wo * cq;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
@@ -304,6 +361,7 @@ __global__ __launch_bounds__(EW_T) void maxpool3_fwd_kernel(const float* __restr
         const int ho = (int)(pix % Ho);
         const long n = pix / Ho;
         float4 m = f4(-INFINITY);
+        uint32_t ix = 0, iy = 0, iz = 0, iw = 0;
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
             const int h = 2 * ho - 1 + dh;
@@ -312,51 +370,47 @@ __global__ __launch_bounds__(EW_T) void maxpool3_fwd_kernel(const float* __restr
             for (int dw = 0; dw < 3; ++dw) {
                 const int w = 2 * wo - 1 + dw;
                 if (w < 0 || w >= W) continue;
-                m = max4(m, ld4(x + ((n * H + h) * W + w) * C + c4));
+                const float4 v = ld4(x + ((n * H + h) * W + w) * C + c4);
+                const uint32_t id = (uint32_t)(dh * 3 + dw);
+                if (v.x > m.x) { m.x = v.x; ix = id; }
+                if (v.y > m.y) { m.y = v.y; iy = id; }
+                if (v.z > m.z) { m.z = v.z; iz = id; }
+                if (v.w > m.w) { m.w = v.w; iw = id; }
             }
         }
         st4(y + i * 4, m);
+        if (idx) idx[i] = ix | (iy << 8) | (iz << 16) | (iw << 24);
     }
 }
 
-__global__ __launch_bounds__(EW_T) void maxpool3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// dx from the saved window positions: an input pixel lies in 1, 2 or 4 windows (ho in {h/2, (h+1)/2}); it receives
+// dy of those whose first maximum it is.  One read of idx (4 B) and dy (16 B) per covering window instead of the nine
+// taps of x: 0.66 ms -> ~0.1 ms on the ResNet stem.
+__global__ __launch_bounds__(EW_T) void maxpool3_bwd_kernel(const uint32_t* __restrict__ idx, const float* __restrict__ dy,
                                                             float* __restrict__ dx, int N, int H, int W, int C, int Ho,
                                                             int Wo) {
     const int cq = C >> 2;
     const long total = (long)N * H * W * cq;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int c4 = (int)(i % cq) * 4;
+        const int cqi = (int)(i % cq);
         long pix = i / cq;
         const int w = (int)(pix % W); pix /= W;
         const int h = (int)(pix % H);
         const long n = pix / H;
         float4 acc = f4(0.f);
-        // windows (ho,wo) with 2*ho-1 <= h <= 2*ho+1
-        for (int ho = (h) >> 1; ho <= (h + 1) >> 1; ++ho) {
-            if (ho < 0 || ho >= Ho) continue;
-            for (int wo = (w) >> 1; wo <= (w + 1) >> 1; ++wo) {
-                if (wo < 0 || wo >= Wo) continue;
-                // first maximum of the window in scan order (torch max_pool2d_with_indices)
-                float mv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                int mi[4] = {-1, -1, -1, -1};
-                for (int dh = 0; dh < 3; ++dh) {
-                    const int hh = 2 * ho - 1 + dh;
-                    if (hh < 0 || hh >= H) continue;
-                    for (int dw = 0; dw < 3; ++dw) {
-                        const int ww = 2 * wo - 1 + dw;
-                        if (ww < 0 || ww >= W) continue;
-                        const float4 v = ld4(x + ((n * H + hh) * W + ww) * C + c4);
-                        const int id = hh * W + ww;
-                        if (v.x > mv[0]) { mv[0] = v.x; mi[0] = id; }
-                        if (v.y > mv[1]) { mv[1] = v.y; mi[1] = id; }
-                        if (v.z > mv[2]) { mv[2] = v.z; mi[2] = id; }
-                        if (v.w > mv[3]) { mv[3] = v.w; mi[3] = id; }
-                    }
-                }
-                const float4 g = ld4(dy + ((n * Ho + ho) * Wo + wo) * C + c4);
-                const int me = h * W + w;
-                acc.x += mi[0] == me ? g.x : 0.f; acc.y += mi[1] == me ? g.y : 0.f;
-                acc.z += mi[2] == me ? g.z : 0.f; acc.w += mi[3] == me ? g.w : 0.f;
+        for (int ho = h >> 1; ho <= (h + 1) >> 1; ++ho) {
+            if (ho >= Ho) continue;
+            const uint32_t dh = (uint32_t)(h - (2 * ho - 1));
+            for (int wo = w >> 1; wo <= (w + 1) >> 1; ++wo) {
+                if (wo >= Wo) continue;
+                const uint32_t me = dh * 3u + (uint32_t)(w - (2 * wo - 1));
+                const long o = ((n * Ho + ho) * Wo + wo) * cq + cqi;
+                const uint32_t id = idx[o];
+                const float4 g = ld4(dy + o * 4);
+                acc.x += (id & 0xffu) == me ? g.x : 0.f;
+                acc.y += ((id >> 8) & 0xffu) == me ? g.y : 0.f;
+                acc.z += ((id >> 16) & 0xffu) == me ? g.z : 0.f;
+                acc.w += (id >> 24) == me ? g.w : 0.f;
             }
         }
         st4(dx + i * 4, acc);
@@ -482,11 +536,6 @@ __global__ __launch_bounds__(EW_T) void reflect_fold_kernel(const float* __restr
 // Parameters, moments and (ZERO_G) the cleared gradient leave with nontemporal stores: 340 MB that nothing reads
 // before the next step's kernels have streamed gigabytes -- left dirty in the caches, the kernel that follows
 // (K1 of the next step) pays for their write-back (measured: 50 -> 87 us, tools/k1_instep_probe.py).
-typedef float adam_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st4_nt(float* p, float4 v) {
-    const adam_f4 w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, reinterpret_cast<adam_f4*>(p));
-}
 
 template <bool ZERO_G>
 __global__ __launch_bounds__(EW_T) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
@@ -541,13 +590,15 @@ extern "C" int pd_bn_fwd_finalize(const void* partial, long R, int C, double cou
         const int cgroups = (C + 31) / 32;
         const int rpb = 256;
         const long rblocks = (R + rpb - 1) / rpb;
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(cgroups * rblocks)), dim3(EW_T), 0, st,
-                           (const float*)partial, (double*)acc_ws, R, C, rpb);
+        hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3((unsigned)(cgroups * rblocks)), dim3(EW_T), 0, st,
+                           (const float*)partial, (double*)acc_ws, R, C, rpb, (const float*)gamma, (const float*)beta,
+                           (float*)running_mean, (float*)running_var, (float*)scale, (float*)shift, (float*)save_mean,
+                           (float*)save_invstd, count, momentum, eps);
+    } else {
+        hipLaunchKernelGGL(bn_fwd_eval_kernel, dim3((C + 127) / 128), dim3(128), 0, st, (const float*)gamma,
+                           (const float*)beta, (float*)running_mean, (float*)running_var, (float*)scale, (float*)shift,
+                           (float*)save_mean, (float*)save_invstd, C, eps);
     }
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, (double*)acc_ws,
-                       (const float*)gamma, (const float*)beta, (float*)running_mean, (float*)running_var,
-                       (float*)scale, (float*)shift, (float*)save_mean, (float*)save_invstd, C, count, momentum, eps,
-                       training);
     return pd::check_launch("pd_bn_fwd_finalize");
 }
 
@@ -558,10 +609,8 @@ extern "C" int pd_bn_bwd_finalize(const void* partial, long R, int C, double cou
     const int cgroups = (C + 31) / 32;
     const int rpb = 256;
     const long rblocks = (R + rpb - 1) / rpb;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(cgroups * rblocks)), dim3(EW_T), 0, st, (const float*)partial,
-                       (double*)acc_ws, R, C, rpb);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, (double*)acc_ws,
-                       (float*)dgamma, (float*)dbeta, (float*)coef, C, count, accumulate);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)(cgroups * rblocks)), dim3(EW_T), 0, st, (const float*)partial,
+                       (double*)acc_ws, R, C, rpb, (float*)dgamma, (float*)dbeta, (float*)coef, count, accumulate);
     return pd::check_launch("pd_bn_bwd_finalize");
 }
 
@@ -652,21 +701,21 @@ extern "C" int pd_chain_bwd_apply(const void* dy, long ld_dy, const void* x, con
     return pd::check_launch("pd_chain_bwd_apply");
 }
 
-extern "C" int pd_maxpool3s2_fwd(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+extern "C" int pd_maxpool3s2_fwd(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream) {
     PD_REQUIRE(x && y && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_maxpool3s2_fwd: bad arguments");
     if (N == 0) return PD_OK;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * (C / 4))), dim3(EW_T), 0,
-                       (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, Ho, Wo);
+                       (hipStream_t)stream, (const float*)x, (float*)y, (uint32_t*)idx, N, H, W, C, Ho, Wo);
     return pd::check_launch("pd_maxpool3s2_fwd");
 }
 
-extern "C" int pd_maxpool3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
-    PD_REQUIRE(x && dy && dx && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_maxpool3s2_bwd: bad arguments");
+extern "C" int pd_maxpool3s2_bwd(const void* idx, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+    PD_REQUIRE(idx && dy && dx && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_maxpool3s2_bwd: bad arguments");
     if (N == 0) return PD_OK;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(EW_T), 0,
-                       (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo);
+                       (hipStream_t)stream, (const uint32_t*)idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo);
     return pd::check_launch("pd_maxpool3s2_bwd");
 }
 

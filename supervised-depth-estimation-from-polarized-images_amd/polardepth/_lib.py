@@ -49,7 +49,7 @@ SIGNATURES = {
                                  _u64, _i, _vp]),
     "pd_chain_bwd_apply": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f,
                                 _u64, _u64, _i, _vp]),
-    "pd_maxpool3s2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_maxpool3s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_maxpool3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_upcat_fwd": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),
     "pd_up_bwd": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp]),

@@ -436,17 +436,22 @@ class MaxPool3s2Fn(torch.autograd.Function):
         x = ops.as_nhwc(x)
         N, C, H, W = x.shape
         y = ops.empty_nhwc(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x.device)
-        check(lib.pd_maxpool3s2_fwd(ptr(x), ptr(y), N, H, W, C, stream_ptr()), "pd_maxpool3s2_fwd")
-        ctx.save_for_backward(x)
+        # the window position of every maximum (one byte per element) replaces x on the tape
+        idx = torch.empty(y.numel(), dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
+        check(lib.pd_maxpool3s2_fwd(ptr(x), ptr(y), ptr(idx), N, H, W, C, stream_ptr()), "pd_maxpool3s2_fwd")
+        ctx.shape = (N, C, H, W)
+        ctx.save_for_backward(idx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        N, C, H, W = x.shape
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
         dy = ops.as_nhwc(dy)
-        dx = torch.empty_like(x)
-        check(lib.pd_maxpool3s2_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, C, stream_ptr()), "pd_maxpool3s2_bwd")
+        if not dy.is_contiguous(memory_format=CL):
+            dy = dy.contiguous(memory_format=CL)
+        dx = ops.empty_nhwc(N, C, H, W, dy.device)
+        check(lib.pd_maxpool3s2_bwd(ptr(idx), ptr(dy), ptr(dx), N, H, W, C, stream_ptr()), "pd_maxpool3s2_bwd")
         return dx
 
 
