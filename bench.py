@@ -253,12 +253,14 @@ def main():
     # HBM traffic per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, gfx950
     # FETCH_SIZE x2 correction) cannot run inside this process -- the committed summary of those passes is quoted
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if os.path.exists(pmc):
-        with open(pmc) as f:
-            dom_pmc = json.load(f).get("dominant", {})
-        if dom_pmc.get("kernel") == dname:
-            traffic, traffic_src = dom_pmc.get("hbm_bytes_per_launch"), "profiles/r01_pmc_hbm_traffic.json"
+    for pmc_name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                dom_pmc = json.load(f).get("dominant", {})
+            if dom_pmc.get("kernel") == dname:
+                traffic, traffic_src = dom_pmc.get("hbm_bytes_per_launch"), "profiles/" + pmc_name
+                break
     roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TF,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,

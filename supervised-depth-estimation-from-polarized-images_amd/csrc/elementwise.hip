@@ -210,11 +210,14 @@ __global__ __launch_bounds__(EW_T) void chain_fwd_kernel(const ChainArgs a) {
     const unsigned cq = a.C >> 2;
     const unsigned Ho = a.pool ? a.H >> 1 : a.H, Wo = a.pool ? a.W >> 1 : a.W;
     const unsigned total = (unsigned)a.N * Ho * Wo * cq;
-    for (unsigned i = blockIdx.x * (unsigned)EW_T + threadIdx.x; i < total; i += gridDim.x * (unsigned)EW_T) {
+    // 256 % cq == 0 (checked on the host): a thread keeps its channel quad across the loop, so the per-channel
+    // coefficients are loaded once instead of twice per element
+    const unsigned i0 = blockIdx.x * (unsigned)EW_T + threadIdx.x;
+    const int c4 = (int)(i0 % cq) * 4;
+    const float4 s = a.scale ? ld4(a.scale + c4) : f4(1.f);
+    const float4 b = a.scale ? ld4(a.shift + c4) : f4(0.f);
+    for (unsigned i = i0; i < total; i += gridDim.x * (unsigned)EW_T) {
         const unsigned pix = i / cq;                // output pixel index
-        const int c4 = (int)(i - pix * cq) * 4;
-        const float4 s = a.scale ? ld4(a.scale + c4) : f4(1.f);
-        const float4 b = a.scale ? ld4(a.shift + c4) : f4(0.f);
         float4 v;
         if (a.pool) {
             const unsigned t = pix / Wo;
@@ -281,30 +284,30 @@ __global__ __launch_bounds__(EW_T) void chain_bwd_kernel(const ChainArgs a) {
     const unsigned cq = a.C >> 2;
     const unsigned total = (unsigned)a.N * a.H * a.W * cq;
     float4 sg = f4(0.f), sgx = f4(0.f);
-    // 256 % cq == 0 (checked on the host): every thread keeps its channel quad across the loop
-    for (unsigned i = blockIdx.x * (unsigned)EW_T + threadIdx.x; i < total; i += gridDim.x * (unsigned)EW_T) {
+    // 256 % cq == 0 (checked on the host): every thread keeps its channel quad across the loop -- the six per-channel
+    // coefficient vectors are loaded once, not once per element
+    const unsigned i0 = blockIdx.x * (unsigned)EW_T + threadIdx.x;
+    const int c4 = (int)(i0 % cq) * 4;
+    const float4 s = a.scale ? ld4(a.scale + c4) : f4(1.f);
+    const float4 b = a.scale ? ld4(a.shift + c4) : f4(0.f);
+    const float4 m = a.mean ? ld4(a.mean + c4) : f4(0.f), is = a.mean ? ld4(a.invstd + c4) : f4(0.f);
+    const float4 c1 = (APPLY && a.mean) ? ld4(a.coef + c4) : f4(0.f), c2 = (APPLY && a.mean) ? ld4(a.coef + a.C + c4) : f4(0.f);
+    for (unsigned i = i0; i < total; i += gridDim.x * (unsigned)EW_T) {
         const unsigned pix = i / cq;
-        const int c4 = (int)(i - pix * cq) * 4;
         const unsigned t = pix / a.W;
         const unsigned w = pix - t * a.W;
         const unsigned n = t / a.H;
         const unsigned h = t - n * a.H;
-        const float4 s = a.scale ? ld4(a.scale + c4) : f4(1.f);
-        const float4 b = a.scale ? ld4(a.shift + c4) : f4(0.f);
         const float4 xv = ld4(a.x + (size_t)pix * a.C + c4);
         const float4 g = chain_grad(a, n, h, w, c4, xv, s, b);
         float4 xh = f4(0.f);
-        if (a.mean) {
-            const float4 m = ld4(a.mean + c4), is = ld4(a.invstd + c4);
-            xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
-        }
+        if (a.mean) xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
         if (!APPLY) {
             sg = add4(sg, g);
             sgx = add4(sgx, mul4(g, xh));
         } else {
             float4 d;
             if (a.mean) {
-                const float4 c1 = ld4(a.coef + c4), c2 = ld4(a.coef + a.C + c4);
                 d = make_float4(s.x * (g.x - c1.x - xh.x * c2.x), s.y * (g.y - c1.y - xh.y * c2.y),
                                 s.z * (g.z - c1.z - xh.z * c2.z), s.w * (g.w - c1.w - xh.w * c2.w));
             } else {
@@ -617,6 +620,7 @@ extern "C" int pd_bn_bwd_finalize(const void* partial, long R, int C, double cou
 static int chain_check(int N, int H, int W, int C, int pool) {
     PD_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_chain: bad dims (C must be a multiple of 4)");
     PD_REQUIRE(!pool || (H >= 2 && W >= 2), "pd_chain: pooling needs H,W >= 2");
+    PD_REQUIRE(EW_T % (C / 4) == 0, "pd_chain: C/4 must divide %d (a thread keeps its channel quad across the loop)", EW_T);
     PD_REQUIRE((long)N * H * W * (C / 4) < (1L << 31) - (1L << 22), "pd_chain: tensor too large for 32-bit element indices");
     return PD_OK;
 }

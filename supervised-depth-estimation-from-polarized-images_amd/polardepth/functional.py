@@ -175,7 +175,9 @@ class ConvBNChainFn(torch.autograd.Function):
         s2d = (USE_S2D_STEMS and weight.shape[2] == 7 and weight.shape[3] == 7 and cfg.stride == 2 and cfg.pad == 3
                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
         ctx.s2d = s2d
+        alg_k = None
         if s2d:
+            alg_k = 49 * x.shape[1]                               # FLOPs are counted for the 7x7 filter, not the padded 4x4x4C
             x = ops.s2d_input(x, cfg.affine)                      # saved for the weight gradient
             w_eff, stride, pad, aff = ops.s2d_weight(weight), 1, 2, None
             out_hw = (x.shape[2], x.shape[3])
@@ -184,9 +186,9 @@ class ConvBNChainFn(torch.autograd.Function):
         if getattr(cfg, "infer", False):
             return ConvBNChainFn._inference(x, w_eff, bias, gamma, beta, res, cfg, stride, pad, aff, out_hw)
         if training:
-            z, part = ops.conv2d_fwd(x, w_eff, bias, stride, pad, want_stats=True, affine=aff, out_hw=out_hw)
+            z, part = ops.conv2d_fwd(x, w_eff, bias, stride, pad, want_stats=True, affine=aff, out_hw=out_hw, alg_k=alg_k)
         else:
-            z, part = ops.conv2d_fwd(x, w_eff, bias, stride, pad, affine=aff, out_hw=out_hw), None
+            z, part = ops.conv2d_fwd(x, w_eff, bias, stride, pad, affine=aff, out_hw=out_hw, alg_k=alg_k), None
         _, _, Hz, Wz = z.shape
         scale, shift, mean, invstd = _f32(dev, Co), _f32(dev, Co), _f32(dev, Co), _f32(dev, Co)
         acc = _bn_acc(dev, Co) if training else None
@@ -272,7 +274,7 @@ class ConvBNChainFn(torch.autograd.Function):
             gw = grad_buf(weight)
             if ctx.s2d:
                 def _stem_wgrad():
-                    dw2 = ops.conv2d_wgrad(x, dz, (Co, x.shape[1], 4, 4), 1, 2)
+                    dw2 = ops.conv2d_wgrad(x, dz, (Co, x.shape[1], 4, 4), 1, 2, alg_k=49 * (x.shape[1] // 4))
                     ops.s2d_weight_grad(dw2, gw, accumulate=True)
                 _wgrad_async(x, dz, _stem_wgrad)
             else:

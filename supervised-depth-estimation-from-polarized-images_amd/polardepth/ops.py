@@ -60,7 +60,7 @@ def conv_out_size(h, k, s, p):
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, want_stats=False,
-               affine=None, out=None, out_hw=None, out_scale=None):
+               affine=None, out=None, out_hw=None, out_scale=None, alg_k=None):
     """y = act(conv(x, w) [* out_scale] + bias).  x: [N,C,H,W] any strides; returns channels_last [N,Co,Ho,Wo].
 
     out_scale: optional fp32 [Co] multiplier of the accumulator (an inference-mode BatchNorm folded into the epilogue).
@@ -69,6 +69,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     of the pre-activation output).  affine=(sub, div) applies (x-sub)/div to in-bounds input taps.
     out: optional pre-allocated NHWC tensor whose channel slice [:, c0:c0+Co] receives the result
     (pass the sliced view; its channel stride must be 1).
+    alg_k: algorithmic contraction length for the profiler's FLOP count when it differs from C*KH*KW (the
+    space-to-depth stems execute K = 64*C for an algorithmic 7x7 filter: 49*C).
     """
     _require_cuda(x, w, bias, out_scale)
     N, C, H, W = x.shape
@@ -91,7 +93,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     sub, div = (affine if affine is not None else (0.0, 1.0))
     sN, sC, sH, sW = x.stride()
     vec = C % 4 == 0 and sC == 1 and affine is None
-    _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd"), 2.0 * N * Ho * Wo * Co * C * KH * KW,
+    _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd"), 2.0 * N * Ho * Wo * Co * (alg_k if alg_k is not None else C * KH * KW),
               lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out_scale), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
                                           Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub,
                                           div, ldy, stream_ptr()), "pd_conv2d"),
@@ -144,7 +146,7 @@ def _workspace(nbytes, device):
 
 
 def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, dw=None, dbias=None,
-                 want_bias=False, accumulate=False):
+                 want_bias=False, accumulate=False, alg_k=None):
     """dW (channels_last [Co,Ci,kh,kw]) and optionally dbias of conv(x, w) given dy (NHWC)."""
     _require_cuda(x, dy)
     dy = as_nhwc(dy)
@@ -163,7 +165,7 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
     ws = _workspace(nbytes, x.device)
     sub, div = (affine if affine is not None else (0.0, 1.0))
     sN, sC, sH, sW = x.stride()
-    _profiled("conv_wgrad_kernel", 2.0 * M * Co * K,
+    _profiled("conv_wgrad_kernel", 2.0 * M * Co * (alg_k if alg_k is not None else K),
               lambda: check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), N, H, W, C,
                                                 sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride, pad, mode,
                                                 int(affine is not None), sub, div, dy.stride(3), int(accumulate),

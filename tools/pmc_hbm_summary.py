@@ -17,7 +17,7 @@ import sys
 
 def short(name):
     name = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
-    m = re.match(r"conv_igemm_kernel<(\d+), (\d+), \d+, \d+, (true|false), \d+>", name)
+    m = re.match(r"conv_igemm_kernel<(\d+), (\d+), \d+, \d+, (true|false), \d+(?:, (?:true|false))?>", name)
     if m:
         return f"conv_igemm_kernel<{m.group(1)},{m.group(2)},{'vec' if m.group(3) == 'true' else 'scalar'}>"
     return name.split("(")[0]
