@@ -292,6 +292,62 @@ __global__ __launch_bounds__(EW_T) void chain_bwd_kernel(const ChainArgs a) {
     const float4 b = a.scale ? ld4(a.shift + c4) : f4(0.f);
     const float4 m = a.mean ? ld4(a.mean + c4) : f4(0.f), is = a.mean ? ld4(a.invstd + c4) : f4(0.f);
     const float4 c1 = (APPLY && a.mean) ? ld4(a.coef + c4) : f4(0.f), c2 = (APPLY && a.mean) ? ld4(a.coef + a.C + c4) : f4(0.f);
+    if (a.pool && !(a.H & 1) && !(a.W & 1)) {
+        // pooled layers, even grid: one thread per 2x2 WINDOW -- four loads of z and one of dy serve four input
+        // pixels (per input pixel the window would be re-read four times: 2.1 / 3.5 TB/s instead of ~5)
+        const unsigned Ho = a.H >> 1, Wo = a.W >> 1;
+        const unsigned wtotal = (unsigned)a.N * Ho * Wo * cq;
+        for (unsigned i = i0; i < wtotal; i += gridDim.x * (unsigned)EW_T) {
+            const unsigned opix = i / cq;
+            const unsigned t = opix / Wo;
+            const unsigned wo = opix - t * Wo;
+            const unsigned n = t / Ho;
+            const unsigned ho = t - n * Ho;
+            const size_t p00 = (((size_t)n * a.H + 2 * ho) * a.W + 2 * wo) * a.C + c4;
+            const size_t offs[4] = {p00, p00 + a.C, p00 + (size_t)a.W * a.C, p00 + (size_t)a.W * a.C + a.C};
+            float4 xv[4], v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xv[j] = ld4(a.x + offs[j]);
+                v[j] = affine4(xv[j], s, b);
+                if (a.relu_pre) v[j] = relu4(v[j]);
+            }
+            float4 g = ld4(a.dy + (size_t)opix * a.ld_dy + c4);
+            if (a.relu_post) {
+                const float4 o = ld4(a.out + (size_t)opix * a.ld_out + c4);
+                g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+            }
+            if (a.drop_p > 0.f) g = mul4(g, dropout_scale(i, a.seed, a.offset, a.drop_p));
+            // first maximum of the window in scan order, like torch max_pool2d
+            int ax = 0, ay = 0, az = 0, aw = 0;
+            float mx = v[0].x, my = v[0].y, mz = v[0].z, mw = v[0].w;
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                if (v[j].x > mx) { mx = v[j].x; ax = j; }
+                if (v[j].y > my) { my = v[j].y; ay = j; }
+                if (v[j].z > mz) { mz = v[j].z; az = j; }
+                if (v[j].w > mw) { mw = v[j].w; aw = j; }
+            }
+            if (a.relu_pre)      // the pooled value passes the gradient only where the pre-pool ReLU was open
+                g = make_float4(mx > 0.f ? g.x : 0.f, my > 0.f ? g.y : 0.f, mz > 0.f ? g.z : 0.f, mw > 0.f ? g.w : 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 gj = make_float4(ax == j ? g.x : 0.f, ay == j ? g.y : 0.f, az == j ? g.z : 0.f, aw == j ? g.w : 0.f);
+                float4 xh = f4(0.f);
+                if (a.mean) xh = make_float4((xv[j].x - m.x) * is.x, (xv[j].y - m.y) * is.y, (xv[j].z - m.z) * is.z, (xv[j].w - m.w) * is.w);
+                if (!APPLY) {
+                    sg = add4(sg, gj);
+                    sgx = add4(sgx, mul4(gj, xh));
+                } else {
+                    float4 d;
+                    if (a.mean) d = make_float4(s.x * (gj.x - c1.x - xh.x * c2.x), s.y * (gj.y - c1.y - xh.y * c2.y),
+                                                s.z * (gj.z - c1.z - xh.z * c2.z), s.w * (gj.w - c1.w - xh.w * c2.w));
+                    else d = mul4(gj, s);
+                    st4_nt(a.dx + offs[j], d);
+                }
+            }
+        }
+    } else
     for (unsigned i = i0; i < total; i += gridDim.x * (unsigned)EW_T) {
         const unsigned pix = i / cq;
         const unsigned t = pix / a.W;
