@@ -56,6 +56,10 @@ struct ConvArgs {
     int mtiles, ntiles;
     int sshift;              // log2(stride) (transposed mode: stride is a power of two)
     unsigned w_bytes;
+    unsigned mg_hw, sh_hw, mg_wo, sh_wo;   // n / (Ho*Wo) and n / Wo as mulhi + shift (n < 2^31), see magic_div()
+#ifdef PD_CONV_ABLATE
+    int abl;
+#endif
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -108,6 +112,135 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, const void* lds_
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Epilogue shared by the implicit-GEMM kernels: bias / folded-BN scale, activation, per-tile BatchNorm partial sums,
+// NHWC store.  C/D layout of the MFMA: col = lane % MT; 32x32: row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
+// 16x16: row = r + 4*(lane>>4), r < 4.
+template <int BM, int BN, int WM, int WN, int MT, typename AccT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[WM / MT][WN / MT], float* scratch, int mt,
+                                              long m0, int n0, int wm, int wn, int lane, int wave, int tid) {
+    constexpr int TM = WM / MT, TN = WN / MT, ACCN = MT == 32 ? 16 : 4, WAVES_N = BN / WN;
+    float (*red)[WN][2] = reinterpret_cast<float (*)[WN][2]>(scratch);
+    if constexpr (MT == 32 && WN == 32) {
+        // Full tile, no bias / scale / activation (every BatchNorm-followed convolution and every data gradient): the
+        // wave transposes its WM x 32 block through LDS (the A/B tiles are dead by now) and leaves with WM/8
+        // buffer_store_dwordx4 of eight full 128-byte lines each instead of WM/2 dword stores, and the per-element
+        // work shrinks to the two statistics updates -- on this chip every VALU instruction is taken from the
+        // matrix pipe of the other workgroups on the SIMD (tools/mfma_peak.hip).
+        const bool lean = a.M - m0 >= BM && n0 + BN <= a.Co && !a.bias && !a.oscale && a.act == ACT_NONE &&
+                          (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0;
+        if (lean) {
+            float* T = scratch + wave * (WM * WN);                 // [WM][32] floats, private to the wave
+            red = reinterpret_cast<float (*)[WN][2]>(scratch + 4 * WM * WN);
+            const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][0][r];
+                    T[(MT * i + (r & 3) + 8 * (r >> 2) + rbase) * WN + col_l] = v;
+                    s1 += v;
+                    s2 = __builtin_fmaf(v, v, s2);
+                }
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)BM * a.ldy * 4));
+            const unsigned off_l = (unsigned)((wm * WM + (lane >> 3)) * (int)a.ldy + n0 + wn * WN + 4 * (lane & 7)) * 4u;
+            const float4* Tq = reinterpret_cast<const float4*>(T) + lane;      // row lane/8, column quad lane%8
+#pragma unroll
+            for (int t = 0; t < WM / 8; ++t) {
+                const float4 v = Tq[t * 64];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, off_l, t * 8 * (int)a.ldy * 4, 0);
+            }
+            if (a.stats) {
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (lane < 32) { red[wave][col_l][0] = s1; red[wave][col_l][1] = s2; }
+                __syncthreads();
+                if (tid < BN) {
+                    const int w_n = tid / WN, cl = tid - w_n * WN;
+                    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int w_m = 0; w_m < BM / WM; ++w_m) {
+                        t1 += red[w_m * WAVES_N + w_n][cl][0];
+                        t2 += red[w_m * WAVES_N + w_n][cl][1];
+                    }
+                    float* o = a.stats + ((long)mt * a.Co + n0 + tid) * 2;
+                    o[0] = t1; o[1] = t2;
+                }
+            }
+            return;
+        }
+    }
+    // ---- epilogue: C/D layout of the MFMA: col = lane % MT; 32x32: row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
+    // 16x16: row = r + 4*(lane>>4), r < 4.
+    // Straight-line code: the activation is a template argument, the row step of every store is a scalar offset
+    // and out-of-range elements are dropped by the bounds check of the buffer store (offset OOB), so the stores
+    // of a wave issue back to back (with per-element branches the compiler drained vmcnt to zero after each one).
+    const int col_l = lane % MT;
+    const int rbase = 4 * (lane / MT);
+    {
+        const long rows_left = a.M - m0;
+        const int rows = rows_left < BM ? (int)rows_left : BM;
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)rows * a.ldy * 4));
+        const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(a.bias ? a.bias : a.w, a.bias ? (unsigned)a.Co * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(a.oscale ? a.oscale : a.w, a.oscale ? (unsigned)a.Co * 4u : 0u);
+        auto body = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WN + MT * j + col_l;
+                const bool cv = col < a.Co;
+                const float bv = a.bias ? buf_ld1(rb_, cv ? (unsigned)col * 4u : OOB) : 0.f;
+                const float sv = a.oscale ? buf_ld1(rs_, cv ? (unsigned)col * 4u : OOB) : 1.f;
+                float s1 = 0.f, s2 = 0.f;
+                const int row_l = wm * WM + rbase;                      // this lane's first row in the tile
+                const unsigned off_l = (unsigned)(row_l * (int)a.ldy + col) * 4u;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < ACCN; ++r) {
+                        const int rr = MT * i + (MT == 32 ? (r & 3) + 8 * (r >> 2) : r);   // compile-time row step: scalar offset
+                        const bool ok = cv & (row_l < rows - rr);
+                        float v = fmaf(acc[i][j][r], sv, bv);    // sv == 1: exactly acc + bv
+                        const float vs = ok ? v : 0.f;
+                        s1 += vs;
+                        s2 += vs * vs;
+                        if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (ACT == ACT_ELU) v = v > 0.f ? v : expm1f(v);
+                        else if (ACT == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ok ? off_l : OOB,
+                                                              rr * (int)a.ldy * 4, 0);
+                    }
+                }
+                if (a.stats) {
+#pragma unroll
+                    for (int m = MT; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+                    if (lane < MT) { red[wave][MT * j + col_l][0] = s1; red[wave][MT * j + col_l][1] = s2; }
+                }
+            }
+        };
+        if (a.act == ACT_NONE) body(std::integral_constant<int, ACT_NONE>{});
+        else if (a.act == ACT_RELU) body(std::integral_constant<int, ACT_RELU>{});
+        else if (a.act == ACT_ELU) body(std::integral_constant<int, ACT_ELU>{});
+        else body(std::integral_constant<int, ACT_SIGMOID>{});
+    }
+    if (a.stats) {
+        __syncthreads();
+        if (tid < BN) {   // column tid of the block tile: sum over the waves that own it
+            const int w_n = tid / WN, cl = tid - w_n * WN;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w_m = 0; w_m < BM / WM; ++w_m) {
+                t1 += red[w_m * WAVES_N + w_n][cl][0];
+                t2 += red[w_m * WAVES_N + w_n][cl][1];
+            }
+            const int col = n0 + tid;
+            if (col < a.Co) {
+                float* o = a.stats + ((long)mt * a.Co + col) * 2;
+                o[0] = t1; o[1] = t2;
+            }
+        }
+    }
+}
+
 // DMA (vector path only): the A and B chunks go global -> LDS directly (buffer_load_dwordx4 ... lds: 1 KiB = eight
 // 128-byte tile rows per wave instruction, lane l -> row l/8, physical slot l%8), no staging registers and no
 // ds_write pass.  The LDS image stays the XOR-swizzled one the fragment reads expect: a thread loads the LOGICAL
@@ -133,7 +266,6 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
     float (*As)[BM][LDT] = reinterpret_cast<float (*)[BM][LDT]>(smem_all);
     float (*Bs)[BN][LDT] = reinterpret_cast<float (*)[BN][LDT]>(smem_all + 2 * BM * LDT);
     int (*rowinfo)[3] = reinterpret_cast<int (*)[3]>(smem_all + 2 * BM * LDT + 2 * BN * LDT);   // scalar path: element offset of the image (or -1), rh, rw
-    float (*red)[WN][2] = reinterpret_cast<float (*)[WN][2]>(&As[0][0][0]);   // epilogue scratch, aliases As
 
     // XCD-aware mapping: consecutive logical tiles (which share input halos / the A tile) land
     // on the same XCD and hence the same L2.  Grid is padded to a multiple of 8.
@@ -332,76 +464,228 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the MFMA: col = lane % MT; 32x32: row = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16;
-    // 16x16: row = r + 4*(lane>>4), r < 4.
-    // Straight-line code: the activation is a template argument, the row step of every store is a scalar offset
-    // and out-of-range elements are dropped by the bounds check of the buffer store (offset OOB), so the stores
-    // of a wave issue back to back (with per-element branches the compiler drained vmcnt to zero after each one).
-    const int col_l = lane % MT;
-    const int rbase = 4 * (lane / MT);
-    {
-        const long rows_left = a.M - m0;
-        const int rows = rows_left < BM ? (int)rows_left : BM;
-        const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)rows * a.ldy * 4));
-        const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(a.bias ? a.bias : a.w, a.bias ? (unsigned)a.Co * 4u : 0u);
-        const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(a.oscale ? a.oscale : a.w, a.oscale ? (unsigned)a.Co * 4u : 0u);
-        auto body = [&](auto act_tag) {
-            constexpr int ACT = decltype(act_tag)::value;
+    conv_epilogue<BM, BN, WM, WN, MT>(a, acc, &As[0][0][0], mt, m0, n0, wm, wn, lane, wave, tid);
+}
+
+// ===================================================================== uniform-tap variant
+// On gfx950 the fp32 MFMA runs on the SIMD's fp32 FMA lanes: tools/mfma_peak.hip shows that LDS reads, LDS-DMA issues,
+// barriers and scalar instructions beside a stream of v_mfma_f32_32x32x2_f32 cost nothing (98-99 % of 157.3 TF at
+// 2-3 waves per SIMD), while every VALU instruction takes ~4.5 cycles away from the matrix pipe whichever wave
+// issues it (30 VALU per 8 MFMAs: 77 %).  The general kernel above spends ~100 VALU instructions per K-chunk on
+// gather addresses (bounds tests, tap bookkeeping, LDS destination, fragment addresses) against 32 MFMAs -- its 81 %.
+// This variant serves the layers that carry the step (16-byte path, C % 32 == 0, zero padding or the stride-1 data
+// gradient): a K-chunk of 32 then lies inside ONE filter tap for the whole workgroup, so
+//   * tap bookkeeping and the tap's byte offset live in SGPRs and enter the load as its scalar offset,
+//   * a row's validity for every tap is one bit of a mask built once per tile (bit kh*KW+kw set = outside the image);
+//     an invalid piece gets bit 31 of its offset set (beyond the descriptor -> the hardware returns zeros),
+//   * the descriptor's base is moved back by the padding, so row offsets and tap offsets are both non-negative,
+//   * LDS destinations (M0) are scalar, fragment addresses are eight loop-invariant registers + immediate offsets
+//     (the loop is unrolled over the two LDS buffers).
+// Per K-chunk: 32 MFMAs, 12 ds_read_b128, 6 LDS-DMA issues and 2 VALU per A piece (v_bfe_u32 + v_lshl_add_u32).
+__device__ __forceinline__ unsigned magic_div(unsigned n, unsigned mg, unsigned sh) {
+    return mg ? __umulhi(n, mg) >> sh : n;     // mg == 0: divisor 1
+}
+
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, unsigned m0v, unsigned voff, unsigned soff) {
+    // s_nop 4: the scalar offset may have been written by the SALU instruction right in front (5 wait states to a
+    // VMEM read of it); s_nop 0: M0 write -> LDS-DMA
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(m0v), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
+    static_assert(MODE == MODE_ZERO || MODE == MODE_TRANSPOSED, "uniform-tap kernel: zero padding or stride-1 data gradient");
+    constexpr int MT = 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / MT, TN = WN / MT;
+    static_assert((BM / WM) * WAVES_N == 4 && BN % 32 == 0, "4 waves per workgroup");
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr unsigned A_BYTES = BM * LDT * 4, B_BYTES = BN * LDT * 4;
+
+    __shared__ __attribute__((aligned(16))) float smem_all[2 * BM * LDT + 2 * BN * LDT];
+
+    const int nblk = a.mtiles * a.ntiles;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (logical >= nblk) return;
+    const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int hw = a.Ho * a.Wo;
+
+    // Descriptor of the activation: first image of the tile, moved back by the padding (zero mode) or by the part of
+    // the filter extent the padding does not cover (data gradient, taps walk backwards) -- see the offsets below.
+    const int img0 = (int)(m0 / hw);
+    const long shift = MODE == MODE_ZERO ? (long)a.pad * (a.sH + a.sW)
+                                         : (long)(a.KH - 1 - a.pad) * a.sH + (long)(a.KW - 1 - a.pad) * a.sW;
+    const long rest = (((long)a.N - img0) * a.sN + shift) * 4;
+#ifdef PD_CONV_ABLATE
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, (a.abl & (2 | 64)) ? 0u : (rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest));
+    const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, (a.abl & (2 | 128)) ? 0u : a.w_bytes);
+#else
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
+    const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, a.w_bytes);
+#endif
+
+    // ---- per-thread gather state (loop invariant)
+    const int prow = tid >> 3;                                   // row of this thread inside every 32-row piece
+    const unsigned col4 = 16u * ((tid & 7) ^ ((prow >> 1) & 7)); // byte offset of its LOGICAL 16-byte slot (swizzle at the source)
+    const unsigned ones_kw = (1u << a.KW) - 1u;
+    unsigned va[A_IT], inv[A_IT], vb[B_IT];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * WN + MT * j + col_l;
-                const bool cv = col < a.Co;
-                const float bv = a.bias ? buf_ld1(rb_, cv ? (unsigned)col * 4u : OOB) : 0.f;
-                const float sv = a.oscale ? buf_ld1(rs_, cv ? (unsigned)col * 4u : OOB) : 1.f;
-                float s1 = 0.f, s2 = 0.f;
-                const int row_l = wm * WM + rbase;                      // this lane's first row in the tile
-                const unsigned off_l = (unsigned)(row_l * (int)a.ldy + col) * 4u;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int r = 0; r < ACCN; ++r) {
-                        const int rr = MT * i + (MT == 32 ? (r & 3) + 8 * (r >> 2) : r);   // compile-time row step: scalar offset
-                        const bool ok = cv & (row_l < rows - rr);
-                        float v = fmaf(acc[i][j][r], sv, bv);    // sv == 1: exactly acc + bv
-                        const float vs = ok ? v : 0.f;
-                        s1 += vs;
-                        s2 += vs * vs;
-                        if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (ACT == ACT_ELU) v = v > 0.f ? v : expm1f(v);
-                        else if (ACT == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ok ? off_l : OOB,
-                                                              rr * (int)a.ldy * 4, 0);
-                    }
-                }
-                if (a.stats) {
-#pragma unroll
-                    for (int m = MT; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
-                    if (lane < MT) { red[wave][MT * j + col_l][0] = s1; red[wave][MT * j + col_l][1] = s2; }
-                }
-            }
-        };
-        if (a.act == ACT_NONE) body(std::integral_constant<int, ACT_NONE>{});
-        else if (a.act == ACT_RELU) body(std::integral_constant<int, ACT_RELU>{});
-        else if (a.act == ACT_ELU) body(std::integral_constant<int, ACT_ELU>{});
-        else body(std::integral_constant<int, ACT_SIGMOID>{});
-    }
-    if (a.stats) {
-        __syncthreads();
-        if (tid < BN) {   // column tid of the block tile: sum over the waves that own it
-            const int w_n = tid / WN, cl = tid - w_n * WN;
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int w_m = 0; w_m < BM / WM; ++w_m) {
-                t1 += red[w_m * WAVES_N + w_n][cl][0];
-                t2 += red[w_m * WAVES_N + w_n][cl][1];
-            }
-            const int col = n0 + tid;
-            if (col < a.Co) {
-                float* o = a.stats + ((long)mt * a.Co + col) * 2;
-                o[0] = t1; o[1] = t2;
-            }
+    for (int i = 0; i < A_IT; ++i) {
+        const long m = m0 + prow + 32 * i;
+        const unsigned mr = (unsigned)(m - (long)img0 * hw);
+        const unsigned dn = magic_div(mr, a.mg_hw, a.sh_hw);
+        const unsigned rem = mr - dn * (unsigned)hw;
+        const int oh = (int)magic_div(rem, a.mg_wo, a.sh_wo);
+        const int ow = (int)rem - oh * a.Wo;
+        va[i] = (unsigned)((int)dn * (int)a.sN + oh * a.stride * (int)a.sH + ow * a.stride * (int)a.sW) * 4u + col4;
+        // taps outside the image, per dimension: a prefix [0, lo) and a suffix [hi, K) of the tap range
+        int lo_h, hi_h, lo_w, hi_w;
+        if (MODE == MODE_ZERO) {            // ih = oh*stride - pad + kh
+            lo_h = a.pad - oh * a.stride; hi_h = a.H + lo_h;
+            lo_w = a.pad - ow * a.stride; hi_w = a.W + lo_w;
+        } else {                            // ih = oh + pad - kh
+            hi_h = oh + a.pad + 1; lo_h = hi_h - a.H;
+            hi_w = ow + a.pad + 1; lo_w = hi_w - a.W;
         }
+        lo_h = min(max(lo_h, 0), a.KH); hi_h = min(max(hi_h, 0), a.KH);
+        lo_w = min(max(lo_w, 0), a.KW); hi_w = min(max(hi_w, 0), a.KW);
+        const unsigned bad_h = ((1u << lo_h) - 1u) | ~((1u << hi_h) - 1u);     // bit kh (bits >= KH are never read)
+        const unsigned bad_w = (((1u << lo_w) - 1u) | ~((1u << hi_w) - 1u)) & ones_kw;
+        unsigned mask = 0;
+        for (int kh = a.KH - 1; kh >= 0; --kh)
+            mask = (mask << a.KW) | (((bad_h >> kh) & 1u) ? ones_kw : bad_w);
+        inv[i] = m < a.M ? mask : 0xffffffffu;
     }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int nr = n0 + prow + 32 * i;
+        vb[i] = nr < a.Co ? (unsigned)(nr * a.K) * 4u + col4 : OOB;
+    }
+
+    // ---- scalar tap state: tap index, channel offset inside the tap, byte offset of (tap, channel chunk)
+    const int dW4 = (MODE == MODE_ZERO ? (int)a.sW : -(int)a.sW) * 4, dH4 = (MODE == MODE_ZERO ? (int)a.sH : -(int)a.sH) * 4;
+    int s_tap = 0, s_kw = 0, s_c = 0;
+    unsigned s_aoff = MODE == MODE_ZERO ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
+    unsigned s_boff = 0;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
+    const unsigned m0_a = lds0 + 1024u * (unsigned)wave, m0_b = lds0 + 2 * A_BYTES + 1024u * (unsigned)wave;
+
+    auto load_chunk = [&](auto dst_tag) {
+        constexpr unsigned DST = decltype(dst_tag)::value;
+#ifdef PD_CONV_ABLATE
+        if (!(a.abl & 1)) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const unsigned bad = (a.abl & 8) ? 0u : __builtin_amdgcn_ubfe(inv[i], (unsigned)s_tap, 1u);
+            dma16s(rx, m0_a + DST * A_BYTES + 4096u * i, (bad << 31) + va[i], s_aoff);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) dma16s(rw_, m0_b + DST * B_BYTES + 4096u * i, vb[i], s_boff);
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const unsigned bad = __builtin_amdgcn_ubfe(inv[i], (unsigned)s_tap, 1u);
+            dma16s(rx, m0_a + DST * A_BYTES + 4096u * i, (bad << 31) + va[i], s_aoff);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) dma16s(rw_, m0_b + DST * B_BYTES + 4096u * i, vb[i], s_boff);
+#endif
+        s_boff += BK * 4; s_aoff += BK * 4; s_c += BK;
+        if (s_c == a.C) {
+            s_c = 0; ++s_tap; s_aoff += (unsigned)(dW4 - a.C * 4);
+            if (++s_kw == a.KW) { s_kw = 0; s_aoff += (unsigned)(dH4 - a.KW * dW4); }
+        }
+    };
+
+    // ---- fragment addresses: lane -> (row = lane % 32, slot group = lane / 32); the swizzle (row>>1)&7 is the same
+    // for rows 32 apart, so the tiles of a wave differ by immediate offsets only
+    const int frow = lane & 31, fh = lane >> 5;
+    unsigned fa_off[4], fb_off[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const unsigned sw = 16u * ((2 * g + fh) ^ ((frow >> 1) & 7));
+        fa_off[g] = (unsigned)(wm * WM + frow) * (LDT * 4) + sw;
+        fb_off[g] = 2 * A_BYTES + (unsigned)(wn * WN + frow) * (LDT * 4) + sw;
+        asm volatile("" : "+v"(fa_off[g]), "+v"(fb_off[g]));     // keep them as registers (no re-derivation per chunk)
+    }
+    const char* lds_c = reinterpret_cast<const char*>(smem_all);
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](auto buf_tag) {
+        constexpr unsigned BUF = decltype(buf_tag)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const float4*>(lds_c + fa_off[g] + (BUF * A_BYTES + (unsigned)i * MT * LDT * 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const float4*>(lds_c + fb_off[g] + (BUF * B_BYTES + (unsigned)j * MT * LDT * 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    const std::integral_constant<unsigned, 0> B0{};
+    const std::integral_constant<unsigned, 1> B1{};
+
+    const int nchunks = a.K / BK;          // K % 32 == 0 on this path
+    load_chunk(B0);
+    dma_wait();
+    __syncthreads();
+    int q = 0;
+#ifdef PD_CONV_ABLATE
+#define PD_SYNC() do { if (!(a.abl & 4)) { dma_wait(); __syncthreads(); } } while (0)
+#else
+#define PD_SYNC() do { dma_wait(); __syncthreads(); } while (0)
+#endif
+    for (; q + 1 < nchunks; q += 2) {
+        load_chunk(B1);
+        compute(B0);
+        PD_SYNC();
+        if (q + 2 < nchunks) load_chunk(B0);
+        compute(B1);
+        PD_SYNC();
+    }
+#undef PD_SYNC
+    if (q < nchunks) {
+        compute(B0);
+        __syncthreads();                   // the epilogue scratch aliases the A tiles
+    }
+#ifdef PD_CONV_ABLATE
+    if (a.abl & 32) {
+        float sacc = 0.f;
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 1234.5f) a.y[0] = sacc;
+        return;
+    }
+#endif
+    conv_epilogue<BM, BN, WM, WN, MT>(a, acc, smem_all, mt, m0, n0, wm, wn, lane, wave, tid);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -413,6 +697,16 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
 #define PD_LAUNCH(V, MD) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, V, MD>), grid, block, 0, st, a)
 #define PD_LAUNCH_DMA(MD) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, MD, true>), grid, block, 0, st, a)
     static const bool dma = !(getenv("PD_CONV_DMA") && getenv("PD_CONV_DMA")[0] == '0');   // direct-to-LDS staging (default on)
+    static const bool uni_on = !(getenv("PD_CONV_UNI") && getenv("PD_CONV_UNI")[0] == '0');  // uniform-tap kernel (default on)
+    if constexpr (BN % 32 == 0 && WN == 32) {
+        const bool uni = vec && dma && uni_on && a.C % BK == 0 && a.KH * a.KW <= 32 && a.KW < 32 && a.pad < a.KH && a.pad < a.KW &&
+                         (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0));
+        if (uni) {
+            if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_ZERO>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_TRANSPOSED>), grid, block, 0, st, a);
+            return pd::check_launch("pd_conv2d");
+        }
+    }
     if (vec && dma) {
         if (a.mode == MODE_ZERO) PD_LAUNCH_DMA(MODE_ZERO);
         else if (a.mode == MODE_REFLECT) PD_LAUNCH_DMA(MODE_REFLECT);
@@ -473,6 +767,18 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, const v
     a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.mode = mode; a.act = act; a.affine = affine; a.sub = sub; a.div = div;
     a.K = KH * KW * C; a.M = (long)N * Ho * Wo; a.ldy = ldy; a.sshift = sshift;
+    auto magic = [](long d, unsigned& mg, unsigned& sh) {       // n / d == mulhi(n, mg) >> sh for 0 <= n < 2^31, d >= 2
+        if (d <= 1 || d >= (1L << 31)) { mg = 0; sh = 0; return; }
+        int l = 0;
+        while ((1L << l) < d) ++l;                                // ceil(log2 d) >= 1
+        mg = (unsigned)((((unsigned long long)1 << (31 + l)) + (unsigned long long)d - 1) / (unsigned long long)d);
+        sh = (unsigned)(l - 1);
+    };
+    magic((long)Ho * Wo, a.mg_hw, a.sh_hw);
+    magic(Wo, a.mg_wo, a.sh_wo);
+#ifdef PD_CONV_ABLATE
+    a.abl = getenv("PD_ABL") ? atoi(getenv("PD_ABL")) : 0;
+#endif
     const long wbytes = (long)Co * a.K * 4;
     PD_REQUIRE(wbytes < 0x7fffffffL, "pd_conv2d: weight tensor too large for 32-bit offsets");
     a.w_bytes = (unsigned)wbytes;
