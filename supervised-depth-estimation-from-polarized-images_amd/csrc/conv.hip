@@ -57,9 +57,6 @@ struct ConvArgs {
     int sshift;              // log2(stride) (transposed mode: stride is a power of two)
     unsigned w_bytes;
     unsigned mg_hw, sh_hw, mg_wo, sh_wo;   // n / (Ho*Wo) and n / Wo as mulhi + shift (n < 2^31), see magic_div()
-#ifdef PD_CONV_ABLATE
-    int abl;
-#endif
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -490,20 +487,31 @@ __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, unsigned m0v, u
     // s_nop 4: the scalar offset may have been written by the SALU instruction right in front (5 wait states to a
     // VMEM read of it); s_nop 0: M0 write -> LDS-DMA
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(m0v), "v"(voff), "s"(r), "s"(soff) : "memory");
+                 :: "s"(m0v), "v"(voff), "s"(r), "s"(soff));
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+// compile-time loop over LDS-DMA piece numbers [P0, P1)
+template <int P0, int P1, typename F, typename D>
+__device__ __forceinline__ void pieces(F& f, D dst) {
+    if constexpr (P0 < P1) {
+        f(dst, std::integral_constant<int, P0>{});
+        pieces<P0 + 1, P1>(f, dst);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int NS>
 __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
     static_assert(MODE == MODE_ZERO || MODE == MODE_TRANSPOSED, "uniform-tap kernel: zero padding or stride-1 data gradient");
     constexpr int MT = 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / MT, TN = WN / MT;
     static_assert((BM / WM) * WAVES_N == 4 && BN % 32 == 0, "4 waves per workgroup");
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32, NP = A_IT + B_IT;   // LDS-DMA pieces per thread and chunk
     constexpr unsigned A_BYTES = BM * LDT * 4, B_BYTES = BN * LDT * 4;
+    constexpr unsigned B_BASE = NS * A_BYTES;
 
-    __shared__ __attribute__((aligned(16))) float smem_all[2 * BM * LDT + 2 * BN * LDT];
+    // ring of NS chunk buffers: A tiles, then B tiles
+    __shared__ __attribute__((aligned(16))) float smem_all[NS * (BM + BN) * LDT];
 
     const int nblk = a.mtiles * a.ntiles;
     const int per_xcd = (int)gridDim.x >> 3;
@@ -525,13 +533,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
     const long shift = MODE == MODE_ZERO ? (long)a.pad * (a.sH + a.sW)
                                          : (long)(a.KH - 1 - a.pad) * a.sH + (long)(a.KW - 1 - a.pad) * a.sW;
     const long rest = (((long)a.N - img0) * a.sN + shift) * 4;
-#ifdef PD_CONV_ABLATE
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, (a.abl & (2 | 64)) ? 0u : (rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest));
-    const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, (a.abl & (2 | 128)) ? 0u : a.w_bytes);
-#else
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
     const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, a.w_bytes);
-#endif
 
     // ---- per-thread gather state (loop invariant)
     const int prow = tid >> 3;                                   // row of this thread inside every 32-row piece
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
         unsigned mask = 0;
         for (int kh = a.KH - 1; kh >= 0; --kh)
             mask = (mask << a.KW) | (((bad_h >> kh) & 1u) ? ones_kw : bad_w);
-        inv[i] = m < a.M ? mask : 0xffffffffu;
+        inv[i] = m < a.M ? (mask | 0x80000000u) : 0xffffffffu;   // bit 31: the tap index of chunks beyond K (ring run-out)
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -571,40 +574,35 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
         vb[i] = nr < a.Co ? (unsigned)(nr * a.K) * 4u + col4 : OOB;
     }
 
-    // ---- scalar tap state: tap index, channel offset inside the tap, byte offset of (tap, channel chunk)
+    // ---- scalar tap state of the chunk the next load_piece() calls fetch: tap index, channel offset inside the tap,
+    // byte offset of (tap, channel chunk).  Chunks past K (the ring keeps loading NS-1 ahead) fetch nothing: tap
+    // index 31 is invalid in every mask, the weight pieces re-read chunk 0.
     const int dW4 = (MODE == MODE_ZERO ? (int)a.sW : -(int)a.sW) * 4, dH4 = (MODE == MODE_ZERO ? (int)a.sH : -(int)a.sH) * 4;
-    int s_tap = 0, s_kw = 0, s_c = 0;
+    const int nchunks = a.K / BK;          // K % 32 == 0 on this path
+    int s_q = 0, s_tap = 0, s_kw = 0, s_c = 0;
     unsigned s_aoff = MODE == MODE_ZERO ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
     unsigned s_boff = 0;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
-    const unsigned m0_a = lds0 + 1024u * (unsigned)wave, m0_b = lds0 + 2 * A_BYTES + 1024u * (unsigned)wave;
+    const unsigned m0_a = lds0 + 1024u * (unsigned)wave, m0_b = lds0 + B_BASE + 1024u * (unsigned)wave;
 
-    auto load_chunk = [&](auto dst_tag) {
+    auto load_piece = [&](auto dst_tag, auto piece_tag) {
         constexpr unsigned DST = decltype(dst_tag)::value;
-#ifdef PD_CONV_ABLATE
-        if (!(a.abl & 1)) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const unsigned bad = (a.abl & 8) ? 0u : __builtin_amdgcn_ubfe(inv[i], (unsigned)s_tap, 1u);
-            dma16s(rx, m0_a + DST * A_BYTES + 4096u * i, (bad << 31) + va[i], s_aoff);
+        constexpr int P = decltype(piece_tag)::value;
+        if constexpr (P < A_IT) {
+            const unsigned bad = __builtin_amdgcn_ubfe(inv[P], (unsigned)s_tap, 1u);
+            dma16s(rx, m0_a + DST * A_BYTES + 4096u * P, (bad << 31) + va[P], s_aoff);
+        } else {
+            dma16s(rw_, m0_b + DST * B_BYTES + 4096u * (P - A_IT), vb[P - A_IT], s_boff);
         }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) dma16s(rw_, m0_b + DST * B_BYTES + 4096u * i, vb[i], s_boff);
-        }
-#else
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const unsigned bad = __builtin_amdgcn_ubfe(inv[i], (unsigned)s_tap, 1u);
-            dma16s(rx, m0_a + DST * A_BYTES + 4096u * i, (bad << 31) + va[i], s_aoff);
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) dma16s(rw_, m0_b + DST * B_BYTES + 4096u * i, vb[i], s_boff);
-#endif
+    };
+    auto advance_chunk = [&]() {
+        ++s_q;
         s_boff += BK * 4; s_aoff += BK * 4; s_c += BK;
         if (s_c == a.C) {
             s_c = 0; ++s_tap; s_aoff += (unsigned)(dW4 - a.C * 4);
             if (++s_kw == a.KW) { s_kw = 0; s_aoff += (unsigned)(dH4 - a.KW * dW4); }
         }
+        if (s_q >= nchunks) { s_tap = 31; s_boff = 0; s_aoff = 0; }
     };
 
     // ---- fragment addresses: lane -> (row = lane % 32, slot group = lane / 32); the swizzle (row>>1)&7 is the same
@@ -615,7 +613,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
     for (int g = 0; g < 4; ++g) {
         const unsigned sw = 16u * ((2 * g + fh) ^ ((frow >> 1) & 7));
         fa_off[g] = (unsigned)(wm * WM + frow) * (LDT * 4) + sw;
-        fb_off[g] = 2 * A_BYTES + (unsigned)(wn * WN + frow) * (LDT * 4) + sw;
+        fb_off[g] = B_BASE + (unsigned)(wn * WN + frow) * (LDT * 4) + sw;
         asm volatile("" : "+v"(fa_off[g]), "+v"(fb_off[g]));     // keep them as registers (no re-derivation per chunk)
     }
     const char* lds_c = reinterpret_cast<const char*>(smem_all);
@@ -629,62 +627,71 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](auto buf_tag) {
+    // One K-chunk: the MFMAs of buffer BUF with the LDS-DMA pieces of the chunk NS-1 ahead spread between the four
+    // fragment groups (a piece issued in the shadow of the wave's own MFMAs costs it nothing; six in a row at the
+    // head of the chunk are ~400 cycles in which the wave feeds no MFMA).
+    auto chunk = [&](auto buf_tag) {
         constexpr unsigned BUF = decltype(buf_tag)::value;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 fa[TM], fb[TN];
+        constexpr unsigned DST = (BUF + NS - 1) % NS;
+        const std::integral_constant<unsigned, DST> dst{};
+        float4 fa[2][TM], fb[2][TN];          // fragments of group g+1 are read while the MFMAs of group g run
+        auto read_frags = [&](int g, int set) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const float4*>(lds_c + fa_off[g] + (BUF * A_BYTES + (unsigned)i * MT * LDT * 4));
+                fa[set][i] = *reinterpret_cast<const float4*>(lds_c + fa_off[g] + (BUF * A_BYTES + (unsigned)i * MT * LDT * 4));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const float4*>(lds_c + fb_off[g] + (BUF * B_BYTES + (unsigned)j * MT * LDT * 4));
+                fb[set][j] = *reinterpret_cast<const float4*>(lds_c + fb_off[g] + (BUF * B_BYTES + (unsigned)j * MT * LDT * 4));
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) read_frags(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);     // (left alone, the scheduler sinks the reads below the MFMAs again)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].x, fb[g & 1][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].y, fb[g & 1][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].z, fb[g & 1][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i].w, fb[g & 1][j].w, acc[i][j], 0, 0, 0);
                 }
+            // pieces g*NP/4 .. (g+1)*NP/4 - 1 of the prefetched chunk
+            if (g == 0) { pieces<0 * NP / 4, 1 * NP / 4>(load_piece, dst); }
+            else if (g == 1) { pieces<1 * NP / 4, 2 * NP / 4>(load_piece, dst); }
+            else if (g == 2) { pieces<2 * NP / 4, 3 * NP / 4>(load_piece, dst); }
+            else { pieces<3 * NP / 4, NP>(load_piece, dst); }
         }
+        advance_chunk();
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * NP) : "memory");
+        __syncthreads();
     };
-    const std::integral_constant<unsigned, 0> B0{};
-    const std::integral_constant<unsigned, 1> B1{};
 
-    const int nchunks = a.K / BK;          // K % 32 == 0 on this path
-    load_chunk(B0);
-    dma_wait();
-    __syncthreads();
-    int q = 0;
-#ifdef PD_CONV_ABLATE
-#define PD_SYNC() do { if (!(a.abl & 4)) { dma_wait(); __syncthreads(); } } while (0)
-#else
-#define PD_SYNC() do { dma_wait(); __syncthreads(); } while (0)
-#endif
-    for (; q + 1 < nchunks; q += 2) {
-        load_chunk(B1);
-        compute(B0);
-        PD_SYNC();
-        if (q + 2 < nchunks) load_chunk(B0);
-        compute(B1);
-        PD_SYNC();
+    // ---- prologue: chunks 0 .. NS-2 in flight, chunk 0 landed
+    {
+        const std::integral_constant<unsigned, 0> d0{};
+        pieces<0, NP>(load_piece, d0);
+        advance_chunk();
+        if constexpr (NS == 3) {
+            const std::integral_constant<unsigned, 1> d1{};
+            pieces<0, NP>(load_piece, d1);
+            advance_chunk();
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * NP) : "memory");
+        __syncthreads();
     }
-#undef PD_SYNC
-    if (q < nchunks) {
-        compute(B0);
-        __syncthreads();                   // the epilogue scratch aliases the A tiles
+    for (int q = 0; q < nchunks; q += NS) {
+        chunk(std::integral_constant<unsigned, 0>{});
+        if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
+        if constexpr (NS == 3) {
+            if (q + 2 < nchunks) chunk(std::integral_constant<unsigned, 2>{});
+        }
     }
-#ifdef PD_CONV_ABLATE
-    if (a.abl & 32) {
-        float sacc = 0.f;
-        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-        if (sacc == 1234.5f) a.y[0] = sacc;
-        return;
+    if constexpr (NS > 2) {                // run-out pieces (zeros / chunk 0 of the weights) still target the ring
+        dma_wait();
+        __syncthreads();
     }
-#endif
     conv_epilogue<BM, BN, WM, WN, MT>(a, acc, smem_all, mt, m0, n0, wm, wn, lane, wave, tid);
 }
 
@@ -699,11 +706,17 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
     static const bool dma = !(getenv("PD_CONV_DMA") && getenv("PD_CONV_DMA")[0] == '0');   // direct-to-LDS staging (default on)
     static const bool uni_on = !(getenv("PD_CONV_UNI") && getenv("PD_CONV_UNI")[0] == '0');  // uniform-tap kernel (default on)
     if constexpr (BN % 32 == 0 && WN == 32) {
-        const bool uni = vec && dma && uni_on && a.C % BK == 0 && a.KH * a.KW <= 32 && a.KW < 32 && a.pad < a.KH && a.pad < a.KW &&
+        const bool uni = vec && dma && uni_on && a.C % BK == 0 && a.KH * a.KW <= 31 && a.pad < a.KH && a.pad < a.KW &&
                          (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0));
         if (uni) {
-            if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_ZERO>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_TRANSPOSED>), grid, block, 0, st, a);
+            static const int ns = getenv("PD_CONV_STAGES") ? atoi(getenv("PD_CONV_STAGES")) : 2;
+            if (ns == 2) {
+                if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_ZERO, 2>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_TRANSPOSED, 2>), grid, block, 0, st, a);
+            } else {
+                if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_ZERO, 3>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_TRANSPOSED, 3>), grid, block, 0, st, a);
+            }
             return pd::check_launch("pd_conv2d");
         }
     }
@@ -776,9 +789,6 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, const v
     };
     magic((long)Ho * Wo, a.mg_hw, a.sh_hw);
     magic(Wo, a.mg_wo, a.sh_wo);
-#ifdef PD_CONV_ABLATE
-    a.abl = getenv("PD_ABL") ? atoi(getenv("PD_ABL")) : 0;
-#endif
     const long wbytes = (long)Co * a.K * 4;
     PD_REQUIRE(wbytes < 0x7fffffffL, "pd_conv2d: weight tensor too large for 32-bit offsets");
     a.w_bytes = (unsigned)wbytes;
@@ -1054,6 +1064,264 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     if (do_bias && tid < TCO && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = bsum;
 }
 
+// ===================================================================== weight gradient, scalar-pixel variant
+// Same reasoning as conv_igemm_uni_kernel: the fp32 MFMA shares the SIMD's FMA lanes with every VALU instruction, and
+// the kernel above pays ~100 of them per 32-pixel chunk (tap bounds tests, incremental pixel coordinates, LDS stores)
+// against 32 MFMAs.  Here both operands go global -> LDS directly and the per-lane part of every address is fixed:
+//   * a lane's k column never changes, so its tap offset (and the +1 pixel of the upper half-wave) is loop invariant;
+//   * one LDS-DMA instruction of X covers ONE pixel pair (ow, ow+1) of one output row (Wo is even), so the pixel's
+//     offset is a scalar (soffset) and the pair's border class -- (top rows | interior | bottom rows) x (left pair |
+//     interior | right pair) -- is a scalar index into a per-lane bit mask built once ("this lane's tap leaves the
+//     image for pixels of that class"); bit 31 of the offset drops an invalid piece in the range check;
+//   * dY rows are contiguous: four pixels per instruction, scalar row offset, the slice end is the descriptor's end;
+//   * unpadded LDS rows; the two pixels of an MFMA step sit 64/128 floats apart, so odd pixels store their row
+//     XOR 32 floats (applied to the source address of the DMA) -- conflict-free ds_read_b32 fragments.
+// Per chunk and wave: 32 MFMAs, 48 ds_read_b32, 6 LDS-DMA issues, 8 VALU.
+struct WgradUniArgs {
+    WgradArgs g;
+    int nb, nbw;          // border rows / border pixel pairs that can hold an invalid tap
+};
+
+template <int DUMMY>
+__global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs ua) {
+    const WgradArgs& a = ua.g;
+    constexpr int TCO = 64, MT = 32, TK = 2;
+    constexpr unsigned D_ROW = TCO * 4, X_ROW = WG_K * 4;                 // bytes per pixel row in LDS
+    constexpr unsigned D_BYTES = WG_MC * D_ROW, X_BYTES = WG_MC * X_ROW;   // per buffer: 8 KB, 16 KB
+    __shared__ __attribute__((aligned(16))) float smem_all[(2 * D_BYTES + 2 * X_BYTES) / 4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = a.ktiles * a.ctiles * a.S;
+    int b = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (b >= nwg) return;
+    const int kt = b % a.ktiles; b /= a.ktiles;
+    const int ct = b % a.ctiles; b /= a.ctiles;
+    const int s = b;
+    const int co0 = ct * TCO, k0 = kt * WG_K;
+    const long mbeg = (long)s * a.mper;
+    const long mend = (mbeg + a.mper < a.M) ? mbeg + a.mper : a.M;
+    const int nrows = (int)(mend - mbeg);
+    const int nchunks = nrows > 0 ? (nrows + WG_MC - 1) / WG_MC : 0;
+    const int hw = a.Ho * a.Wo;
+
+    const int img0 = (int)(mbeg / hw);
+    const long shift = (long)a.pad * (a.sH + a.sW);                 // descriptor base moved back by the padding
+    const long rest = (((long)a.N - img0) * a.sN + shift) * 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
+    const float* dy0 = a.dy + mbeg * a.ldd;
+
+    // ---- per-lane invariants
+    // X: lane -> (pixel of the pair = lane/32, physical 16-byte slot = lane%32, logical slot = slot ^ 8*(pixel&1))
+    const int xh = lane >> 5;
+    const int kx = k0 + 4 * ((lane & 31) ^ (8 * xh));
+    const int tap = kx / a.C;
+    const int xc = kx - tap * a.C, xkh = tap / a.KW, xkw = tap - xkh * a.KW;
+    const unsigned vx = (unsigned)(xkh * (int)a.sH + (xkw + xh * a.stride) * (int)a.sW + xc) * 4u;
+    const int ncw = 2 * ua.nbw + 1;
+    unsigned xmask = 0x80000000u;                                    // bit 31: the "beyond the tensor" class
+    if (kx < a.K) {
+        for (int ch = 0; ch <= 2 * ua.nb; ++ch) {
+            const int oh = ch <= ua.nb ? ch : a.Ho - ua.nb + (ch - ua.nb - 1);
+            const bool bad_h = (unsigned)(oh * a.stride - a.pad + xkh) >= (unsigned)a.H;
+            for (int cw = 0; cw < ncw; ++cw) {
+                const int ow = (cw <= ua.nbw ? 2 * cw : a.Wo - 2 * ua.nbw + 2 * (cw - ua.nbw - 1)) + xh;
+                const bool bad_w = (unsigned)(ow * a.stride - a.pad + xkw) >= (unsigned)a.W;
+                xmask |= (unsigned)(bad_h | bad_w) << (ch * ncw + cw);
+            }
+        }
+    } else {
+        xmask = 0xffffffffu;
+    }
+    // dY: lane -> (pixel of the quad = lane/16, physical slot = lane%16, logical slot = slot ^ 8*(pixel&1))
+    const int dpi = lane >> 4;
+    const int dco = co0 + 4 * ((lane & 15) ^ (8 * (dpi & 1)));
+    const unsigned vd = dco < a.Co ? (unsigned)(dpi * (int)a.ldd + dco) * 4u : OOB;
+
+    // ---- scalar pixel state of this wave: it stages pixels 8*wave .. 8*wave+7 of every chunk
+    const int st_h4 = a.stride * (int)a.sH * 4, st_w4 = a.stride * (int)a.sW * 4, sn4 = (int)a.sN * 4;
+    const int d_row4 = st_h4 - a.Wo * st_w4, d_img4 = sn4 - a.Ho * st_h4;   // offset steps at a row / image wrap
+    int s_p = 8 * wave;                                              // pixel index inside the slice
+    int s_oh, s_ow, s_soff;                                          // its row, column and byte offset (without the tap)
+    {
+        const int m = (int)(mbeg - (long)img0 * hw) + s_p;
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        s_oh = rem / a.Wo; s_ow = rem - s_oh * a.Wo;
+        s_soff = n * sn4 + s_oh * st_h4 + s_ow * st_w4;
+        // the divisions run on the VALU: pin the results to SGPRs, or the whole bookkeeping chain follows them there
+        s_oh = __builtin_amdgcn_readfirstlane(s_oh); s_ow = __builtin_amdgcn_readfirstlane(s_ow);
+        s_soff = __builtin_amdgcn_readfirstlane(s_soff);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
+    const unsigned m0_d = lds0 + (unsigned)wave * 8 * D_ROW, m0_x = lds0 + 2 * D_BYTES + (unsigned)wave * 8 * X_ROW;
+
+    // LDS-DMA piece P of the chunk the scalar state points at: 0, 1 = dY (four pixels each), 2..5 = X (one pixel pair
+    // each; the pair state moves on).  Chunks past the slice fetch nothing: the dY descriptor has no records left and
+    // the pair's class is the "beyond the tensor" bit.
+    auto load_piece = [&](auto dst_tag, auto piece_tag) {
+        constexpr unsigned DST = decltype(dst_tag)::value;
+        constexpr int P = decltype(piece_tag)::value;
+        if constexpr (P < 2) {
+            // the scalar offset of a buffer access is outside the range check, so the slice end is enforced by a
+            // descriptor per instruction (base and record count are SALU arithmetic): rows >= nrows read as zero
+            const int r0 = s_p + 4 * P, left = nrows - r0;
+            const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy0 + (long)r0 * a.ldd, left > 0 ? (unsigned)(left * (int)a.ldd) * 4u : 0u);
+            dma16s(rd, m0_d + DST * D_BYTES + P * 4 * D_ROW, vd, 0u);
+        } else {
+            constexpr int J = P - 2;
+            // border class of the pair: rows 0..nb-1 | interior | last nb rows  x  the same over column pairs (min/max, no branches)
+            const int ch = min(s_oh, ua.nb) + max(s_oh - (a.Ho - ua.nb) + 1, 0);
+            const int pw = s_ow >> 1;
+            const int cw = min(pw, ua.nbw) + max(pw - ((a.Wo >> 1) - ua.nbw) + 1, 0);
+            const unsigned cls = (unsigned)(ch * ncw + cw) | (s_p < nrows ? 0u : 31u);   // (classes are < 31)
+            const unsigned bad = __builtin_amdgcn_ubfe(xmask, cls, 1u);
+            dma16s(rx, m0_x + DST * X_BYTES + J * 2 * X_ROW, (bad << 31) + vx, (unsigned)s_soff);
+            // Pixel bookkeeping as selects, not branches: straight-line scalar code that the scheduler can slide under
+            // the 64-cycle MFMAs around it (a branchy version costs the wave ~150 cycles per piece with nothing issued).
+            constexpr int STEP = J < 3 ? 2 : WG_MC - 6;        // next pair of the row / this wave's first pair of the next chunk
+            s_p += STEP; s_ow += STEP; s_soff += STEP * st_w4;
+#pragma unroll
+            for (int w = 0; w < (J < 3 ? 1 : 2); ++w) {        // Wo >= 14 (host check): 26 columns wrap at most twice
+                const int ow0 = s_ow;
+                s_ow = ow0 >= a.Wo ? ow0 - a.Wo : ow0;
+                s_soff += ow0 >= a.Wo ? d_row4 : 0;
+                const int oh1 = ow0 >= a.Wo ? s_oh + 1 : s_oh;
+                s_soff += oh1 == a.Ho ? d_img4 : 0;            // (without a wrap oh1 = oh < Ho)
+                s_oh = oh1 == a.Ho ? 0 : oh1;
+            }
+        }
+    };
+
+    // A k tile with at most 64 valid columns (the last tile of K = 576: 4.5 tiles) would leave the wn = 1 waves idle:
+    // there both wave columns take the first 64 columns and split the pixel steps (fragment groups alternate); the
+    // two partial tiles are added through LDS at the end.
+    const bool half = k0 + TK * MT >= a.K;
+    const int wn_k = half ? 0 : wn;
+    // ---- fragments: lane -> (index inside the 32-wide tile = lane%32, pixel of the step = lane/32)
+    const int fi = lane & 31, fk = lane >> 5;
+    unsigned fd_off = fk * D_ROW + 4u * ((wm * MT + fi) ^ (32 * fk));
+    unsigned fx_off[TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t) fx_off[t] = 2 * D_BYTES + fk * X_ROW + 4u * (((wn_k * TK + t) * MT + fi) ^ (32 * fk));
+    if (half) {     // the wave's first fragment group is group wn: folded into the lane base, the chunk reads "groups 0 and 2"
+        fd_off += wn * (4 * 2 * D_ROW);
+        fx_off[0] += wn * (4 * 2 * X_ROW); fx_off[1] += wn * (4 * 2 * X_ROW);
+    }
+    asm volatile("" : "+v"(fd_off), "+v"(fx_off[0]), "+v"(fx_off[1]));
+    const char* lds_c = reinterpret_cast<const char*>(smem_all);
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t acc[TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = a.bpart != nullptr && kt == 0;
+
+    // One chunk: the MFMAs of buffer BUF; the six pieces of the next chunk go out between the four fragment groups,
+    // in the shadow of the wave's own MFMAs.  HALF (compile time: the two loops below never meet inside a chunk, or
+    // the accumulators would be copied between their register sets every chunk): groups wn and wn + 2 only.
+    auto chunk = [&](auto buf_tag, auto half_tag) {
+        constexpr unsigned BUF = decltype(buf_tag)::value;
+        constexpr bool HALF = decltype(half_tag)::value;
+        const std::integral_constant<unsigned, BUF ^ 1> dst{};
+        constexpr int NST = WG_MC / 2, UG = 4, NG = NST / UG;
+        float av[2][UG], bv[2][UG][TK];
+        auto read_group = [&](int sg, int slot) {
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                const unsigned step = UG * sg + u;
+                av[slot][u] = *reinterpret_cast<const float*>(lds_c + fd_off + (BUF * D_BYTES + step * 2 * D_ROW));
+#pragma unroll
+                for (int t = 0; t < TK; ++t)
+                    bv[slot][u][t] = *reinterpret_cast<const float*>(lds_c + fx_off[t] + (BUF * X_BYTES + step * 2 * X_ROW));
+            }
+        };
+        if constexpr (!HALF) {
+            read_group(0, 0);
+#pragma unroll
+            for (int sg = 0; sg < NG; ++sg) {
+                if (sg + 1 < NG) read_group(sg + 1, (sg + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < UG; ++u) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sg & 1][u], bv[sg & 1][u][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sg & 1][u], bv[sg & 1][u][1], acc[1], 0, 0, 0);
+                }
+                if (sg == 0) pieces<0, 2>(load_piece, dst);
+                else if (sg == 1) pieces<2, 4>(load_piece, dst);
+                else if (sg == 2) pieces<4, 6>(load_piece, dst);
+            }
+        } else {
+            read_group(0, 0);
+            read_group(2, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int u = 0; u < UG; ++u) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][u], bv[h][u][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][u], bv[h][u][1], acc[1], 0, 0, 0);
+                }
+                if (h == 0) pieces<0, 3>(load_piece, dst);
+                else pieces<3, 6>(load_piece, dst);
+            }
+        }
+        if (do_bias && tid < TCO) {
+#pragma unroll 8
+            for (int r = 0; r < WG_MC; ++r)
+                bsum += *reinterpret_cast<const float*>(lds_c + BUF * D_BYTES + r * D_ROW + 4u * (tid ^ (32 * (r & 1))));
+        }
+        dma_wait();
+        __syncthreads();
+    };
+
+    pieces<0, 6>(load_piece, std::integral_constant<unsigned, 0>{});
+    dma_wait();
+    __syncthreads();
+    if (!half) {
+        for (int q = 0; q < nchunks; q += 2) {
+            chunk(std::integral_constant<unsigned, 0>{}, std::false_type{});
+            if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{}, std::false_type{});
+        }
+    } else {
+        for (int q = 0; q < nchunks; q += 2) {
+            chunk(std::integral_constant<unsigned, 0>{}, std::true_type{});
+            if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{}, std::true_type{});
+        }
+    }
+
+    if (half) {                             // (uniform per workgroup; the ring is drained: every chunk ends with a barrier)
+        float* xch = smem_all + (wm * 64 + lane) * 33;              // 33-float rows: conflict-free
+        if (wn == 1) {
+#pragma unroll
+            for (int t = 0; t < TK; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[16 * t + r] = acc[t][r];
+        }
+        __syncthreads();
+        if (wn == 1) return;
+#pragma unroll
+        for (int t = 0; t < TK; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += xch[16 * t + r];
+    }
+    // C/D layout: col = lane % 32 -> k; row -> co: (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int t = 0; t < TK; ++t) {
+        const int k = k0 + (wn_k * TK + t) * MT + fi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * MT + (r & 3) + 8 * (r >> 2) + 4 * fk;
+            if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc[t][r];
+        }
+    }
+    if (do_bias && tid < TCO && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = bsum;
+}
+
 // out[i] (+)= sum_s part[s][i]: 64 columns x 4 slice lanes per workgroup; every lane keeps four independent
 // loads in flight; the lane partials are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -1098,7 +1366,8 @@ inline int wgrad_tco(int Co) { return Co > 32 ? 64 : (Co > 16 ? 32 : 16); }
 void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
     const int tco = wgrad_tco(Co);
     const long tiles = (long)((Co + tco - 1) / tco) * ((K + WG_K - 1) / WG_K);
-    long s = 1536 / tiles;                    // <= two full rounds of 3 resident workgroups per CU (floor: no ragged tail)
+    static const long total = getenv("PD_WGRAD_WGS") ? atol(getenv("PD_WGRAD_WGS")) : 1536;
+    long s = total / tiles;                   // <= two full rounds of 3 resident workgroups per CU (floor: no ragged tail)
     const long smax = (M + 511) / 512;
     if (s > smax) s = smax;
     if (s < 1) s = 1;
@@ -1148,6 +1417,15 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(((long)a.ktiles * a.ctiles * a.S + 7) / 8 * 8)), block(NT);
 #define PD_WG(T, V, MD) hipLaunchKernelGGL((conv_wgrad_kernel<T, V, MD>), grid, block, 0, st, a)
+    // scalar-pixel variant: 16-byte path, zero padding, 64-wide co tile, even output rows (pixel pairs stay inside a
+    // row), border classes that fit the 31-bit mask
+    static const bool uni_on = !(getenv("PD_WGRAD_UNI") && getenv("PD_WGRAD_UNI")[0] == '0');
+    const int nb = (pad + stride - 1) / stride, nbw = (nb + 1) / 2;
+    if (uni_on && tco == 64 && vec && mode == MODE_ZERO && Co % 4 == 0 && Wo % 2 == 0 && ldd % 4 == 0 &&
+        Ho >= 2 * nb && Wo >= 4 * nbw && Wo >= 14 && (2 * nb + 1) * (2 * nbw + 1) <= 31 && a.mper % WG_MC == 0 && a.M % 4 == 0) {
+        WgradUniArgs ua; ua.g = a; ua.nb = nb; ua.nbw = nbw;
+        hipLaunchKernelGGL((conv_wgrad_uni_kernel<0>), grid, block, 0, st, ua);
+    } else
     if (tco == 64) {
         if (vec) { if (mode == MODE_ZERO) PD_WG(64, true, MODE_ZERO); else PD_WG(64, true, MODE_REFLECT); }
         else { if (mode == MODE_ZERO) PD_WG(64, false, MODE_ZERO); else PD_WG(64, false, MODE_REFLECT); }

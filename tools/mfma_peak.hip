@@ -7,7 +7,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { M_ONLY = 0, M_READ = 1, M_BARRIER = 2, M_PREFETCH = 4, M_VALU = 8, M_B64 = 16, M_ONE = 32, M_TWO = 64 };
+enum { M_ONLY = 0, M_READ = 1, M_BARRIER = 2, M_PREFETCH = 4, M_VALU = 8, M_B64 = 16, M_ONE = 32, M_TWO = 64, M_B32 = 128 };
 
 // NACC independent accumulators; per group of 8 MFMAs (the conv kernel issues 3 ds_read_b128 per 8 MFMAs):
 //   M_READ     3 x ds_read_b128 consumed by the group's own MFMAs
@@ -15,6 +15,7 @@ enum { M_ONLY = 0, M_READ = 1, M_BARRIER = 2, M_PREFETCH = 4, M_VALU = 8, M_B64 
 //   M_B64      the same bytes as 6 x ds_read_b64
 //   M_ONE/TWO  1 or 2 ds_read_b128 per group instead of 3
 //   M_VALU     no LDS reads, ~30 dependent VALU ops per group instead
+//   M_B32      12 x ds_read_b32 per group (the weight-gradient kernel's fragment reads: 3 per 2 MFMAs)
 //   M_BARRIER  s_barrier every 32 MFMAs
 template <int NACC, int MODE>
 __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float a0, float b0) {
@@ -35,7 +36,13 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float a0
     constexpr int NREAD = (MODE & M_ONE) ? 1 : (MODE & M_TWO) ? 2 : 3;
     auto read = [&](float4* dst, int grp) {
         const int o = ((grp & 3) * 1024 + tid * 4);           // 0 .. 4 K floats
-        if (MODE & M_B64) {
+        if (MODE & M_B32) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int w = (grp & 3) * 1024 + 4096 * j + (tid & 63) + 256 * (tid >> 6);
+                dst[j].x = lds[w]; dst[j].y = lds[w + 64]; dst[j].z = lds[w + 128]; dst[j].w = lds[w + 192];
+            }
+        } else if (MODE & M_B64) {
 #pragma unroll
             for (int j = 0; j < NREAD; ++j) {
                 const float2 lo = *reinterpret_cast<const float2*>(&lds[o + 4096 * j]);
@@ -111,6 +118,8 @@ int main() {
         run<2, M_PREFETCH>("mfma + 3 ds_read_b128 / 8, prefetched", w, out);
         run<2, M_PREFETCH | M_B64>("mfma + 6 ds_read_b64 / 8, prefetched", w, out);
         run<2, M_PREFETCH | M_BARRIER>("prefetched + barrier/32", w, out);
+        run<2, M_READ | M_B32>("mfma + 12 ds_read_b32 / 8", w, out);
+        run<2, M_PREFETCH | M_B32>("mfma + 12 ds_read_b32 / 8, prefetched", w, out);
     }
     return 0;
 }
