@@ -1076,7 +1076,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 //   * dY rows are contiguous: four pixels per instruction, scalar row offset, the slice end is the descriptor's end;
 //   * unpadded LDS rows; the two pixels of an MFMA step sit 64/128 floats apart, so odd pixels store their row
 //     XOR 32 floats (applied to the source address of the DMA) -- conflict-free ds_read_b32 fragments.
-// Per chunk and wave: 32 MFMAs, 48 ds_read_b32, 6 LDS-DMA issues, 8 VALU.
+// Per chunk and wave: 32 MFMAs, 48 ds_read_b32, 6 LDS-DMA issues, 8 VALU.  (Layers with a bias gradient -- the decoder's
+// reflection-padded convolutions -- stay on the kernel above.)
 struct WgradUniArgs {
     WgradArgs g;
     int nb, nbw;          // border rows / border pixel pairs that can hold an invalid tap
@@ -1218,8 +1219,6 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
     for (int t = 0; t < TK; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float bsum = 0.f;
-    const bool do_bias = a.bpart != nullptr && kt == 0;
 
     // One chunk: the MFMAs of buffer BUF; the six pieces of the next chunk go out between the four fragment groups,
     // in the shadow of the wave's own MFMAs.  HALF (compile time: the two loops below never meet inside a chunk, or
@@ -1270,11 +1269,6 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
                 else pieces<3, 6>(load_piece, dst);
             }
         }
-        if (do_bias && tid < TCO) {
-#pragma unroll 8
-            for (int r = 0; r < WG_MC; ++r)
-                bsum += *reinterpret_cast<const float*>(lds_c + BUF * D_BYTES + r * D_ROW + 4u * (tid ^ (32 * (r & 1))));
-        }
         dma_wait();
         __syncthreads();
     };
@@ -1319,7 +1313,6 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
             if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc[t][r];
         }
     }
-    if (do_bias && tid < TCO && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = bsum;
 }
 
 // out[i] (+)= sum_s part[s][i]: 64 columns x 4 slice lanes per workgroup; every lane keeps four independent
@@ -1358,6 +1351,34 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
         const int t = (int)(r % T);
         const int ci = (int)(r / T);
         wt[i] = w[((long)co * T + t) * Ci + ci];
+    }
+}
+
+// All convolution weights of a parameter store in one launch: entry e = {element offset in both flat buffers, Co, T, Ci},
+// blk[e] = first workgroup of entry e (1024 elements per workgroup), blk[n] = grid size.
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                       const int* __restrict__ table,
+                                                                       const int* __restrict__ blk, int n) {
+    int lo = 0, hi = n;                         // last e with blk[e] <= blockIdx.x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blk[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int off = table[4 * lo], Co = table[4 * lo + 1], T = table[4 * lo + 2], Ci = table[4 * lo + 3];
+    const int cnt = Co * T * Ci;
+    const float* w = src + off;
+    float* wt = dst + off;
+    const int base = ((int)blockIdx.x - blk[lo]) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = base + j * 256 + (int)threadIdx.x;
+        if (i < cnt) {
+            const int co = i % Co;
+            const int r = i / Co;
+            const int t = r % T;
+            const int ci = r / T;
+            wt[i] = w[(co * T + t) * Ci + ci];
+        }
     }
 }
 
@@ -1421,7 +1442,7 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     // row), border classes that fit the 31-bit mask
     static const bool uni_on = !(getenv("PD_WGRAD_UNI") && getenv("PD_WGRAD_UNI")[0] == '0');
     const int nb = (pad + stride - 1) / stride, nbw = (nb + 1) / 2;
-    if (uni_on && tco == 64 && vec && mode == MODE_ZERO && Co % 4 == 0 && Wo % 2 == 0 && ldd % 4 == 0 &&
+    if (uni_on && tco == 64 && vec && mode == MODE_ZERO && !dbias && Co % 4 == 0 && Wo % 2 == 0 && ldd % 4 == 0 &&
         Ho >= 2 * nb && Wo >= 4 * nbw && Wo >= 14 && (2 * nb + 1) * (2 * nbw + 1) <= 31 && a.mper % WG_MC == 0 && a.M % 4 == 0) {
         WgradUniArgs ua; ua.g = a; ua.nb = nb; ua.nbw = nbw;
         hipLaunchKernelGGL((conv_wgrad_uni_kernel<0>), grid, block, 0, st, ua);
@@ -1457,6 +1478,13 @@ extern "C" int pd_weight_transpose(const void* w, void* wt, int Co, int T, int C
     return pd::check_launch("pd_weight_transpose");
 }
 
+extern "C" int pd_weight_transpose_batched(const void* src, void* dst, const void* table, const void* blk, int n,
+                                           int nblocks, void* stream) {
+    PD_REQUIRE(src && dst && table && blk && n > 0 && nblocks > 0, "pd_weight_transpose_batched: bad arguments");
+    hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, (float*)dst, (const int*)table, (const int*)blk, n);
+    return pd::check_launch("pd_weight_transpose_batched");
+}
 
 // ===================================================================== 7x7 / stride-2 stems as 4x4 / stride-1
 // A 7x7 stride-2 pad-3 convolution over [C,H,W] equals a 4x4 stride-1 pad-2 convolution over the

@@ -38,6 +38,7 @@ SIGNATURES = {
     "pd_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i,
                              _i, _i, _f, _f, _l, _i, _vp]),
     "pd_weight_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pd_weight_transpose_batched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "pd_stem_s2d_input": (_i, [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _f, _f, _vp]),
     "pd_stem_s2d_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "pd_stem_s2d_weight_grad": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -48,6 +48,44 @@ class ParamStore:
         for (name, p), off in zip(self.entries, offs):
             self.offsets[name] = (off, p.numel())
             self._adopt(p, off)
+        # Data-gradient operands: every 4-D weight transposed ([Co][T][Ci] -> [Ci][T][Co]) into flat_t at the same
+        # offset by ONE launch per backward pass (the first request after a forward convolution, ops.FWD_EPOCH) --
+        # instead of one launch per layer and step.
+        self.flat_t = None
+        self._wt_epoch = -1
+        self._wt_index, rows, blk = {}, [], [0]
+        for (name, p), off in zip(self.entries, offs):
+            if p.dim() == 4 and p.numel() < 2 ** 31:
+                co, ci, kh, kw = p.shape
+                self._wt_index[self.flat.data_ptr() + 4 * off] = (off, co, ci, kh, kw)
+                rows.append([off, co, kh * kw, ci])
+                blk.append(blk[-1] + (p.numel() + 1023) // 1024)
+        if rows:
+            self._wt_table = torch.tensor(rows, dtype=torch.int32, device=device)
+            self._wt_blk = torch.tensor(blk, dtype=torch.int32, device=device)
+            self._wt_n, self._wt_blocks = len(rows), blk[-1]
+            from . import ops as _ops
+            _ops.WT_PROVIDERS[:] = [pr for pr in _ops.WT_PROVIDERS if pr.flat.data_ptr() != self.flat.data_ptr()]
+            _ops.WT_PROVIDERS.append(self)
+
+    def weights_changed(self):
+        """Drop the transposed copies (FusedAdam.step calls it; a forward convolution has the same effect)."""
+        self._wt_epoch = -1
+
+    def transposed(self, w):
+        e = self._wt_index.get(w.data_ptr())
+        if e is None or tuple(w.shape) != (e[1], e[2], e[3], e[4]) or not w.is_cuda:
+            return None
+        off, co, ci, kh, kw = e
+        from . import ops as _ops
+        if self._wt_epoch != _ops.FWD_EPOCH:
+            if self.flat_t is None:
+                self.flat_t = torch.empty_like(self.flat)
+            from ._lib import lib, check, ptr, stream_ptr
+            check(lib.pd_weight_transpose_batched(ptr(self.flat), ptr(self.flat_t), ptr(self._wt_table), ptr(self._wt_blk),
+                                                  self._wt_n, self._wt_blocks, stream_ptr()), "pd_weight_transpose_batched")
+            self._wt_epoch = _ops.FWD_EPOCH
+        return self.flat_t[off:off + co * ci * kh * kw].view(ci, kh, kw, co).permute(0, 3, 1, 2)
 
     def _view(self, buf, p, off):
         flat = buf[off:off + p.numel()]
@@ -121,6 +159,7 @@ class FusedAdam(torch.optim.Optimizer):
                                float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
                                self.step_count, float(self.grad_scale), int(self.zero_grad_in_step), stream_ptr()),
               "pd_adam_step")
+        self.store.weights_changed()           # (raw-pointer write: the transposed copies are stale)
         if self.zero_grad_in_step:
             # (the tail behind n_used -- parameters that never receive gradients, e.g. ResNet layer3/4/fc -- is never read)
             self.store.mark_zeroed()

@@ -73,6 +73,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     space-to-depth stems execute K = 64*C for an algorithmic 7x7 filter: 49*C).
     """
     _require_cuda(x, w, bias, out_scale)
+    global FWD_EPOCH
+    FWD_EPOCH += 1
     N, C, H, W = x.shape
     Co, Ci, KH, KW = w.shape
     assert Ci == C, f"channel mismatch {Ci} vs {C}"
@@ -101,11 +103,24 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     return (out, stats) if want_stats else out
 
 
+# objects with .transposed(w) -> tensor | None: a parameter store hands out the data-gradient operands of ALL its
+# convolution weights from one batched launch per backward pass (engine.ParamStore registers itself here).  The copies
+# are valid until the next forward convolution: FWD_EPOCH counts conv2d_fwd calls, and weights cannot change between a
+# forward pass and its backward pass without invalidating the gradients anyway -- no reliance on version counters
+# (writes through ``p.data`` or raw pointers do not bump any).
+WT_PROVIDERS = []
+FWD_EPOCH = 0
+
+
 def weight_transposed(w):
     """[Co,Ci,kh,kw] (channels_last) -> operand of the data-gradient GEMM: [Ci][kh][kw][Co] storage,
     returned as a logical [Ci,Co,kh,kw] channels_last tensor."""
     Co, Ci, KH, KW = w.shape
     w = weight_cl(w)
+    for prov in WT_PROVIDERS:
+        wt = prov.transposed(w)
+        if wt is not None:
+            return wt
     wt = torch.empty((Ci, Co, KH, KW), dtype=torch.float32, device=w.device, memory_format=CL)
     check(lib.pd_weight_transpose(ptr(w), ptr(wt), Co, KH * KW, Ci, stream_ptr()), "pd_weight_transpose")
     return wt

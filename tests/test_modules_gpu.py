@@ -226,3 +226,40 @@ def test_bf16_attention_matches_fp32_attention_within_bf16_tolerance(shape):
                                1.0 / 128 ** 0.5, stream_ptr()), "pd_attn_bf16_fwd")
     assert (lse.cpu().double() - torch.logsumexp(scores.detach(), -1)).abs().max().item() < 2e-2
     assert torch.equal(o2, o.detach())
+
+
+def test_batched_weight_transposes_follow_the_weights():
+    """ParamStore serves the data-gradient operands of all its conv weights from one launch per backward pass: the
+    copies are redone at the first request after any forward convolution (or optimizer step), so they follow every
+    way the weights can change between two passes -- torch in-place ops, writes through .data, the raw-pointer Adam."""
+    from polardepth import engine, ops
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3), torch.nn.Conv2d(16, 4, 5), torch.nn.Linear(4, 2)).cuda()
+    store = engine.ParamStore({"net": net})
+    opt = engine.FusedAdam(store, lr=1e-2)
+    convs = [m for m in net if isinstance(m, torch.nn.Conv2d)]
+
+    def check_all():
+        for m in convs:
+            wt = ops.weight_transposed(m.weight.data)
+            assert wt.data_ptr() != m.weight.data_ptr()
+            assert wt.shape == (m.in_channels, m.out_channels) + m.kernel_size
+            assert torch.equal(wt, m.weight.data.permute(1, 0, 2, 3)), "stale or wrong transposed weight"
+            assert torch.equal(ops.weight_transposed(m.weight.data.clone()), wt)   # the per-layer kernel (tensor outside any store)
+
+    x = torch.randn(2, 8, 12, 12, device="cuda")
+    check_all()
+    with torch.no_grad():
+        convs[0].weight.mul_(2.0)
+        convs[1].weight.data.add_(1.0)
+    ops.conv2d_fwd(x, convs[0].weight.data)            # the forward pass every backward pass follows
+    check_all()
+    launches_before = store._wt_epoch
+    check_all()                                        # same pass: served from the same batch
+    assert store._wt_epoch == launches_before
+    store.grad.normal_()
+    store.grad_is_zero = False
+    before = convs[0].weight.data.clone()
+    opt.step()
+    assert not torch.equal(before, convs[0].weight.data)
+    check_all()
