@@ -221,6 +221,7 @@ def main():
     # (weight-gradient kernels normally overlap the data-gradient kernels on a side stream; for per-kernel
     # durations the instrumented steps run them serially on one stream)
     overlap, PF.USE_WGRAD_STREAM = PF.USE_WGRAD_STREAM, False
+    enc_streams, tr.encoder_streams = tr.encoder_streams, False      # (likewise: the three encoders on one stream)
     ops.PROFILE = []
     from polardepth import polar as pdpolar
     k1_step_events, k1_real = [], pdpolar.polar_forward
@@ -240,6 +241,7 @@ def main():
     pdpolar.polar_forward = k1_real
     prof, ops.PROFILE = ops.PROFILE, None
     PF.USE_WGRAD_STREAM = overlap
+    tr.encoder_streams = enc_streams
     INSTR_STEPS = 4
     k1_in_step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in k1_step_events)[len(k1_step_events) // 2]
     by_kernel = {}

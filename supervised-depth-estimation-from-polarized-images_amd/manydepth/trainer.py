@@ -176,6 +176,9 @@ class Trainer:
         # single process; default = per replica (standard DDP semantics, no exchange on the loss path)
         global_norm = self.distributed and (bool(getattr(self.opt, "global_loss_norm", False))
                                             or os.environ.get("PD_GLOBAL_LOSS_NORM") == "1")
+        # independent encoders on separate HIP streams (PD_ENCODER_STREAMS=0: everything on the current stream)
+        self.encoder_streams = os.environ.get("PD_ENCODER_STREAMS", "1") != "0" and self.device.type == "cuda"
+        self._enc_streams = []
         self.loss_cfg = PF.LossCfg(self.opt.scales, self.opt.min_depth, self.opt.max_depth, self.opt.normals_loss_weight,
                                    self.opt.disparity_smoothness, self.opt.height, self.opt.width, global_norm=global_norm)
         self.epoch, self.step = 0, 0
@@ -263,15 +266,52 @@ class Trainer:
 
     def _forward_models(self, inputs):
         normals = self._polar_inputs(inputs)
-        feats = self.models["rgb_encoder"](inputs["color_aug", 0, 0].float())
         xolp_feats = normals_feats = None
-        if self.opt.augment_xolp:
-            xolp_feats = self.models["xolp_encoder"](inputs["xolp", 0, 0].float())
-        if self.opt.augment_normals:
-            normals_feats = self.models["normals_encoder"](inputs["xolp", 0, 0].float(), normals=normals)
+        side = []
+        if self.encoder_streams and (self.opt.augment_xolp or self.opt.augment_normals):
+            # The three encoders are independent until the joint encoder: the shallow XOLP / normals encoders run on
+            # two side streams next to the ResNet on the main one, so the HBM-bound kernels of one encoder (BatchNorm /
+            # ReLU / pool chains) overlap the matrix-bound convolutions of another.  autograd replays every backward
+            # node on its forward stream and inserts the cross-stream waits itself.
+            main = torch.cuda.current_stream()
+            x_in = inputs["xolp", 0, 0].float()
+            if self.opt.augment_xolp:
+                sx = self._encoder_stream(0)
+                sx.wait_stream(main)
+                with torch.cuda.stream(sx):
+                    xolp_feats = self.models["xolp_encoder"](x_in)
+                x_in.record_stream(sx)
+                side.append((sx, xolp_feats))
+            if self.opt.augment_normals:
+                sn = self._encoder_stream(1)
+                sn.wait_stream(main)
+                with torch.cuda.stream(sn):
+                    normals_feats = self.models["normals_encoder"](x_in, normals=normals)
+                x_in.record_stream(sn)
+                if normals is not None:
+                    normals.record_stream(sn)
+                side.append((sn, normals_feats))
+        feats = self.models["rgb_encoder"](inputs["color_aug", 0, 0].float())
+        if side:
+            main = torch.cuda.current_stream()
+            for st, out in side:
+                main.wait_stream(st)
+                for t in (out if isinstance(out, (list, tuple)) else [out]):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
+        else:
+            if self.opt.augment_xolp:
+                xolp_feats = self.models["xolp_encoder"](inputs["xolp", 0, 0].float())
+            if self.opt.augment_normals:
+                normals_feats = self.models["normals_encoder"](inputs["xolp", 0, 0].float(), normals=normals)
         enc_feats = self.models["joint_encoder"](feats[-1], xolp_feats, normals_feats)
         feats = list(feats) + enc_feats
         return dict(self.models['mono_depth'](feats))
+
+    def _encoder_stream(self, i):
+        while len(self._enc_streams) <= i:
+            self._enc_streams.append(torch.cuda.Stream(device=self.device))
+        return self._enc_streams[i]
 
     def process_batch(self, inputs, is_train=False):
         for key, ipt in inputs.items():

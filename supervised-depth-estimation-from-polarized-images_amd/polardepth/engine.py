@@ -85,6 +85,10 @@ class ParamStore:
             check(lib.pd_weight_transpose_batched(ptr(self.flat), ptr(self.flat_t), ptr(self._wt_table), ptr(self._wt_blk),
                                                   self._wt_n, self._wt_blocks, stream_ptr()), "pd_weight_transpose_batched")
             self._wt_epoch = _ops.FWD_EPOCH
+            self._wt_event = torch.cuda.Event()
+            self._wt_event.record()
+        else:
+            torch.cuda.current_stream().wait_event(self._wt_event)   # (backward nodes of other streams ask too)
         return self.flat_t[off:off + co * ci * kh * kw].view(ci, kh, kw, co).permute(0, 3, 1, 2)
 
     def _view(self, buf, p, off):

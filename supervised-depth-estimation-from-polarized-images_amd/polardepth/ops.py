@@ -25,9 +25,14 @@ def _profiled(label, flops, fn, shape=None):
     return r
 
 
-def _igemm_label(M, Co, vec, kind):
+def _igemm_label(M, Co, vec, kind, C=0, KH=1, KW=1, stride=1, pad=0, mode=0):
+    """Profiler label = the kernel family pd_conv2d launches for this call (same rule as launch_conv in conv.hip)."""
     bm = lib.pd_conv2d_tile_m(M, Co)
     bn = 64 if Co > 32 else (32 if Co > 16 else 16)
+    uni = (vec and bn >= 32 and C % 32 == 0 and C > 0 and KH * KW <= 31 and pad < KH and pad < KW and
+           (mode == MODE_ZERO or (mode == MODE_TRANSPOSED and stride == 1)))
+    if uni:
+        return f"conv_igemm_uni_kernel<{bm},{bn}>"
     return f"conv_igemm_kernel<{bm},{bn},{'vec' if vec else 'scalar'}>"
 
 
@@ -95,7 +100,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     sub, div = (affine if affine is not None else (0.0, 1.0))
     sN, sC, sH, sW = x.stride()
     vec = C % 4 == 0 and sC == 1 and affine is None
-    _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd"), 2.0 * N * Ho * Wo * Co * (alg_k if alg_k is not None else C * KH * KW),
+    _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd", C, KH, KW, stride, pad, mode), 2.0 * N * Ho * Wo * Co * (alg_k if alg_k is not None else C * KH * KW),
               lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out_scale), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
                                           Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub,
                                           div, ldy, stream_ptr()), "pd_conv2d"),
@@ -138,7 +143,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None):
     dx = empty_nhwc(N, Ci, H, W, dy.device)
     sN, sC, sH, sW = dy.stride()
     # algorithmic flops of the data gradient = those of the forward conv it differentiates
-    _profiled(_igemm_label(N * H * W, Ci, True, "dgrad"), 2.0 * N * Hy * Wy * Co * Ci * KH * KW,
+    _profiled(_igemm_label(N * H * W, Ci, True, "dgrad", Co, KH, KW, stride, pad, MODE_TRANSPOSED), 2.0 * N * Hy * Wy * Co * Ci * KH * KW,
               lambda: check(lib.pd_conv2d(ptr(dy), ptr(wt), None, None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,
                                           H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci,
                                           stream_ptr()), "pd_conv2d(dgrad)"),
@@ -265,7 +270,7 @@ def gemm_nt(a, b, out=None):
     assert K == Kb and a.is_contiguous() and b.is_contiguous()
     if out is None:
         out = torch.empty((M, Nn), dtype=torch.float32, device=a.device)
-    _profiled(_igemm_label(M, Nn, K % 4 == 0, "gemm"), 2.0 * M * Nn * K,
+    _profiled(_igemm_label(M, Nn, K % 4 == 0, "gemm", K), 2.0 * M * Nn * K,
               lambda: check(lib.pd_conv2d(ptr(a), ptr(b), None, None, ptr(out), None, 1, M, 1, K, M * K, K, K, 1,
                                           M, 1, Nn, 1, 1, 1, 0, MODE_ZERO, ACT_NONE, 0, 0.0, 1.0, out.stride(0),
                                           stream_ptr()), "pd_conv2d(gemm_nt)"))

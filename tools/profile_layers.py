@@ -20,6 +20,7 @@ if __name__ == "__main__":
     for _ in range(2):
         bench.train_step(tr, batch)
     PF.USE_WGRAD_STREAM = False
+    tr.encoder_streams = False
     ops.PROFILE = []
     bench.train_step(tr, batch)
     torch.cuda.synchronize()
