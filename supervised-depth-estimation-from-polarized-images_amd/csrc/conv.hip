@@ -709,7 +709,10 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
         const bool uni = vec && dma && uni_on && a.C % BK == 0 && a.KH * a.KW <= 31 && a.pad < a.KH && a.pad < a.KW &&
                          (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0));
         if (uni) {
-            static const int ns = getenv("PD_CONV_STAGES") ? atoi(getenv("PD_CONV_STAGES")) : 2;
+            // ring depth: 2 for the 128-row tiles (3 workgroups per CU); 3 for the 64x64 tile of the small-M layers, whose
+            // short chunks (16 MFMAs per wave) leave the loads half the time to land: 118 -> 135 TF on 3x3x256 @32x40
+            static const int ns_env = getenv("PD_CONV_STAGES") ? atoi(getenv("PD_CONV_STAGES")) : 0;
+            const int ns = ns_env ? ns_env : (BM == 64 ? 3 : 2);
             if (ns == 2) {
                 if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_ZERO, 2>), grid, block, 0, st, a);
                 else hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_TRANSPOSED, 2>), grid, block, 0, st, a);

@@ -73,6 +73,49 @@ def test_conv_forward_dgrad_wgrad(case):
         _close(dx.cpu(), xr.grad)
 
 
+UNI_CASES = [
+    # N, C, H, W, Co, k, s, p -- shapes the uniform-tap forward / data-gradient kernels and the scalar-pixel
+    # weight-gradient kernel take (C % 32 == 0, zero padding, no bias): full tiles (transposed lean epilogue), pixel
+    # tails, tiles spanning images, stride 2, half-empty k tiles (K = 576, 288), several Cout tiles, pad 0 and 1x1
+    (2, 64, 32, 40, 64, 3, 1, 1),
+    (1, 64, 20, 28, 64, 5, 1, 2),
+    (2, 128, 16, 20, 128, 3, 1, 1),
+    (2, 64, 32, 40, 128, 3, 2, 1),
+    (3, 32, 14, 14, 64, 3, 1, 1),
+    (2, 96, 16, 20, 64, 3, 1, 1),
+    (1, 256, 8, 16, 256, 1, 1, 0),
+    (2, 64, 18, 22, 64, 3, 1, 0),
+    (5, 64, 6, 16, 64, 3, 1, 1),
+    (1, 64, 64, 48, 32, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", UNI_CASES)
+def test_uniform_tap_and_scalar_pixel_kernels(case):
+    N, C, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=s, padding=p)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    y, stats = ops.conv2d_fwd(xd, wd, None, stride=s, pad=p, want_stats=True)
+    _close(y.cpu(), ref.detach())
+    tot = stats.double().sum(0).cpu()
+    rf = ref.detach().double()
+    _close(tot[:, 0], rf.sum((0, 2, 3)), 1e-5)
+    _close(tot[:, 1], (rf ** 2).sum((0, 2, 3)), 1e-5)
+    _close(ops.conv2d_fwd(xd, wd, None, stride=s, pad=p).cpu(), ref.detach())       # without the statistics
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    dw = ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p)
+    _close(dw.cpu(), wr.grad)
+    dx = ops.conv2d_dgrad(dyd, wd, (H, W), stride=s, pad=p)
+    _close(dx.cpu(), xr.grad)
+
+
 def test_conv_nchw_input_with_affine_and_activations():
     g = torch.Generator().manual_seed(7)
     x = torch.rand(2, 3, 24, 32, generator=g)
