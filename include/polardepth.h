@@ -151,7 +151,7 @@ int pd_stem_s2d_weight_grad(const void* dw2, void* dw, int Cout, int C, int accu
 int pd_weight_transpose(const void* w, void* wt, int Cout, int T, int Cin, void* stream);
 /* Every convolution weight of a flat parameter buffer in one launch (the data-gradient operands of a whole step):
  * entry e of `table` (device int32[n][4]) = {element offset in src and dst, Cout, T, Cin}; blk (device int32[n+1]) =
- * first workgroup of entry e at 1024 elements per workgroup, blk[n] = nblocks.  Replaces one pd_weight_transpose per
+ * first workgroup of entry e at T * ceil(Cout/32) * ceil(Cin/32) workgroups per entry, blk[n] = nblocks.  Replaces one pd_weight_transpose per
  * layer and step (the reference keeps no such copy: cuDNN's backward-data reads the forward filter, trainer.py:430). */
 int pd_weight_transpose_batched(const void* src, void* dst, const void* table, const void* blk, int n, int nblocks,
                                 void* stream);

@@ -1358,31 +1358,33 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
 }
 
 // All convolution weights of a parameter store in one launch: entry e = {element offset in both flat buffers, Co, T, Ci},
-// blk[e] = first workgroup of entry e (1024 elements per workgroup), blk[n] = grid size.
+// blk[e] = first workgroup of entry e, one workgroup per 32(co) x 32(ci) tile of one tap (LDS transpose: 128-byte
+// rows on both sides), blk[n] = grid size.
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                                        const int* __restrict__ table,
                                                                        const int* __restrict__ blk, int n) {
+    __shared__ float tile[32][33];
     int lo = 0, hi = n;                         // last e with blk[e] <= blockIdx.x
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (blk[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
     }
     const int off = table[4 * lo], Co = table[4 * lo + 1], T = table[4 * lo + 2], Ci = table[4 * lo + 3];
-    const int cnt = Co * T * Ci;
     const float* w = src + off;
     float* wt = dst + off;
-    const int base = ((int)blockIdx.x - blk[lo]) * 1024;
+    int lb = (int)blockIdx.x - blk[lo];
+    const int tiles_ci = (Ci + 31) >> 5, tiles_co = (Co + 31) >> 5;
+    const int ci0 = (lb % tiles_ci) << 5; lb /= tiles_ci;
+    const int co0 = (lb % tiles_co) << 5;
+    const int t = lb / tiles_co;
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = base + j * 256 + (int)threadIdx.x;
-        if (i < cnt) {
-            const int co = i % Co;
-            const int r = i / Co;
-            const int t = r % T;
-            const int ci = r / T;
-            wt[i] = w[(co * T + t) * Ci + ci];
-        }
-    }
+    for (int r = y; r < 32; r += 8)
+        if (co0 + r < Co && ci0 + x < Ci) tile[r][x] = w[((long)(co0 + r) * T + t) * Ci + ci0 + x];
+    __syncthreads();
+#pragma unroll
+    for (int r = y; r < 32; r += 8)
+        if (ci0 + r < Ci && co0 + x < Co) wt[((long)(ci0 + r) * T + t) * Co + co0 + x] = tile[x][r];
 }
 
 inline int wgrad_tco(int Co) { return Co > 32 ? 64 : (Co > 16 ? 32 : 16); }

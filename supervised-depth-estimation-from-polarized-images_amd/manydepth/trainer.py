@@ -311,6 +311,7 @@ class Trainer:
     def _encoder_stream(self, i):
         while len(self._enc_streams) <= i:
             self._enc_streams.append(torch.cuda.Stream(device=self.device))
+            PF.register_producer_stream(self._enc_streams[-1])      # the gradient reducer / Adam wait for it too
         return self._enc_streams[i]
 
     def process_batch(self, inputs, is_train=False):

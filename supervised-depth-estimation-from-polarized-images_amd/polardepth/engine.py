@@ -59,7 +59,7 @@ class ParamStore:
                 co, ci, kh, kw = p.shape
                 self._wt_index[self.flat.data_ptr() + 4 * off] = (off, co, ci, kh, kw)
                 rows.append([off, co, kh * kw, ci])
-                blk.append(blk[-1] + (p.numel() + 1023) // 1024)
+                blk.append(blk[-1] + kh * kw * ((co + 31) // 32) * ((ci + 31) // 32))   # one workgroup per 32x32 tile and tap
         if rows:
             self._wt_table = torch.tensor(rows, dtype=torch.int32, device=device)
             self._wt_blk = torch.tensor(blk, dtype=torch.int32, device=device)

@@ -55,10 +55,21 @@ def wgrad_stream(device):
     return st
 
 
+_PRODUCER_STREAMS = []      # further streams that write parameter gradients (the trainer's encoder streams)
+
+
+def register_producer_stream(st):
+    if all(st is not q for q in _PRODUCER_STREAMS):
+        _PRODUCER_STREAMS.append(st)
+
+
 def sync_wgrad_stream(stream=None):
-    """Make `stream` (default: the current one) wait for all weight-gradient kernels issued so far."""
-    for st in _WGRAD_STREAMS.values():
-        (stream or torch.cuda.current_stream()).wait_stream(st)
+    """Make `stream` (default: the current one) wait for all gradient-producing side streams: the weight-gradient
+    stream and the registered encoder streams (a gradient bucket of the reducer may span encoders)."""
+    target = stream or torch.cuda.current_stream()
+    for st in list(_WGRAD_STREAMS.values()) + _PRODUCER_STREAMS:
+        if st is not target and st != target:
+            target.wait_stream(st)
 
 
 _join_queued = False

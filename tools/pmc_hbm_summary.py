@@ -20,6 +20,9 @@ def short(name):
     m = re.match(r"conv_igemm_kernel<(\d+), (\d+), \d+, \d+, (true|false), \d+(?:, (?:true|false))?>", name)
     if m:
         return f"conv_igemm_kernel<{m.group(1)},{m.group(2)},{'vec' if m.group(3) == 'true' else 'scalar'}>"
+    m = re.match(r"conv_igemm_uni_kernel<(\d+), (\d+), \d+, \d+, \d+, \d+>", name)
+    if m:                      # forward and data-gradient instantiations of one tile share bench.py's label
+        return f"conv_igemm_uni_kernel<{m.group(1)},{m.group(2)}>"
     return name.split("(")[0]
 
 
@@ -45,9 +48,12 @@ if __name__ == "__main__":
                       "hbm_bytes_per_launch": int((2 * f + w) * 1024), "launches": n}
     conv = {k: v for k, v in kernels.items() if k.startswith("conv_")}
     dom = max(conv.items(), key=lambda kv: kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[0] if conv else None
-    dom = "conv_igemm_kernel<128,64,vec>" if "conv_igemm_kernel<128,64,vec>" in kernels else dom
+    for pref in ("conv_igemm_uni_kernel<128,64>", "conv_igemm_kernel<128,64,vec>"):   # bench.py's dominant label
+        if pref in kernels:
+            dom = pref
+            break
     out = {"_about": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- "
-                     "PD_WGRAD_STREAM=0 python bench.py --steps 1 --warmup 1 --no_cpu_baseline; KB per launch (mean over "
+                     "PD_WGRAD_STREAM=0 PD_ENCODER_STREAMS=0 python bench.py --steps 1 --warmup 1 --no_cpu_baseline; KB per launch (mean over "
                      "the launches of the run); hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                      "(tools/pmc_hbm_summary.py)",
            "dominant": {"kernel": dom, **({"hbm_bytes_per_launch": kernels[dom]["hbm_bytes_per_launch"],
