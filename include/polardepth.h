@@ -127,6 +127,14 @@ int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_sc
               int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode, int act,
               int affine, float sub, float div, long ldy, void* stream);
 
+/* y = conv(x, w) + addend: the same convolution (no bias / scale / activation / statistics) with an NHWC tensor of the
+ * output's shape (row stride ld_add, may alias y) added in the epilogue.  Used for the data gradient of the first
+ * convolution of a residual block, which autograd would otherwise sum with the gradient of the skip connection in a
+ * separate pass (the reference: torch's `out += identity` backward, pre_encoders.py:46, torchvision BasicBlock). */
+int pd_conv2d_add(const void* x, const void* w, const void* addend, long ld_add, void* y,
+                  int N, int H, int W, int C, long sN, long sH, long sW, long sC,
+                  int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode, long ldy, void* stream);
+
 /* Weight gradient dW[Cout][KH][KW][Cin] (+ optional dbias[Cout]) of the convolution above
  * (modes 0 and 1).  dy is NHWC on the output grid with row stride ldd.  Partial tiles go to
  * `workspace` (pd_conv2d_wgrad_workspace bytes) and are summed deterministically; accumulate != 0

@@ -43,6 +43,8 @@ struct ConvArgs {
     const float* oscale;     // per-output-channel multiplier of the accumulator (folded BatchNorm) or null
     float* y;
     float* stats;            // [gridM][Co][2] or null
+    const float* add;        // NHWC tensor added to the result before the store (row stride ld_add) or null; may alias y
+    long ld_add;
     int N, H, W, C;          // logical dims of x
     long sN, sH, sW, sC;     // element strides of x
     int Ho, Wo, Co;          // output grid / channels
@@ -124,11 +126,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[WM 
         // work shrinks to the two statistics updates -- on this chip every VALU instruction is taken from the
         // matrix pipe of the other workgroups on the SIMD (tools/mfma_peak.hip).
         const bool lean = a.M - m0 >= BM && n0 + BN <= a.Co && !a.bias && !a.oscale && a.act == ACT_NONE &&
-                          (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0;
+                          (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
+                          (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0));
         if (lean) {
             float* T = scratch + wave * (WM * WN);                 // [WM][32] floats, private to the wave
             red = reinterpret_cast<float (*)[WN][2]>(scratch + 4 * WM * WN);
             const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+            // addend (the residual gradient a data gradient is summed with): its loads fly during the transposition
+            float4 addv[WM / 8];
+            if (a.add) {
+                const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.add + m0 * a.ld_add, (unsigned)((long)BM * a.ld_add * 4));
+                const unsigned off_a = (unsigned)((wm * WM + (lane >> 3)) * (int)a.ld_add + n0 + wn * WN + 4 * (lane & 7)) * 4u;
+#pragma unroll
+                for (int t = 0; t < WM / 8; ++t) addv[t] = buf_ld4(ra, off_a + (unsigned)(t * 8 * (int)a.ld_add * 4));
+            }
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -144,7 +155,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[WM 
             const float4* Tq = reinterpret_cast<const float4*>(T) + lane;      // row lane/8, column quad lane%8
 #pragma unroll
             for (int t = 0; t < WM / 8; ++t) {
-                const float4 v = Tq[t * 64];
+                float4 v = Tq[t * 64];
+                if (a.add) { v.x += addv[t].x; v.y += addv[t].y; v.z += addv[t].z; v.w += addv[t].w; }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, off_l, t * 8 * (int)a.ldy * 4, 0);
             }
             if (a.stats) {
@@ -179,6 +191,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[WM 
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)rows * a.ldy * 4));
         const __amdgpu_buffer_rsrc_t rb_ = make_rsrc(a.bias ? a.bias : a.w, a.bias ? (unsigned)a.Co * 4u : 0u);
         const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(a.oscale ? a.oscale : a.w, a.oscale ? (unsigned)a.Co * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t ra_ = make_rsrc(a.add ? a.add + m0 * a.ld_add : a.w, a.add ? (unsigned)((long)rows * a.ld_add * 4) : 0u);
         auto body = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
@@ -203,6 +216,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, AccT (&acc)[WM 
                         if (ACT == ACT_RELU) v = fmaxf(v, 0.f);
                         else if (ACT == ACT_ELU) v = v > 0.f ? v : expm1f(v);
                         else if (ACT == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                        if (a.add) v += buf_ld1(ra_, ok ? (unsigned)((row_l + rr) * (int)a.ld_add + col) * 4u : OOB);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, ok ? off_l : OOB,
                                                               rr * (int)a.ldy * 4, 0);
                     }
@@ -755,10 +769,33 @@ extern "C" long pd_conv2d_stats_rows(long M, int Co) {
     return (M + bm - 1) / bm;
 }
 
+static int conv2d_impl(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
+                       const void* addend, long ld_add,
+                       int N, int H, int W, int C, long sN, long sH, long sW, long sC,
+                       int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
+                       int affine, float sub, float div, long ldy, void* stream);
+
 extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
                          int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                          int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
                          int affine, float sub, float div, long ldy, void* stream) {
+    return conv2d_impl(x, w, bias, out_scale, y, stats, nullptr, 0, N, H, W, C, sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride,
+                       pad, mode, act, affine, sub, div, ldy, stream);
+}
+
+extern "C" int pd_conv2d_add(const void* x, const void* w, const void* addend, long ld_add, void* y,
+                             int N, int H, int W, int C, long sN, long sH, long sW, long sC,
+                             int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, long ldy, void* stream) {
+    PD_REQUIRE(addend && ld_add >= Co, "pd_conv2d_add: bad addend");
+    return conv2d_impl(x, w, nullptr, nullptr, y, nullptr, addend, ld_add, N, H, W, C, sN, sH, sW, sC, Ho, Wo, Co, KH, KW,
+                       stride, pad, mode, ACT_NONE, 0, 0.f, 1.f, ldy, stream);
+}
+
+static int conv2d_impl(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
+                       const void* addend, long ld_add,
+                       int N, int H, int W, int C, long sN, long sH, long sW, long sC,
+                       int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
+                       int affine, float sub, float div, long ldy, void* stream) {
     PD_REQUIRE(x && w && y, "pd_conv2d: null tensor");
     PD_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && Co > 0, "pd_conv2d: bad dims");
     PD_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "pd_conv2d: bad filter geometry");
@@ -779,6 +816,7 @@ extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, const v
     if (N == 0) return PD_OK;
     ConvArgs a;
     a.x = (const float*)x; a.w = (const float*)w; a.bias = (const float*)bias; a.oscale = (const float*)out_scale; a.y = (float*)y; a.stats = (float*)stats;
+    a.add = (const float*)addend; a.ld_add = ld_add;
     a.N = N; a.H = H; a.W = W; a.C = C; a.sN = sN; a.sH = sH; a.sW = sW; a.sC = sC;
     a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.mode = mode; a.act = act; a.affine = affine; a.sub = sub; a.div = div;

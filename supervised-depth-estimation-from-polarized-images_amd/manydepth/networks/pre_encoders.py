@@ -36,10 +36,10 @@ class ConvBlock(nn.Module):
         self.stride, self.padding = stride, padding
         self.in_affine = None          # (sub, div) folded into the conv gather (ShallowEncoder.normalizeInput)
 
-    def forward(self, x, res=None):
+    def forward(self, x, res=None, skip_in=None, skip_out=None):
         cfg = PF.ChainCfg(stride=self.stride, pad=self.padding, relu_pre=True,
                           pool=self.downsampling_mode == 'maxpool', drop_p=self.dropout.p, relu_post=False,
-                          affine=self.in_affine)
+                          affine=self.in_affine, skip_in=skip_in, skip_out=skip_out)
         return PF.conv_bn_chain(x, self.conv, self.bn, cfg, res=res, training=self.training)
 
 
@@ -52,7 +52,9 @@ class ResidualBlock(nn.Module):
         self.conv2 = ConvBlock(channels, channels, kernel_size, 'none', padding, dropout)
 
     def forward(self, x):
-        return self.conv2(self.conv1(x), res=x)
+        # both convolutions read x: the skip gradient rides in the first convolution's data-gradient epilogue
+        mail = PF.SkipGrad() if (torch.is_grad_enabled() and x.requires_grad) else None
+        return self.conv2(self.conv1(x, skip_in=mail), res=x, skip_out=mail)
 
 
 class ShallowEncoder(nn.Module):

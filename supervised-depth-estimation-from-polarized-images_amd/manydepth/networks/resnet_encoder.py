@@ -39,13 +39,17 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         tr = self.training
-        y = PF.conv_bn_chain(x, self.conv1, self.bn1, PF.ChainCfg(stride=self.stride, pad=1, relu_pre=True), training=tr)
+        # identity blocks: conv1 and the skip read the same x -- the skip gradient rides in conv1's data-gradient epilogue
+        mail = PF.SkipGrad() if (self.downsample is None and torch.is_grad_enabled() and x.requires_grad) else None
+        y = PF.conv_bn_chain(x, self.conv1, self.bn1, PF.ChainCfg(stride=self.stride, pad=1, relu_pre=True, skip_in=mail),
+                             training=tr)
         idt = x
         if self.downsample is not None:
             idt = PF.conv_bn_chain(x, self.downsample[0], self.downsample[1],
                                    PF.ChainCfg(stride=self.stride, pad=0, relu_pre=False), training=tr)
         # bn2 -> + identity -> relu
-        return PF.conv_bn_chain(y, self.conv2, self.bn2, PF.ChainCfg(stride=1, pad=1, relu_pre=False, relu_post=True),
+        return PF.conv_bn_chain(y, self.conv2, self.bn2,
+                                PF.ChainCfg(stride=1, pad=1, relu_pre=False, relu_post=True, skip_out=mail),
                                 res=idt, training=tr)
 
 

@@ -145,14 +145,33 @@ class BNParams:
         self.eps = bn.eps
 
 
-class ChainCfg:
-    __slots__ = ("stride", "pad", "relu_pre", "pool", "drop_p", "relu_post", "affine", "bn", "seed", "offset", "infer")
+class SkipGrad:
+    """Mailbox of a residual block: the backward pass of the block's LAST convolution deposits the gradient of the skip
+    connection here instead of returning it; the backward pass of the block's FIRST convolution (which autograd runs
+    later: its output feeds the last one) adds it in the epilogue of its data-gradient kernel.  Both convolutions read
+    the same block input, so the sum is exactly what autograd would have formed with a separate add kernel."""
+    __slots__ = ("grad",)
 
-    def __init__(self, stride=1, pad=0, relu_pre=True, pool=False, drop_p=0.0, relu_post=False, affine=None, bn=None):
+    def __init__(self):
+        self.grad = None
+
+
+USE_SKIP_FUSION = os.environ.get("PD_SKIP_FUSION", "1") != "0"
+
+
+class ChainCfg:
+    __slots__ = ("stride", "pad", "relu_pre", "pool", "drop_p", "relu_post", "affine", "bn", "seed", "offset", "infer",
+                 "skip_out", "skip_in")
+
+    def __init__(self, stride=1, pad=0, relu_pre=True, pool=False, drop_p=0.0, relu_post=False, affine=None, bn=None,
+                 skip_out=None, skip_in=None):
         self.stride, self.pad, self.relu_pre, self.pool = stride, pad, relu_pre, pool
         self.drop_p, self.relu_post, self.affine, self.bn = float(drop_p), relu_post, affine, bn
         self.seed = self.offset = 0
         self.infer = False
+        # SkipGrad mailboxes: skip_out on the convolution whose `res` is the block input, skip_in on the convolution
+        # that consumes the block input directly (only when both see the SAME tensor)
+        self.skip_out, self.skip_in = (skip_out, skip_in) if USE_SKIP_FUSION else (None, None)
 
 
 # ------------------------------------------------------------------ conv -> BN -> ReLU -> pool -> dropout -> +res -> ReLU
@@ -280,6 +299,9 @@ class ConvBNChainFn(torch.autograd.Function):
               "pd_chain_bwd_apply")
         if ctx.has_res and not cfg.relu_post and ctx.needs_input_grad[5]:
             dres = dy                     # out = f(x) + res: the residual gradient is dy itself
+        if dres is not None and cfg.skip_out is not None and dres.stride(1) == 1:
+            cfg.skip_out.grad = dres      # summed into the data gradient of the block's first convolution instead
+            dres = None
         if weight.requires_grad:
             # the bias feeds a BatchNorm: its gradient is identically zero (mean subtraction)
             gw = grad_buf(weight)
@@ -297,7 +319,14 @@ class ConvBNChainFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.s2d:
                 raise NotImplementedError("input gradient of a space-to-depth stem (stems read data, not activations)")
-            dx = ops.conv2d_dgrad(dz, weight, (x.shape[2], x.shape[3]), cfg.stride, cfg.pad)
+            skip = None
+            if cfg.skip_in is not None:
+                skip, cfg.skip_in.grad = cfg.skip_in.grad, None
+                if skip is not None and tuple(skip.shape) != tuple(x.shape):
+                    raise RuntimeError("SkipGrad: the skip gradient does not have the block input's shape")
+            dx = ops.conv2d_dgrad(dz, weight, (x.shape[2], x.shape[3]), cfg.stride, cfg.pad, addend=skip)
+        elif cfg.skip_in is not None and cfg.skip_in.grad is not None:
+            raise RuntimeError("SkipGrad: a skip gradient was deposited but the block input needs no gradient")
         for p in (weight, bias, gamma, beta):
             if p is not None:
                 _ready(p)

@@ -131,8 +131,11 @@ def weight_transposed(w):
     return wt
 
 
-def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None):
-    """dX of a zero-padded convolution: transposed convolution of dy (NHWC) with w."""
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
+    """dX of a zero-padded convolution: transposed convolution of dy (NHWC) with w.
+
+    addend: optional tensor of dX's shape (channel stride 1) that is added in the kernel's epilogue -- the gradient of a
+    residual block's skip connection, which autograd would otherwise add in a separate pass."""
     _require_cuda(dy, w)
     dy = as_nhwc(dy)
     N, Co, Hy, Wy = dy.shape
@@ -142,6 +145,17 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None):
         wt = weight_transposed(w)
     dx = empty_nhwc(N, Ci, H, W, dy.device)
     sN, sC, sH, sW = dy.stride()
+    if addend is not None:
+        assert addend.shape == dx.shape and addend.stride(1) == 1 and addend.is_cuda
+        ld_add = addend.stride(3)
+        assert addend.stride(2) == W * ld_add and addend.stride(0) == H * W * ld_add
+        _profiled(_igemm_label(N * H * W, Ci, True, "dgrad", Co, KH, KW, stride, pad, MODE_TRANSPOSED),
+                  2.0 * N * Hy * Wy * Co * Ci * KH * KW,
+                  lambda: check(lib.pd_conv2d_add(ptr(dy), ptr(wt), ptr(addend), ld_add, ptr(dx), N, Hy, Wy, Co, sN, sH, sW,
+                                                  sC, H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, Ci, stream_ptr()),
+                                "pd_conv2d_add(dgrad)"),
+                  shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))
+        return dx
     # algorithmic flops of the data gradient = those of the forward conv it differentiates
     _profiled(_igemm_label(N * H * W, Ci, True, "dgrad", Co, KH, KW, stride, pad, MODE_TRANSPOSED), 2.0 * N * Hy * Wy * Co * Ci * KH * KW,
               lambda: check(lib.pd_conv2d(ptr(dy), ptr(wt), None, None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,

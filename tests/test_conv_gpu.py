@@ -116,6 +116,32 @@ def test_uniform_tap_and_scalar_pixel_kernels(case):
     _close(dx.cpu(), xr.grad)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 32, 40, 64, 3, 1, 1), (1, 64, 20, 28, 64, 5, 1, 2), (2, 16, 9, 11, 24, 3, 1, 1),
+                                  (2, 64, 16, 20, 128, 3, 2, 1)])
+def test_data_gradient_with_addend_in_the_epilogue(case):
+    """pd_conv2d_add: dX = dgrad(dY, W) + addend in one kernel (full tiles: transposed epilogue; tails and the
+    general kernel: element-wise), for a separate addend and for a strided view of a wider buffer."""
+    N, C, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5
+    ref = F.conv2d(x, w, None, stride=s, padding=p)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    add = torch.randn(N, C, H, W, generator=g)
+    expect = x.grad + add
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    addd = add.cuda().contiguous(memory_format=torch.channels_last)
+    dx = ops.conv2d_dgrad(dyd, wd, (H, W), stride=s, pad=p, addend=addd)
+    _close(dx.cpu(), expect)
+    assert torch.equal(addd.cpu(), add)                       # the addend itself is left alone
+    wide = torch.zeros(N, C + 8, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    wide[:, 4:4 + C] = addd
+    dx2 = ops.conv2d_dgrad(dyd, wd, (H, W), stride=s, pad=p, addend=wide[:, 4:4 + C])
+    _close(dx2.cpu(), expect)
+
+
 def test_conv_nchw_input_with_affine_and_activations():
     g = torch.Generator().manual_seed(7)
     x = torch.rand(2, 3, 24, 32, generator=g)
