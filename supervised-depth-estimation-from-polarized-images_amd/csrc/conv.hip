@@ -515,7 +515,9 @@ __device__ __forceinline__ void pieces(F& f, D dst) {
 
 template <int BM, int BN, int WM, int WN, int MODE, int NS>
 __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
-    static_assert(MODE == MODE_ZERO || MODE == MODE_TRANSPOSED, "uniform-tap kernel: zero padding or stride-1 data gradient");
+    // MODE_REFLECT (the decoder's ReflectionPad2d(1) + Conv3x3): no tap is ever invalid, but a border row's offset is
+    // not linear in the tap.  The per-row offsets of the CURRENT tap are recomputed on the VALU only when the tap
+    // changes (every C/32 chunks, a uniform branch); the pieces then take them as they are -- no VALU per piece.
     constexpr int MT = 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / MT, TN = WN / MT;
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
     // Descriptor of the activation: first image of the tile, moved back by the padding (zero mode) or by the part of
     // the filter extent the padding does not cover (data gradient, taps walk backwards) -- see the offsets below.
     const int img0 = (int)(m0 / hw);
-    const long shift = MODE == MODE_ZERO ? (long)a.pad * (a.sH + a.sW)
+    const long shift = MODE == MODE_REFLECT ? 0L : MODE == MODE_ZERO ? (long)a.pad * (a.sH + a.sW)
                                          : (long)(a.KH - 1 - a.pad) * a.sH + (long)(a.KW - 1 - a.pad) * a.sW;
     const long rest = (((long)a.N - img0) * a.sN + shift) * 4;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
@@ -555,6 +557,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
     const unsigned col4 = 16u * ((tid & 7) ^ ((prow >> 1) & 7)); // byte offset of its LOGICAL 16-byte slot (swizzle at the source)
     const unsigned ones_kw = (1u << a.KW) - 1u;
     unsigned va[A_IT], inv[A_IT], vb[B_IT];
+    int rfh[MODE == MODE_REFLECT ? A_IT : 1], rfw[MODE == MODE_REFLECT ? A_IT : 1];   // reflect: oh*stride - pad, ow*stride - pad
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const long m = m0 + prow + 32 * i;
@@ -563,6 +566,12 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
         const unsigned rem = mr - dn * (unsigned)hw;
         const int oh = (int)magic_div(rem, a.mg_wo, a.sh_wo);
         const int ow = (int)rem - oh * a.Wo;
+        if constexpr (MODE == MODE_REFLECT) {
+            va[i] = (unsigned)((int)dn * (int)a.sN) * 4u + col4;      // image base; the pixel part follows the tap
+            rfh[i] = oh * a.stride - a.pad; rfw[i] = ow * a.stride - a.pad;
+            inv[i] = m < a.M ? 0u : 0xffffffffu;
+            continue;
+        }
         va[i] = (unsigned)((int)dn * (int)a.sN + oh * a.stride * (int)a.sH + ow * a.stride * (int)a.sW) * 4u + col4;
         // taps outside the image, per dimension: a prefix [0, lo) and a suffix [hi, K) of the tap range
         int lo_h, hi_h, lo_w, hi_w;
@@ -594,15 +603,32 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
     const int dW4 = (MODE == MODE_ZERO ? (int)a.sW : -(int)a.sW) * 4, dH4 = (MODE == MODE_ZERO ? (int)a.sH : -(int)a.sH) * 4;
     const int nchunks = a.K / BK;          // K % 32 == 0 on this path
     int s_q = 0, s_tap = 0, s_kw = 0, s_c = 0;
-    unsigned s_aoff = MODE == MODE_ZERO ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
+    unsigned s_aoff = MODE != MODE_TRANSPOSED ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
     unsigned s_boff = 0;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
     const unsigned m0_a = lds0 + 1024u * (unsigned)wave, m0_b = lds0 + B_BASE + 1024u * (unsigned)wave;
 
+    // reflect: byte offsets of the rows for the tap (s_kh, s_kw), redone when the tap changes
+    unsigned vr[MODE == MODE_REFLECT ? A_IT : 1];
+    int s_kh = 0;
+    auto reflect_rows = [&]() {
+        if constexpr (MODE == MODE_REFLECT) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                int ih = rfh[i] + s_kh, iw = rfw[i] + s_kw;
+                ih = ih < 0 ? -ih : ih; ih = ih >= a.H ? 2 * a.H - 2 - ih : ih;
+                iw = iw < 0 ? -iw : iw; iw = iw >= a.W ? 2 * a.W - 2 - iw : iw;
+                vr[i] = inv[i] ? OOB : va[i] + (unsigned)(ih * (int)a.sH + iw * (int)a.sW) * 4u;
+            }
+        }
+    };
+    reflect_rows();
     auto load_piece = [&](auto dst_tag, auto piece_tag) {
         constexpr unsigned DST = decltype(dst_tag)::value;
         constexpr int P = decltype(piece_tag)::value;
-        if constexpr (P < A_IT) {
+        if constexpr (P < A_IT && MODE == MODE_REFLECT) {
+            dma16s(rx, m0_a + DST * A_BYTES + 4096u * P, vr[P], s_aoff);      // s_aoff = channel chunk inside the tap
+        } else if constexpr (P < A_IT) {
             const unsigned bad = __builtin_amdgcn_ubfe(inv[P], (unsigned)s_tap, 1u);
             dma16s(rx, m0_a + DST * A_BYTES + 4096u * P, (bad << 31) + va[P], s_aoff);
         } else {
@@ -611,6 +637,16 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
     };
     auto advance_chunk = [&]() {
         ++s_q;
+        if constexpr (MODE == MODE_REFLECT) {
+            s_boff += BK * 4; s_aoff += BK * 4; s_c += BK;
+            if (s_q >= nchunks) { s_boff = 0; s_aoff = 0; s_c = 0; }     // ring run-out: re-read chunk 0 of the last tap (harmless)
+            else if (s_c == a.C) {
+                s_c = 0; s_aoff = 0;
+                if (++s_kw == a.KW) { s_kw = 0; ++s_kh; }
+                reflect_rows();
+            }
+            return;
+        }
         s_boff += BK * 4; s_aoff += BK * 4; s_c += BK;
         if (s_c == a.C) {
             s_c = 0; ++s_tap; s_aoff += (unsigned)(dW4 - a.C * 4);
@@ -721,7 +757,11 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
     static const bool uni_on = !(getenv("PD_CONV_UNI") && getenv("PD_CONV_UNI")[0] == '0');  // uniform-tap kernel (default on)
     if constexpr (BN % 32 == 0 && WN == 32) {
         const bool uni = vec && dma && uni_on && a.C % BK == 0 && a.KH * a.KW <= 31 && a.pad < a.KH && a.pad < a.KW &&
-                         (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0));
+                         (a.mode == MODE_ZERO || a.mode == MODE_REFLECT || (a.mode == MODE_TRANSPOSED && a.sshift == 0));
+        if (uni && a.mode == MODE_REFLECT) {       // (pad < H, W is checked by pd_conv2d)
+            hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_REFLECT, 2>), grid, block, 0, st, a);
+            return pd::check_launch("pd_conv2d");
+        }
         if (uni) {
             // ring depth: 2 for the 128-row tiles (3 workgroups per CU); 3 for the 64x64 tile of the small-M layers, whose
             // short chunks (16 MFMAs per wave) leave the loads half the time to land: 118 -> 135 TF on 3x3x256 @32x40

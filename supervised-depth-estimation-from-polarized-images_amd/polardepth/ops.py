@@ -30,7 +30,7 @@ def _igemm_label(M, Co, vec, kind, C=0, KH=1, KW=1, stride=1, pad=0, mode=0):
     bm = lib.pd_conv2d_tile_m(M, Co)
     bn = 64 if Co > 32 else (32 if Co > 16 else 16)
     uni = (vec and bn >= 32 and C % 32 == 0 and C > 0 and KH * KW <= 31 and pad < KH and pad < KW and
-           (mode == MODE_ZERO or (mode == MODE_TRANSPOSED and stride == 1)))
+           (mode in (MODE_ZERO, MODE_REFLECT) or (mode == MODE_TRANSPOSED and stride == 1)))
     if uni:
         return f"conv_igemm_uni_kernel<{bm},{bn}>"
     return f"conv_igemm_kernel<{bm},{bn},{'vec' if vec else 'scalar'}>"
