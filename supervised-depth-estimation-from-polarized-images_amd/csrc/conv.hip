@@ -1157,14 +1157,16 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 //   * dY rows are contiguous: four pixels per instruction, scalar row offset, the slice end is the descriptor's end;
 //   * unpadded LDS rows; the two pixels of an MFMA step sit 64/128 floats apart, so odd pixels store their row
 //     XOR 32 floats (applied to the source address of the DMA) -- conflict-free ds_read_b32 fragments.
-// Per chunk and wave: 32 MFMAs, 48 ds_read_b32, 6 LDS-DMA issues, 8 VALU.  (Layers with a bias gradient -- the decoder's
-// reflection-padded convolutions -- stay on the kernel above.)
+// Per chunk and wave: 32 MFMAs, 48 ds_read_b32, 6 LDS-DMA issues, 8 VALU.
 struct WgradUniArgs {
     WgradArgs g;
     int nb, nbw;          // border rows / border pixel pairs that can hold an invalid tap
 };
 
-template <int DUMMY>
+// REFLECT (ReflectionPad2d(1) + Conv3x3, the decoder): no tap is invalid; a lane whose tap leaves the image for the
+// pair's row / column gets +-2 rows / columns added, selected by four scalar flags of the pair (top, bottom, first,
+// last column): 6 VALU per X piece instead of 2.  BIAS: the kt == 0 tiles also sum dY over their pixels.
+template <bool REFLECT, bool BIAS>
 __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs ua) {
     const WgradArgs& a = ua.g;
     constexpr int TCO = 64, MT = 32, TK = 2;
@@ -1197,13 +1199,22 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
     // ---- per-lane invariants
     // X: lane -> (pixel of the pair = lane/32, physical 16-byte slot = lane%32, logical slot = slot ^ 8*(pixel&1))
     const int xh = lane >> 5;
-    const int kx = k0 + 4 * ((lane & 31) ^ (8 * xh));
+    const int kx0 = k0 + 4 * ((lane & 31) ^ (8 * xh));
+    const int kx = REFLECT ? min(kx0, a.K - 4) : kx0;   // reflect: lanes past K re-read the last columns (never stored)
     const int tap = kx / a.C;
     const int xc = kx - tap * a.C, xkh = tap / a.KW, xkw = tap - xkh * a.KW;
     const unsigned vx = (unsigned)(xkh * (int)a.sH + (xkw + xh * a.stride) * (int)a.sW + xc) * 4u;
     const int ncw = 2 * ua.nbw + 1;
+    // reflect corrections of this lane's tap (pad 1, 3x3, stride 1): row -1 -> 1, row H -> H-2, same for columns; the
+    // column flags refer to the pair's first pixel, so they apply to one half-wave each
+    const unsigned c_top = REFLECT && xkh == 0 ? (unsigned)(2 * (int)a.sH * 4) : 0u;
+    const unsigned c_bot = REFLECT && xkh == 2 ? (unsigned)(-2 * (int)a.sH * 4) : 0u;
+    const unsigned c_left = REFLECT && xkw == 0 && xh == 0 ? (unsigned)(2 * (int)a.sW * 4) : 0u;
+    const unsigned c_right = REFLECT && xkw == 2 && xh == 1 ? (unsigned)(-2 * (int)a.sW * 4) : 0u;
     unsigned xmask = 0x80000000u;                                    // bit 31: the "beyond the tensor" class
-    if (kx < a.K) {
+    if (REFLECT) {
+        xmask = 0;
+    } else if (kx < a.K) {
         for (int ch = 0; ch <= 2 * ua.nb; ++ch) {
             const int oh = ch <= ua.nb ? ch : a.Ho - ua.nb + (ch - ua.nb - 1);
             const bool bad_h = (unsigned)(oh * a.stride - a.pad + xkh) >= (unsigned)a.H;
@@ -1257,9 +1268,19 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
             const int ch = min(s_oh, ua.nb) + max(s_oh - (a.Ho - ua.nb) + 1, 0);
             const int pw = s_ow >> 1;
             const int cw = min(pw, ua.nbw) + max(pw - ((a.Wo >> 1) - ua.nbw) + 1, 0);
+            if constexpr (REFLECT) {
+                // pairs past the slice read an interior pair instead (their dY rows are zero): nothing leaves the tensor
+                const bool live = s_p < nrows;
+                const unsigned f_t = live && s_oh == 0 ? ~0u : 0u, f_b = live && s_oh == a.Ho - 1 ? ~0u : 0u;
+                const unsigned f_l = live && s_ow == 0 ? ~0u : 0u, f_r = live && s_ow == a.Wo - 2 ? ~0u : 0u;
+                const unsigned voff = vx + (f_t & c_top) + (f_b & c_bot) + ((f_l & c_left) + (f_r & c_right));
+                dma16s(rx, m0_x + DST * X_BYTES + J * 2 * X_ROW, voff,
+                       live ? (unsigned)s_soff : (unsigned)((int)a.sH + 2 * (int)a.sW) * 4u);
+            } else {
             const unsigned cls = (unsigned)(ch * ncw + cw) | (s_p < nrows ? 0u : 31u);   // (classes are < 31)
             const unsigned bad = __builtin_amdgcn_ubfe(xmask, cls, 1u);
             dma16s(rx, m0_x + DST * X_BYTES + J * 2 * X_ROW, (bad << 31) + vx, (unsigned)s_soff);
+            }
             // Pixel bookkeeping as selects, not branches: straight-line scalar code that the scheduler can slide under
             // the 64-cycle MFMAs around it (a branchy version costs the wave ~150 cycles per piece with nothing issued).
             constexpr int STEP = J < 3 ? 2 : WG_MC - 6;        // next pair of the row / this wave's first pair of the next chunk
@@ -1300,6 +1321,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
     for (int t = 0; t < TK; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = BIAS && a.bpart != nullptr && kt == 0;
 
     // One chunk: the MFMAs of buffer BUF; the six pieces of the next chunk go out between the four fragment groups,
     // in the shadow of the wave's own MFMAs.  HALF (compile time: the two loops below never meet inside a chunk, or
@@ -1350,6 +1373,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
                 else pieces<3, 6>(load_piece, dst);
             }
         }
+        if constexpr (BIAS) {
+            if (do_bias && tid < TCO) {
+#pragma unroll 8
+                for (int r = 0; r < WG_MC; ++r)
+                    bsum += *reinterpret_cast<const float*>(lds_c + BUF * D_BYTES + r * D_ROW + 4u * (tid ^ (32 * (r & 1))));
+            }
+        }
         dma_wait();
         __syncthreads();
     };
@@ -1394,6 +1424,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
             if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc[t][r];
         }
     }
+    if (do_bias && tid < TCO && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = bsum;
 }
 
 // out[i] (+)= sum_s part[s][i]: 64 columns x 4 slice lanes per workgroup; every lane keeps four independent
@@ -1525,10 +1556,18 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     // row), border classes that fit the 31-bit mask
     static const bool uni_on = !(getenv("PD_WGRAD_UNI") && getenv("PD_WGRAD_UNI")[0] == '0');
     const int nb = (pad + stride - 1) / stride, nbw = (nb + 1) / 2;
-    if (uni_on && tco == 64 && vec && mode == MODE_ZERO && !dbias && Co % 4 == 0 && Wo % 2 == 0 && ldd % 4 == 0 &&
-        Ho >= 2 * nb && Wo >= 4 * nbw && Wo >= 14 && (2 * nb + 1) * (2 * nbw + 1) <= 31 && a.mper % WG_MC == 0 && a.M % 4 == 0) {
+    const bool refl_ok = mode == MODE_REFLECT && pad == 1 && KH == 3 && KW == 3 && stride == 1 && Ho == H && Wo == W && H >= 3;
+    if (uni_on && tco == 64 && vec && (mode == MODE_ZERO || refl_ok) && Co % 4 == 0 && Wo % 2 == 0 && ldd % 4 == 0 &&
+        Ho >= 2 * nb && Wo >= 4 * nbw && Wo >= 14 && (2 * nb + 1) * (2 * nbw + 1) <= 31 && a.mper % WG_MC == 0 &&
+        a.M % 4 == 0 && a.K >= 4) {
         WgradUniArgs ua; ua.g = a; ua.nb = nb; ua.nbw = nbw;
-        hipLaunchKernelGGL((conv_wgrad_uni_kernel<0>), grid, block, 0, st, ua);
+        if (mode == MODE_ZERO) {
+            if (dbias) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true>), grid, block, 0, st, ua);
+            else hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, false>), grid, block, 0, st, ua);
+        } else {
+            if (dbias) hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, true>), grid, block, 0, st, ua);
+            else hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, false>), grid, block, 0, st, ua);
+        }
     } else
     if (tco == 64) {
         if (vec) { if (mode == MODE_ZERO) PD_WG(64, true, MODE_ZERO); else PD_WG(64, true, MODE_REFLECT); }

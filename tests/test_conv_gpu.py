@@ -117,7 +117,7 @@ def test_uniform_tap_and_scalar_pixel_kernels(case):
 
 
 @pytest.mark.parametrize("case", [(2, 128, 16, 20, 64), (1, 96, 12, 14, 32), (2, 64, 8, 8, 64), (1, 256, 5, 4, 128),
-                                  (3, 32, 2, 3, 64), (1, 64, 64, 48, 64)])
+                                  (3, 32, 2, 3, 64), (1, 64, 64, 48, 64), (2, 96, 13, 14, 64), (1, 512, 3, 16, 256)])
 def test_reflection_padded_conv_on_the_uniform_tap_kernel(case):
     """ReflectionPad2d(1) + Conv3x3 with C % 32 == 0 (the decoder's upconvs): border rows take their reflected offsets
     per tap; tiny images where both borders fold onto neighbouring pixels; with and without bias / ELU."""
@@ -126,11 +126,21 @@ def test_reflection_padded_conv_on_the_uniform_tap_kernel(case):
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
     b = torch.randn(Co, generator=g)
-    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, None)
+    wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), wr, br)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    ref = ref.detach() - b[None, :, None, None]
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     wd = w.cuda().contiguous(memory_format=torch.channels_last)
     _close(ops.conv2d_fwd(xd, wd, None, stride=1, pad=1, mode=1).cpu(), ref)
     _close(ops.conv2d_fwd(xd, wd, b.cuda(), stride=1, pad=1, mode=1, act=ops.ACT_ELU).cpu(), F.elu(ref + b[None, :, None, None]), 3e-5)
+    # weight / bias gradient (scalar-pixel kernel with reflect corrections when Cout >= 33 and W is even and >= 14)
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    dw, db = ops.conv2d_wgrad(xd, dyd, w.shape, stride=1, pad=1, mode=1, want_bias=True)
+    _close(dw.cpu(), wr.grad)
+    _close(db.cpu(), br.grad)
+    _close(ops.conv2d_wgrad(xd, dyd, w.shape, stride=1, pad=1, mode=1).cpu(), wr.grad)
 
 
 @pytest.mark.parametrize("case", [(2, 64, 32, 40, 64, 3, 1, 1), (1, 64, 20, 28, 64, 5, 1, 2), (2, 16, 9, 11, 24, 3, 1, 1),
