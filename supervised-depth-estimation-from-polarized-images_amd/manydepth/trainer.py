@@ -251,6 +251,9 @@ class Trainer:
     def _polar_inputs(self, inputs):
         """On-device XOLP / normals from the raw planes when the loader hands them over (K1)."""
         normals = None
+        if ("pol_mosaic", 0, 0) in inputs and ("pol", 0, 0) not in inputs:
+            # un-split sensor frame (four polarizer images as quadrants): split on the device
+            inputs[("pol", 0, 0)] = pdpolar.split_mosaic(inputs[("pol_mosaic", 0, 0)])
         if ("pol", 0, 0) in inputs and (self.opt.augment_xolp or self.opt.augment_normals):
             want = ["xolp"] + (["normals"] if self.opt.augment_normals else [])
             pol = inputs[("pol", 0, 0)]

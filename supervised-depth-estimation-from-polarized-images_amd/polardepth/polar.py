@@ -99,6 +99,21 @@ def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=No
     return out
 
 
+def split_mosaic(mosaic):
+    """Raw sensor frame [..., 2h, 2w] with the four polarizer images as QUADRANTS -> planes [..., 4, h, w] in K1's
+    order 0/45/90/135 degrees.  Quadrant layout of the reference's offline splitter (polarisation/
+    pol_split_and_save.py:16-25 with the angle labels of indoor_dataset.py:435-438): top-left = pol00 (0 deg),
+    top-right = pol01 (45), bottom-left = pol10 (90), bottom-right = pol11 (135).  Works on host or device tensors
+    (one strided copy); with it the loader can hand over the un-split frame."""
+    H2, W2 = mosaic.shape[-2], mosaic.shape[-1]
+    if H2 % 2 or W2 % 2:
+        raise ValueError(f"split_mosaic: the quadrant frame must have even sides, got {H2}x{W2}")
+    h, w = H2 // 2, W2 // 2
+    tl, tr = mosaic[..., :h, :w], mosaic[..., :h, w:]
+    bl, br = mosaic[..., h:, :w], mosaic[..., h:, w:]
+    return torch.stack((tl, tr, bl, br), dim=-3).contiguous()
+
+
 def normals_from_xolp(xolp, n=1.5, precise=False):
     """ShallowNormalsEncoder.get_normals on the GPU: fp32 [B,2,H,W] (DoLP, AoLP) -> fp32 [B,9,H,W]."""
     if not (isinstance(xolp, torch.Tensor) and xolp.is_cuda):

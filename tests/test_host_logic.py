@@ -329,3 +329,21 @@ def test_torchvision_keyed_resnet18_weights_load_through_env(tmp_path, monkeypat
     monkeypatch.delenv("PD_RESNET18_WEIGHTS")
     with pytest.warns(UserWarning, match="from scratch"):
         networks.ShallowResnetEncoder(18, True)
+
+
+def test_quadrant_mosaic_split_matches_the_reference_splitter_layout():
+    """pol_split_and_save.py:16-25: pol00 = top-left, pol10 = bottom-left, pol01 = top-right, pol11 = bottom-right;
+    K1 wants 0/45/90/135 degrees = pol00, pol01, pol10, pol11 (indoor_dataset.py:435-438)."""
+    import torch
+    from polardepth import polar as pdpolar
+    h, w = 6, 8
+    m = torch.arange(2 * 2 * h * 2 * w, dtype=torch.int32).reshape(2, 2 * h, 2 * w).to(torch.uint8)
+    planes = pdpolar.split_mosaic(m)
+    assert planes.shape == (2, 4, h, w) and planes.is_contiguous()
+    assert torch.equal(planes[:, 0], m[:, :h, :w])      # pol00, 0 deg
+    assert torch.equal(planes[:, 1], m[:, :h, w:])      # pol01, 45 deg
+    assert torch.equal(planes[:, 2], m[:, h:, :w])      # pol10, 90 deg
+    assert torch.equal(planes[:, 3], m[:, h:, w:])      # pol11, 135 deg
+    import pytest
+    with pytest.raises(ValueError):
+        pdpolar.split_mosaic(torch.zeros(1, 5, 8, dtype=torch.uint8))
