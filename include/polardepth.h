@@ -127,6 +127,24 @@ int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_sc
               int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode, int act,
               int affine, float sub, float div, long ldy, void* stream);
 
+/* The 16-channel decoder tail (depth_decoder.py upconv(0,0) 32->16, upconv(0,1) 16->16; layers.py:329-380): 3x3
+ * convolutions with 16 output channels from an input halo tile staged once in LDS (the implicit GEMM above re-stages
+ * the input per tap and is bound by that path at 16 output channels).
+ *   mode 0: y = act(conv3x3(reflection_pad1(x), w) + bias), x NHWC [N,H,W,C] (C = 16 or 32, strides sN/sH/sW, channel
+ *           stride 1), w [16][3][3][C], y NHWC [N,H,W,16] with row stride ldy, act 0 none | 2 ELU;
+ *   mode 1: data gradient on the reflection-PADDED grid: x = dz [N,H,W,16], w = the transposed filter
+ *           [Cout][3][3][16] (pd_weight_transpose), y [N,H+2,W+2,Cout] (Cout = 16 or 32), zero outside the image;
+ *           pd_reflect_fold folds the border afterwards. */
+int pd_conv16(const void* x, const void* w, const void* bias, void* y, int N, int H, int W, int C,
+              long sN, long sH, long sW, int Ho, int Wo, int Cout, long ldy, int mode, int act, void* stream);
+
+/* Weight (+ bias) gradient of the mode-0 convolution above: dw [16][3][3][C] (+)= sum_p dz[p] (x) x[reflect(p+tap-1)],
+ * dbias [16] (+)= sum_p dz[p] (or NULL).  Persistent workgroups, one deterministic partial per workgroup in
+ * `workspace` (>= pd_conv16_wgrad_workspace(C) bytes), summed in a fixed order. */
+size_t pd_conv16_wgrad_workspace(int C);
+int pd_conv16_wgrad(const void* x, const void* dz, void* dw, void* dbias, void* workspace, size_t ws_bytes,
+                    int N, int H, int W, int C, long sN, long sH, long sW, long ldd, int accumulate, void* stream);
+
 /* y = conv(x, w) + addend: the same convolution (no bias / scale / activation / statistics) with an NHWC tensor of the
  * output's shape (row stride ld_add, may alias y) added in the epilogue.  Used for the data gradient of the first
  * convolution of a residual block, which autograd would otherwise sum with the gradient of the skip connection in a

@@ -4,6 +4,8 @@ Activations are fp32, logically NCHW, physically NHWC (torch.channels_last); wei
 [Cout,Cin,kh,kw] logically and [Cout][kh][kw][Cin] physically (channels_last), i.e. exactly the
 operand layout of the implicit-GEMM kernels -- no repacking on the forward path.
 """
+import os
+
 import torch
 
 from ._lib import lib, check, ptr, stream_ptr
@@ -100,6 +102,15 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     sub, div = (affine if affine is not None else (0.0, 1.0))
     sN, sC, sH, sW = x.stride()
     vec = C % 4 == 0 and sC == 1 and affine is None
+    if (USE_CONV16 and mode == MODE_REFLECT and Co == 16 and C in (16, 32) and KH == 3 and KW == 3 and stride == 1 and pad == 1
+            and vec and not want_stats and out_scale is None and act in (ACT_NONE, ACT_ELU) and out_hw is None
+            and H >= 2 and W >= 2 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0):
+        # 16-channel decoder tail: halo-tile kernel (every input pixel staged once instead of once per tap)
+        _profiled("conv16_halo_kernel", 2.0 * N * Ho * Wo * Co * C * 9,
+                  lambda: check(lib.pd_conv16(ptr(x), ptr(w), ptr(bias), ptr(out), N, H, W, C, sN, sH, sW, Ho, Wo, Co, ldy,
+                                              0, act, stream_ptr()), "pd_conv16"),
+                  shape=("fwd", N, C, H, W, Co, KH, stride, mode))
+        return out
     _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd", C, KH, KW, stride, pad, mode), 2.0 * N * Ho * Wo * Co * (alg_k if alg_k is not None else C * KH * KW),
               lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out_scale), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
                                           Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub,
@@ -113,6 +124,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
 # are valid until the next forward convolution: FWD_EPOCH counts conv2d_fwd calls, and weights cannot change between a
 # forward pass and its backward pass without invalidating the gradients anyway -- no reliance on version counters
 # (writes through ``p.data`` or raw pointers do not bump any).
+USE_CONV16 = os.environ.get("PD_CONV16", "1") != "0"     # halo-tile kernel for the 16-channel decoder tail
 WT_PROVIDERS = []
 FWD_EPOCH = 0
 
@@ -145,6 +157,14 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
         wt = weight_transposed(w)
     dx = empty_nhwc(N, Ci, H, W, dy.device)
     sN, sC, sH, sW = dy.stride()
+    if (USE_CONV16 and addend is None and Co == 16 and Ci in (16, 32) and KH == 3 and KW == 3 and stride == 1 and pad == 0
+            and H == Hy + 2 and W == Wy + 2 and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0):
+        # data gradient of a 16-channel reflect conv on the padded grid: halo-tile kernel
+        _profiled("conv16_halo_kernel", 2.0 * N * Hy * Wy * Co * Ci * 9,
+                  lambda: check(lib.pd_conv16(ptr(dy), ptr(wt), None, ptr(dx), N, Hy, Wy, Co, sN, sH, sW, H, W, Ci, Ci, 1, 0,
+                                              stream_ptr()), "pd_conv16(dgrad)"),
+                  shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))
+        return dx
     if addend is not None:
         assert addend.shape == dx.shape and addend.stride(1) == 1 and addend.is_cuda
         ld_add = addend.stride(3)
@@ -195,6 +215,17 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
     if want_bias and dbias is None:
         dbias = torch.empty(Co, dtype=torch.float32, device=x.device)
     M, K = N * Ho * Wo, KH * KW * C
+    sN, sC, sH, sW = x.stride()
+    if (USE_CONV16 and mode == MODE_REFLECT and Co == 16 and C in (16, 32) and KH == 3 and KW == 3 and stride == 1 and pad == 1
+            and affine is None and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0 and H >= 2 and W >= 2
+            and dy.stride(3) % 4 == 0):
+        ws = _workspace(lib.pd_conv16_wgrad_workspace(C), x.device)
+        _profiled("conv16_wgrad_kernel", 2.0 * M * Co * K,
+                  lambda: check(lib.pd_conv16_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), N, H, W, C,
+                                                    sN, sH, sW, dy.stride(3), int(accumulate), stream_ptr()),
+                                "pd_conv16_wgrad"),
+                  shape=("wgrad", N, C, H, W, Co, KH, stride, mode))
+        return (dw, dbias) if (want_bias or dbias is not None) else dw
     nbytes = lib.pd_conv2d_wgrad_workspace(M, Co, K)
     ws = _workspace(nbytes, x.device)
     sub, div = (affine if affine is not None else (0.0, 1.0))

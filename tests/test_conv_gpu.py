@@ -169,6 +169,48 @@ def test_data_gradient_with_addend_in_the_epilogue(case):
     _close(dx2.cpu(), expect)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 40), (1, 32, 16, 20), (2, 16, 9, 35), (1, 32, 13, 7), (3, 16, 2, 2),
+                                  (1, 16, 64, 96), (1, 32, 3, 70)])
+def test_sixteen_channel_tail_halo_kernel(case):
+    """pd_conv16: ReflectionPad2d(1) + Conv3x3 with 16 output channels (+ bias, ELU) from a halo tile in LDS, and its data
+    gradient on the padded grid (through ReflectConvActFn: pd_conv16 mode 1 + pd_reflect_fold), against autograd
+    through a PyTorch fp32 CPU reference; tiles that overhang the image, images smaller than a tile, 2x2."""
+    from polardepth import functional as PF
+    N, C, H, W = case
+    g = torch.Generator().manual_seed(sum(case) + 11)
+    x = torch.randn(N, C, H, W, generator=g)
+    conv = torch.nn.Conv2d(C, 16, 3)
+    conv.weight.data = torch.randn(16, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    conv.bias.data = torch.randn(16, generator=g) * 0.3
+    gy = torch.randn(N, 16, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.elu(F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), conv.weight, conv.bias))
+    (yr * gy).sum().backward()
+    ref = (yr.detach(), xr.grad, conv.weight.grad.clone(), conv.bias.grad.clone())
+    conv.weight.grad = conv.bias.grad = None
+    assert ops.USE_CONV16
+    conv = conv.cuda()
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    xc = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ops.PROFILE = []
+    y = PF.reflect_conv_act(xc, conv, ops.ACT_ELU)
+    (y * gy.cuda()).sum().backward()
+    PF.sync_wgrad_stream()
+    labels = [p[0] for p in ops.PROFILE]
+    ops.PROFILE = None
+    assert labels.count("conv16_halo_kernel") == 2, labels       # forward and data gradient took the halo kernel
+    assert labels.count("conv16_wgrad_kernel") == 1, labels      # ... and the weight / bias gradient its sibling
+    _close(y.detach().cpu(), ref[0], 3e-5)
+    _close(xc.grad.cpu(), ref[1], 3e-5)
+    _close(conv.weight.grad.cpu(), ref[2], 3e-5)
+    _close(conv.bias.grad.cpu(), ref[3], 3e-5)
+    # without the activation, into a channel slice of a wider buffer (row stride != 16)
+    buf = torch.zeros(N, 48, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    ops.conv2d_fwd(xc.detach(), conv.weight.data, conv.bias.data, stride=1, pad=1, mode=1, out=buf[:, 16:32])
+    _close(buf[:, 16:32].cpu(), F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), conv.weight.data.cpu(), conv.bias.data.cpu()), 3e-5)
+    assert buf[:, :16].abs().max().item() == 0 and buf[:, 32:].abs().max().item() == 0
+
+
 def test_conv_nchw_input_with_affine_and_activations():
     g = torch.Generator().manual_seed(7)
     x = torch.rand(2, 3, 24, 32, generator=g)
