@@ -18,5 +18,6 @@ tools/sq_prof2.sh ev > $O/r02_conv_sq_counters2.txt 2>&1
 tools/bin/mfma_peak > $O/r02_mfma_peak.log 2>&1
 python3 tools/bench_fwd.py > $O/r02_conv_bench_fwd.log 2>&1
 python3 tools/bench_chain.py > $O/r02_chain_kernels.log 2>&1
+python3 tools/bench_c16.py > $O/r02_conv16_kernels.log 2>&1
 rm -rf $O/serial $O/overlap $O/fetch $O/write $R/gpurun_out/sq_ev $R/gpurun_out/sq2_ev
 echo done

@@ -19,7 +19,7 @@ def main(d):
     for r in step:
         c[short(r['Kernel_Name'])] += 1
         t[short(r['Kernel_Name'])] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
-    conv = sum(v for k, v in t.items() if 'conv_' in k)
+    conv = sum(v for k, v in t.items() if 'conv_' in k or k.startswith('conv16_'))      # (conv16_* = the 16-channel tail kernels)
     print('launches/step', len(step), 'span ms %.2f' % ((int(step[-1]['End_Timestamp']) - int(step[0]['Start_Timestamp'])) / 1e6),
           'conv ms %.2f' % conv, 'non-conv ms %.2f' % (sum(t.values()) - conv))
     for k, v in sorted(t.items(), key=lambda kv: -kv[1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 30]:
