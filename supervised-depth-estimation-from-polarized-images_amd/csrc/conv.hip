@@ -1168,17 +1168,20 @@ struct WgradUniArgs {
 // REFLECT (ReflectionPad2d(1) + Conv3x3, the decoder): no tap is invalid; a lane whose tap leaves the image for the
 // pair's row / column gets +-2 rows / columns added, selected by four scalar flags of the pair (top, bottom, first,
 // last column): 6 VALU per X piece instead of 2.  BIAS: the kt == 0 tiles also sum dY over their pixels.
-template <bool REFLECT, bool BIAS>
+// TCO = 64: waves 2 (co) x 2 (k), 32x64 wave tiles; TCO = 32 (17..32 output channels): waves 1 x 4, 32x32 wave tiles.
+template <bool REFLECT, bool BIAS, int TCO = 64>
 __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs ua) {
     const WgradArgs& a = ua.g;
-    constexpr int TCO = 64, MT = 32, TK = 2;
+    constexpr int MT = 32, NW_K = TCO == 64 ? 2 : 4, TK = WG_K / MT / NW_K;   // k waves, 32-wide k sub-tiles per wave
+    constexpr int PPD = 1024 / (TCO * 4), NDP = 8 / PPD;                         // pixels per dY piece (4 | 8), dY pieces per wave and chunk (2 | 1)
+    constexpr int NP = NDP + 4;                                                   // LDS-DMA pieces per wave and chunk
     constexpr unsigned D_ROW = TCO * 4, X_ROW = WG_K * 4;                 // bytes per pixel row in LDS
     constexpr unsigned D_BYTES = WG_MC * D_ROW, X_BYTES = WG_MC * X_ROW;   // per buffer: 8 KB, 16 KB
     __shared__ __attribute__((aligned(16))) float smem_all[(2 * D_BYTES + 2 * X_BYTES) / 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NW_K, wn = wave % NW_K;
     const int nwg = a.ktiles * a.ctiles * a.S;
     int b = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
     if (b >= nwg) return;
@@ -1230,8 +1233,10 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
         xmask = 0xffffffffu;
     }
     // dY: lane -> (pixel of the quad = lane/16, physical slot = lane%16, logical slot = slot ^ 8*(pixel&1))
-    const int dpi = lane >> 4;
-    const int dco = co0 + 4 * ((lane & 15) ^ (8 * (dpi & 1)));
+    const int dpi = lane / (TCO / 4);
+    // (64-float rows: the two pixels of an MFMA step share banks -> odd pixels are stored XOR 32 floats; 32-float rows
+    // of adjacent pixels already sit on the two bank halves)
+    const int dco = co0 + 4 * (TCO == 64 ? ((lane & 15) ^ (8 * (dpi & 1))) : (lane & 7));
     const unsigned vd = dco < a.Co ? (unsigned)(dpi * (int)a.ldd + dco) * 4u : OOB;
 
     // ---- scalar pixel state of this wave: it stages pixels 8*wave .. 8*wave+7 of every chunk
@@ -1258,14 +1263,14 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
     auto load_piece = [&](auto dst_tag, auto piece_tag) {
         constexpr unsigned DST = decltype(dst_tag)::value;
         constexpr int P = decltype(piece_tag)::value;
-        if constexpr (P < 2) {
+        if constexpr (P < NDP) {
             // the scalar offset of a buffer access is outside the range check, so the slice end is enforced by a
             // descriptor per instruction (base and record count are SALU arithmetic): rows >= nrows read as zero
-            const int r0 = s_p + 4 * P, left = nrows - r0;
+            const int r0 = s_p + PPD * P, left = nrows - r0;
             const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy0 + (long)r0 * a.ldd, left > 0 ? (unsigned)(left * (int)a.ldd) * 4u : 0u);
-            dma16s(rd, m0_d + DST * D_BYTES + P * 4 * D_ROW, vd, 0u);
+            dma16s(rd, m0_d + DST * D_BYTES + P * PPD * D_ROW, vd, 0u);
         } else {
-            constexpr int J = P - 2;
+            constexpr int J = P - NDP;
             // border class of the pair: rows 0..nb-1 | interior | last nb rows  x  the same over column pairs (min/max, no branches)
             const int ch = min(s_oh, ua.nb) + max(s_oh - (a.Ho - ua.nb) + 1, 0);
             const int pw = s_ow >> 1;
@@ -1302,19 +1307,20 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
     // A k tile with at most 64 valid columns (the last tile of K = 576: 4.5 tiles) would leave the wn = 1 waves idle:
     // there both wave columns take the first 64 columns and split the pixel steps (fragment groups alternate); the
     // two partial tiles are added through LDS at the end.
-    const bool half = k0 + TK * MT >= a.K;
-    const int wn_k = half ? 0 : wn;
+    const bool half = k0 + 2 * MT >= a.K;
+    const int wn_k = half ? wn % (NW_K / 2) : wn, hs = wn / (NW_K / 2);     // (half mode: k wave, helper index 0 | 1)
     // ---- fragments: lane -> (index inside the 32-wide tile = lane%32, pixel of the step = lane/32)
     const int fi = lane & 31, fk = lane >> 5;
-    unsigned fd_off = fk * D_ROW + 4u * ((wm * MT + fi) ^ (32 * fk));
+    unsigned fd_off = fk * D_ROW + 4u * (TCO == 64 ? ((wm * MT + fi) ^ (32 * fk)) : fi);
     unsigned fx_off[TK];
 #pragma unroll
     for (int t = 0; t < TK; ++t) fx_off[t] = 2 * D_BYTES + fk * X_ROW + 4u * (((wn_k * TK + t) * MT + fi) ^ (32 * fk));
     if (half) {     // the wave's first fragment group is group wn: folded into the lane base, the chunk reads "groups 0 and 2"
-        fd_off += wn * (4 * 2 * D_ROW);
-        fx_off[0] += wn * (4 * 2 * X_ROW); fx_off[1] += wn * (4 * 2 * X_ROW);
+        fd_off += hs * (4 * 2 * D_ROW);
+#pragma unroll
+        for (int t = 0; t < TK; ++t) fx_off[t] += hs * (4 * 2 * X_ROW);
     }
-    asm volatile("" : "+v"(fd_off), "+v"(fx_off[0]), "+v"(fx_off[1]));
+    asm volatile("" : "+v"(fd_off), "+v"(fx_off[0]), "+v"(fx_off[TK - 1]));
     const char* lds_c = reinterpret_cast<const char*>(smem_all);
 
     typedef float accv_t __attribute__((ext_vector_type(16)));
@@ -1352,13 +1358,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
                 if (sg + 1 < NG) read_group(sg + 1, (sg + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < UG; ++u) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sg & 1][u], bv[sg & 1][u][0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sg & 1][u], bv[sg & 1][u][1], acc[1], 0, 0, 0);
-                }
-                if (sg == 0) pieces<0, 2>(load_piece, dst);
-                else if (sg == 1) pieces<2, 4>(load_piece, dst);
-                else if (sg == 2) pieces<4, 6>(load_piece, dst);
+                for (int u = 0; u < UG; ++u)
+#pragma unroll
+                    for (int t = 0; t < TK; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sg & 1][u], bv[sg & 1][u][t], acc[t], 0, 0, 0);
+                if (sg == 0) pieces<0, NP / 3>(load_piece, dst);
+                else if (sg == 1) pieces<NP / 3, 2 * NP / 3>(load_piece, dst);
+                else if (sg == 2) pieces<2 * NP / 3, NP>(load_piece, dst);
             }
         } else {
             read_group(0, 0);
@@ -1367,26 +1373,26 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int u = 0; u < UG; ++u) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][u], bv[h][u][0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][u], bv[h][u][1], acc[1], 0, 0, 0);
-                }
-                if (h == 0) pieces<0, 3>(load_piece, dst);
-                else pieces<3, 6>(load_piece, dst);
+                for (int u = 0; u < UG; ++u)
+#pragma unroll
+                    for (int t = 0; t < TK; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][u], bv[h][u][t], acc[t], 0, 0, 0);
+                if (h == 0) pieces<0, NP / 2>(load_piece, dst);
+                else pieces<NP / 2, NP>(load_piece, dst);
             }
         }
         if constexpr (BIAS) {
             if (do_bias && tid < TCO) {
 #pragma unroll 8
                 for (int r = 0; r < WG_MC; ++r)
-                    bsum += *reinterpret_cast<const float*>(lds_c + BUF * D_BYTES + r * D_ROW + 4u * (tid ^ (32 * (r & 1))));
+                    bsum += *reinterpret_cast<const float*>(lds_c + BUF * D_BYTES + r * D_ROW + 4u * (TCO == 64 ? (tid ^ (32 * (r & 1))) : tid));
             }
         }
         dma_wait();
         __syncthreads();
     };
 
-    pieces<0, 6>(load_piece, std::integral_constant<unsigned, 0>{});
+    pieces<0, NP>(load_piece, std::integral_constant<unsigned, 0>{});
     dma_wait();
     __syncthreads();
     if (!half) {
@@ -1402,15 +1408,15 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
     }
 
     if (half) {                             // (uniform per workgroup; the ring is drained: every chunk ends with a barrier)
-        float* xch = smem_all + (wm * 64 + lane) * 33;              // 33-float rows: conflict-free
-        if (wn == 1) {
+        float* xch = smem_all + ((wm * (NW_K / 2) + wn_k) * 64 + lane) * 33;   // 33-float rows: conflict-free
+        if (hs == 1) {
 #pragma unroll
             for (int t = 0; t < TK; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) xch[16 * t + r] = acc[t][r];
         }
         __syncthreads();
-        if (wn == 1) return;
+        if (hs == 1) return;
 #pragma unroll
         for (int t = 0; t < TK; ++t)
 #pragma unroll
@@ -1559,11 +1565,14 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     static const bool uni_on = !(getenv("PD_WGRAD_UNI") && getenv("PD_WGRAD_UNI")[0] == '0');
     const int nb = (pad + stride - 1) / stride, nbw = (nb + 1) / 2;
     const bool refl_ok = mode == MODE_REFLECT && pad == 1 && KH == 3 && KW == 3 && stride == 1 && Ho == H && Wo == W && H >= 3;
-    if (uni_on && tco == 64 && vec && (mode == MODE_ZERO || refl_ok) && Co % 4 == 0 && Wo % 2 == 0 && ldd % 4 == 0 &&
+    if (uni_on && (tco == 64 || tco == 32) && vec && (mode == MODE_ZERO || refl_ok) && Co % 4 == 0 && Wo % 2 == 0 && ldd % 4 == 0 &&
         Ho >= 2 * nb && Wo >= 4 * nbw && Wo >= 14 && (2 * nb + 1) * (2 * nbw + 1) <= 31 && a.mper % WG_MC == 0 &&
         a.M % 4 == 0 && a.K >= 4) {
         WgradUniArgs ua; ua.g = a; ua.nb = nb; ua.nbw = nbw;
-        if (mode == MODE_ZERO) {
+        if (tco == 32) {              // 17..32 output channels (decoder 96->32, 64->32): reflect + bias in this network
+            if (mode == MODE_ZERO) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 32>), grid, block, 0, st, ua);
+            else hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, true, 32>), grid, block, 0, st, ua);
+        } else if (mode == MODE_ZERO) {
             if (dbias) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true>), grid, block, 0, st, ua);
             else hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, false>), grid, block, 0, st, ua);
         } else {
