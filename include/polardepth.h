@@ -134,7 +134,9 @@ int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_sc
  *           stride 1), w [16][3][3][C], y NHWC [N,H,W,16] with row stride ldy, act 0 none | 2 ELU;
  *   mode 1: data gradient on the reflection-PADDED grid: x = dz [N,H,W,16], w = the transposed filter
  *           [Cout][3][3][16] (pd_weight_transpose), y [N,H+2,W+2,Cout] (Cout = 16 or 32), zero outside the image;
- *           pd_reflect_fold folds the border afterwards. */
+ *           pd_reflect_fold folds the border afterwards;
+ *   mode 2: the zero-padding (pad 1) data gradient on the H x W grid (same operands as mode 1, y [N,H,W,Cout]) = the
+ *           interior of mode 1's result; pd_reflect_dgrad_border adds the folded border strips. */
 int pd_conv16(const void* x, const void* w, const void* bias, void* y, int N, int H, int W, int C,
               long sN, long sH, long sW, int Ho, int Wo, int Cout, long ldy, int mode, int act, void* stream);
 
@@ -234,6 +236,12 @@ int pd_up_bwd(const void* dout, long ld_d, void* da, int N, int H, int W, int Ca
 int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int act, void* stream);
 /* Gradient of ReflectionPad2d(1): dxp [N,H+2,W+2,C] -> dx [N,H,W,C]  (layers.py:372). */
 int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, int C, void* stream);
+/* The same gradient without the padded intermediate: dx (in/out, NHWC [N,H,W,Cin]) already holds the zero-padding
+ * (pad 1) data gradient -- the interior of the padded-grid gradient -- and receives the four folded border strips
+ * (1x3 / 3x1 filter slices applied to the first / last row and column of dz [N,H,W,Cout], row stride ldd;
+ * w [Cout][3][3][Cin], the forward filter).  Touches 2(H+W) pixels per image instead of two full-tensor passes. */
+int pd_reflect_dgrad_border(const void* dz, long ldd, const void* w, void* dx, int N, int H, int W, int Cout, int Cin,
+                            void* stream);
 /* torch.optim.Adam step (trainer.py:238,442) over one flat fp32 buffer; grads are pre-multiplied
  * by grad_scale (1/world_size after the RCCL sum).  zero_grad != 0 also clears g in the same pass
  * (trainer.py:436 zero_grad of the NEXT iteration, without a separate 85 MB memset). */

@@ -14,6 +14,8 @@
 //     chunk; MFMA number c contracts ci = 4*kk + c over kk -- a permutation of ci shared by A and B.
 // MODE 0: forward, reflection padding 1, bias + ELU/none (layers.py:364-380 Conv3x3 + ConvBlock's ELU).
 // MODE 1: data gradient on the padded (H+2) x (W+2) grid (zero outside the image), folded by pd_reflect_fold.
+// MODE 2: zero-padding (pad 1) data gradient on the H x W grid = the interior of MODE 1's result; the reflected border
+//         strips are added by pd_reflect_dgrad_border.
 #include "pd_common.h"
 #include <type_traits>
 
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void conv16_halo_kernel(const Conv16Args a) {
     __shared__ __attribute__((aligned(16))) float wl[WL4 * 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int hmin = MODE == 0 ? -1 : -2;                    // source row of halo row 0 relative to r0 (same for columns)
+    constexpr int hmin = MODE == 1 ? -2 : -1;                    // source row of halo row 0 relative to r0 (same for columns)
 
     // ---- filter -> LDS: w[n][tap][k] -> wl[((tap*NCI + s)*4 + kk)*(16*NCO) + n][c], k = 16 s + 4 kk + c
     for (int i = tid; i < 9 * C * 16 * NCO / 4; i += 256) {      // one float4 of consecutive k per item
@@ -341,11 +343,11 @@ __global__ __launch_bounds__(256) void conv16_wgrad_kernel(const Wgrad16Args a) 
 extern "C" int pd_conv16(const void* x, const void* w, const void* bias, void* y, int N, int H, int W, int C,
                          long sN, long sH, long sW, int Ho, int Wo, int Cout, long ldy, int mode, int act, void* stream) {
     PD_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "pd_conv16: bad arguments");
-    PD_REQUIRE(mode == 0 || mode == 1, "pd_conv16: mode 0 (reflect forward) or 1 (data gradient on the padded grid)");
+    PD_REQUIRE(mode >= 0 && mode <= 2, "pd_conv16: mode 0 (reflect forward), 1 (data gradient on the padded grid), 2 (pad-1 data gradient)");
     PD_REQUIRE(act == 0 || act == 2, "pd_conv16: activation none or ELU");
-    PD_REQUIRE((mode == 0 && Cout == 16 && (C == 16 || C == 32)) || (mode == 1 && C == 16 && (Cout == 16 || Cout == 32)),
+    PD_REQUIRE((mode == 0 && Cout == 16 && (C == 16 || C == 32)) || (mode != 0 && C == 16 && (Cout == 16 || Cout == 32)),
                "pd_conv16: unsupported channel counts %d -> %d (mode %d)", C, Cout, mode);
-    PD_REQUIRE(mode != 0 || (H >= 2 && W >= 2 && Ho == H && Wo == W), "pd_conv16: reflect forward keeps the grid (H, W >= 2)");
+    PD_REQUIRE(mode == 1 || (H >= 2 && W >= 2 && Ho == H && Wo == W), "pd_conv16: modes 0 and 2 keep the grid (H, W >= 2)");
     PD_REQUIRE(mode != 1 || (Ho == H + 2 && Wo == W + 2), "pd_conv16: the data gradient lands on the (H+2) x (W+2) grid");
     PD_REQUIRE(sN % 4 == 0 && sH % 4 == 0 && sW % 4 == 0 && pd::aligned16(x) && pd::aligned16(w) && ldy >= Cout,
                "pd_conv16: 16-byte aligned NHWC operands");
@@ -362,9 +364,12 @@ extern "C" int pd_conv16(const void* x, const void* w, const void* bias, void* y
     if (mode == 0) {
         if (C == 16) hipLaunchKernelGGL((conv16_halo_kernel<1, 1, 0>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv16_halo_kernel<2, 1, 0>), grid, block, 0, st, a);
-    } else {
+    } else if (mode == 1) {
         if (Cout == 16) hipLaunchKernelGGL((conv16_halo_kernel<1, 1, 1>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv16_halo_kernel<1, 2, 1>), grid, block, 0, st, a);
+    } else {
+        if (Cout == 16) hipLaunchKernelGGL((conv16_halo_kernel<1, 1, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv16_halo_kernel<1, 2, 2>), grid, block, 0, st, a);
     }
     return pd::check_launch("pd_conv16");
 }

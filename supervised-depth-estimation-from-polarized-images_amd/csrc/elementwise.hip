@@ -591,6 +591,84 @@ __global__ __launch_bounds__(EW_T) void reflect_fold_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- reflection-pad border terms of a data gradient
+// dX of y = conv3x3(reflection_pad1(x)): the gradient on the padded grid, dxp[p] = sum_k dz[p + 1 - k] w[k], folded back
+// (padded row -1 onto row 1, row H onto row H-2, same for columns).  Its INTERIOR is exactly the zero-padding (pad 1)
+// data gradient, which the conv kernels write straight into dx; what remains are the four border strips of dxp, each
+// a 1x3 / 3x1 slice of the filter applied to the first / last row or column of dz -- added here to rows 1, H-2 and
+// columns 1, W-2 of dx: replaces the full-tensor pass of pd_reflect_fold (read the padded gradient, write dx) by a
+// kernel that touches 2(H+W) pixels per image.
+// dz [N,H,W,Co] (row stride ldd), w [Co][3][3][Ci], dx [N,H,W,Ci] in/out.
+// sum_co d[co] * w[co * ws]: eight independent partial sums keep eight (lane-coalesced) weight loads in flight
+__device__ __forceinline__ float dot_co(const float* __restrict__ d, const float* __restrict__ wp, int Co, long ws) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int co = 0;
+    for (; co + 8 <= Co; co += 8) {
+        const float4 d0 = ld4(d + co), d1 = ld4(d + co + 4);
+        s[0] += d0.x * wp[(co + 0) * ws]; s[1] += d0.y * wp[(co + 1) * ws]; s[2] += d0.z * wp[(co + 2) * ws]; s[3] += d0.w * wp[(co + 3) * ws];
+        s[4] += d1.x * wp[(co + 4) * ws]; s[5] += d1.y * wp[(co + 5) * ws]; s[6] += d1.z * wp[(co + 6) * ws]; s[7] += d1.w * wp[(co + 7) * ws];
+    }
+    for (; co < Co; ++co) s[0] += d[co] * wp[co * ws];
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+// One thread per (target pixel, ci).  Meant for the shallow decoder levels (few channels, thousands of border pixels);
+// in the deep ones every target re-streams its slice of a multi-megabyte filter and the fold pass over the small
+// tensor is cheaper (functional.ReflectConvActFn picks per layer).
+__global__ __launch_bounds__(EW_T) void reflect_dgrad_border_flat_kernel(const float* __restrict__ dz, long ldd,
+                                                                         const float* __restrict__ w, float* __restrict__ dx,
+                                                                         int N, int H, int W, int Co, int Ci) {
+    const int per_img = 2 * W + 2 * H;
+    const long total = (long)N * per_img * Ci;
+    for (long idx = blockIdx.x * (long)EW_T + threadIdx.x; idx < total; idx += (long)gridDim.x * EW_T) {
+        const int ci = (int)(idx % Ci);
+        long t = idx / Ci;
+        const int e = (int)(t % per_img);
+        const long n = t / per_img;
+        int i, j;
+        if (e < 2 * W) {
+            i = e < W ? 1 : H - 2; j = e < W ? e : e - W;
+            if (e >= W && H - 2 == 1) continue;
+        } else {
+            const int f = e - 2 * W;
+            j = f < H ? 1 : W - 2; i = f < H ? f : f - H;
+            if ((f >= H && W - 2 == 1) || i == 1 || i == H - 2) continue;
+        }
+        const float* dzn = dz + n * (long)H * W * ldd;
+        const float* wb = w + ci;
+        auto strip_h = [&](int zr, int kh, int q) {
+            float s = 0.f;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int c = q + 1 - kw;
+                if (c < 0 || c >= W) continue;
+                s += dot_co(dzn + ((long)zr * W + c) * ldd, wb + ((long)kh * 3 + kw) * Ci, Co, 9L * Ci);
+            }
+            return s;
+        };
+        auto strip_v = [&](int zc, int kw, int p) {
+            float s = 0.f;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int r = p + 1 - kh;
+                if (r < 0 || r >= H) continue;
+                s += dot_co(dzn + ((long)r * W + zc) * ldd, wb + ((long)kh * 3 + kw) * Ci, Co, 9L * Ci);
+            }
+            return s;
+        };
+        auto full_h = [&](int zr, int kh) {
+            float s = strip_h(zr, kh, j);
+            if (j == 1) s += strip_h(zr, kh, -1);
+            if (j == W - 2) s += strip_h(zr, kh, W);
+            return s;
+        };
+        float corr = 0.f;
+        if (i == 1) corr += full_h(0, 0);
+        if (i == H - 2) corr += full_h(H - 1, 2);
+        if (j == 1) corr += strip_v(0, 0, i);
+        if (j == W - 2) corr += strip_v(W - 1, 2, i);
+        dx[((n * H + i) * (long)W + j) * Ci + ci] += corr;
+    }
+}
+
 // ---------------------------------------------------------------- fused Adam over a flat buffer
 // Parameters, moments and (ZERO_G) the cleared gradient leave with nontemporal stores: 340 MB that nothing reads
 // before the next step's kernels have streamed gigabytes -- left dirty in the caches, the kernel that follows
@@ -817,6 +895,15 @@ extern "C" int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, i
         hipLaunchKernelGGL(reflect_fold_kernel<1>, dim3(ew_grid((long)N * H * W * C)), dim3(EW_T), 0,
                            (hipStream_t)stream, (const float*)dxp, (float*)dx, N, H, W, C);
     return pd::check_launch("pd_reflect_fold");
+}
+
+extern "C" int pd_reflect_dgrad_border(const void* dz, long ldd, const void* w, void* dx, int N, int H, int W, int Co,
+                                       int Ci, void* stream) {
+    PD_REQUIRE(dz && w && dx && N >= 0 && H >= 2 && W >= 2 && Co > 0 && Ci > 0 && ldd >= Co, "pd_reflect_dgrad_border: bad arguments");
+    if (N == 0) return PD_OK;
+    hipLaunchKernelGGL(reflect_dgrad_border_flat_kernel, dim3(ew_grid((long)N * (2 * W + 2 * H) * Ci)), dim3(EW_T), 0,
+                       (hipStream_t)stream, (const float*)dz, ldd, (const float*)w, (float*)dx, N, H, W, Co, Ci);
+    return pd::check_launch("pd_reflect_dgrad_border");
 }
 
 extern "C" int pd_adam_step(void* p, void* g, void* m, void* v, long n, float lr, float beta1, float beta2,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "pd_up_bwd": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "pd_act_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "pd_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_reflect_dgrad_border": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pd_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _i, _vp]),
     "pd_loss_rows": (_i, [_l]),
     "pd_disp_to_depth": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),

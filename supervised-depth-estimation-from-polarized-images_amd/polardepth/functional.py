@@ -157,6 +157,7 @@ class SkipGrad:
 
 
 USE_SKIP_FUSION = os.environ.get("PD_SKIP_FUSION", "1") != "0"
+USE_REFLECT_BORDER = os.environ.get("PD_REFLECT_BORDER", "1") != "0"   # reflect-conv dX = pad-1 dgrad + border strips (no fold pass)
 
 
 class ChainCfg:
@@ -380,10 +381,20 @@ class ReflectConvActFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             Ci = x.shape[1]
-            # gradient on the reflection-padded grid (a zero-pad transposed conv), then fold the border
-            dxp = ops.conv2d_dgrad(dz, weight, (H + 2, W + 2), 1, 0)
-            dx = ops.empty_nhwc(N, Ci, H, W, dy.device)
-            check(lib.pd_reflect_fold(ptr(dxp), ptr(dx), N, H, W, Ci, stream_ptr()), "pd_reflect_fold")
+            if USE_REFLECT_BORDER and 1 < Co < 128:
+                # (from 128 output channels on the fold pass over the small deep tensor is cheaper than the border kernel,
+                #  whose every target pixel re-streams its slice of a multi-megabyte filter)
+                # the interior of the padded-grid gradient IS the zero-padding (pad 1) data gradient: it goes straight
+                # into dx; the four folded border strips are added by a kernel that touches 2(H+W) pixels per image
+                dx = ops.conv2d_dgrad(dz, weight, (H, W), 1, 1)
+                dzv, ld_dz = nhwc_view(dz)
+                check(lib.pd_reflect_dgrad_border(ptr(dzv), ld_dz, ptr(ops.weight_cl(weight)), ptr(dx), N, H, W, Co, Ci,
+                                                  stream_ptr()), "pd_reflect_dgrad_border")
+            else:
+                # gradient on the reflection-padded grid (a zero-pad transposed conv), then fold the border
+                dxp = ops.conv2d_dgrad(dz, weight, (H + 2, W + 2), 1, 0)
+                dx = ops.empty_nhwc(N, Ci, H, W, dy.device)
+                check(lib.pd_reflect_fold(ptr(dxp), ptr(dx), N, H, W, Ci, stream_ptr()), "pd_reflect_fold")
         for p in (weight, bias):
             if p is not None:
                 _ready(p)

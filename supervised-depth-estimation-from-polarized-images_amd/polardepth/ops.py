@@ -157,12 +157,13 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
         wt = weight_transposed(w)
     dx = empty_nhwc(N, Ci, H, W, dy.device)
     sN, sC, sH, sW = dy.stride()
-    if (USE_CONV16 and addend is None and Co == 16 and Ci in (16, 32) and KH == 3 and KW == 3 and stride == 1 and pad == 0
-            and H == Hy + 2 and W == Wy + 2 and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0):
-        # data gradient of a 16-channel reflect conv on the padded grid: halo-tile kernel
+    c16_mode = 1 if (pad == 0 and H == Hy + 2 and W == Wy + 2) else (2 if (pad == 1 and H == Hy and W == Wy) else 0)
+    if (USE_CONV16 and addend is None and Co == 16 and Ci in (16, 32) and KH == 3 and KW == 3 and stride == 1 and c16_mode
+            and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0 and Hy >= 2 and Wy >= 2):
+        # data gradient of a 16-channel 3x3 conv (on the padded grid, or pad 1 on the same grid): halo-tile kernel
         _profiled("conv16_halo_kernel", 2.0 * N * Hy * Wy * Co * Ci * 9,
-                  lambda: check(lib.pd_conv16(ptr(dy), ptr(wt), None, ptr(dx), N, Hy, Wy, Co, sN, sH, sW, H, W, Ci, Ci, 1, 0,
-                                              stream_ptr()), "pd_conv16(dgrad)"),
+                  lambda: check(lib.pd_conv16(ptr(dy), ptr(wt), None, ptr(dx), N, Hy, Wy, Co, sN, sH, sW, H, W, Ci, Ci, c16_mode,
+                                              0, stream_ptr()), "pd_conv16(dgrad)"),
                   shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))
         return dx
     if addend is not None:

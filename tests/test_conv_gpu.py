@@ -141,6 +141,20 @@ def test_reflection_padded_conv_on_the_uniform_tap_kernel(case):
     _close(dw.cpu(), wr.grad)
     _close(db.cpu(), br.grad)
     _close(ops.conv2d_wgrad(xd, dyd, w.shape, stride=1, pad=1, mode=1).cpu(), wr.grad)
+    # data gradient through the autograd node: zero-padding (pad 1) data gradient + the folded border strips
+    # (pd_reflect_dgrad_border), and the older padded-grid + pd_reflect_fold route, against torch
+    from polardepth import functional as PF
+    xr = x.clone().requires_grad_(True)
+    (F.elu(F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), w, b)) * dy).sum().backward()
+    conv = torch.nn.Conv2d(C, Co, 3).cuda()
+    conv.weight.data = wd.clone(); conv.bias.data = b.cuda()
+    for border in (True, False):
+        PF.USE_REFLECT_BORDER = border
+        xc = xd.clone().requires_grad_(True)
+        (PF.reflect_conv_act(xc, conv, ops.ACT_ELU) * dyd).sum().backward()
+        PF.sync_wgrad_stream()
+        _close(xc.grad.cpu(), xr.grad, 3e-5)
+    PF.USE_REFLECT_BORDER = True
 
 
 @pytest.mark.parametrize("case", [(2, 64, 32, 40, 64, 3, 1, 1), (1, 64, 20, 28, 64, 5, 1, 2), (2, 16, 9, 11, 24, 3, 1, 1),
