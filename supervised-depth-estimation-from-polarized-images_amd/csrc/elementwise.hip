@@ -170,6 +170,51 @@ __global__ __launch_bounds__(EW_T) void bn_bwd_stats_kernel(const float* __restr
     }
 }
 
+// Few partial rows (every layer below 256x320: <= 2560 tiles): ONE workgroup per 32 channels sums all rows -- 32 channels x
+// 32 row lanes, fp64, fixed order -- and finalises its channels itself: no atomics, no ticket, no second trip through L2
+// (the multi-workgroup version above is a chain of load -> atomic -> fence -> ticket -> atomic load latencies, ~14 us
+// whatever the size).
+template <bool FWD>
+__global__ __launch_bounds__(1024) void bn_stats_small_kernel(const float* __restrict__ part, long R, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ rmean, float* __restrict__ rvar,
+                                                              float* __restrict__ scale, float* __restrict__ shift,
+                                                              float* __restrict__ smean, float* __restrict__ sinvstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef, double count, float momentum,
+                                                              float eps, int accumulate) {
+    __shared__ double red[32][32][2];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0, u0 = 0.0, u1 = 0.0, w0 = 0.0, w1 = 0.0;
+    if (c < C) {
+        long r = rl;
+        for (; r + 96 < R; r += 128) {          // four independent loads in flight per thread
+            const float2 a = *reinterpret_cast<const float2*>(part + (r * C + c) * 2);
+            const float2 b = *reinterpret_cast<const float2*>(part + ((r + 32) * C + c) * 2);
+            const float2 d = *reinterpret_cast<const float2*>(part + ((r + 64) * C + c) * 2);
+            const float2 e = *reinterpret_cast<const float2*>(part + ((r + 96) * C + c) * 2);
+            s0 += a.x; s1 += a.y; t0 += b.x; t1 += b.y; u0 += d.x; u1 += d.y; w0 += e.x; w1 += e.y;
+        }
+        for (; r < R; r += 32) { const float2 a = *reinterpret_cast<const float2*>(part + (r * C + c) * 2); s0 += a.x; s1 += a.y; }
+    }
+    red[rl][cl][0] = (s0 + t0) + (u0 + w0); red[rl][cl][1] = (s1 + t1) + (u1 + w1);
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { a0 += red[i][cl][0]; a1 += red[i][cl][1]; }
+        if (FWD) {
+            bn_fwd_finalize_channel(c, a0, a1, gamma, beta, rmean, rvar, scale, shift, smean, sinvstd, count, momentum, eps, 1);
+        } else {
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a1;
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a0;
+            coef[c] = (float)(a0 / count);
+            coef[C + c] = (float)(a1 / count);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- BN-apply chain
 struct ChainArgs {
     const float* x;        // raw conv output [N,H,W,C] contiguous
@@ -723,7 +768,12 @@ extern "C" int pd_bn_fwd_finalize(const void* partial, long R, int C, double cou
     PD_REQUIRE(!training || (partial && acc_ws && R > 0 && count > 0), "pd_bn_fwd_finalize: training needs partials");
     PD_REQUIRE(training || (running_mean && running_var), "pd_bn_fwd_finalize: eval needs running stats");
     hipStream_t st = (hipStream_t)stream;
-    if (training) {
+    if (training && R <= 4096) {
+        hipLaunchKernelGGL(bn_stats_small_kernel<true>, dim3((C + 31) / 32), dim3(1024), 0, st, (const float*)partial, R, C,
+                           (const float*)gamma, (const float*)beta, (float*)running_mean, (float*)running_var, (float*)scale,
+                           (float*)shift, (float*)save_mean, (float*)save_invstd, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr, count, momentum, eps, 0);
+    } else if (training) {
         const int cgroups = (C + 31) / 32;
         const int rpb = 256;
         const long rblocks = (R + rpb - 1) / rpb;
@@ -743,6 +793,13 @@ extern "C" int pd_bn_bwd_finalize(const void* partial, long R, int C, double cou
                                   void* dbeta, void* coef, int accumulate, void* stream) {
     PD_REQUIRE(partial && acc_ws && coef && C > 0 && R > 0 && count > 0, "pd_bn_bwd_finalize: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    if (R <= 4096) {
+        hipLaunchKernelGGL(bn_stats_small_kernel<false>, dim3((C + 31) / 32), dim3(1024), 0, st, (const float*)partial, R, C,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)dgamma, (float*)dbeta, (float*)coef,
+                           count, 0.f, 0.f, accumulate);
+        return pd::check_launch("pd_bn_bwd_finalize");
+    }
     const int cgroups = (C + 31) / 32;
     const int rpb = 256;
     const long rblocks = (R + rpb - 1) / rpb;
