@@ -147,6 +147,14 @@ size_t pd_conv16_wgrad_workspace(int C);
 int pd_conv16_wgrad(const void* x, const void* dz, void* dw, void* dbias, void* workspace, size_t ws_bytes,
                     int N, int H, int W, int C, long sN, long sH, long sW, long ldd, int accumulate, void* stream);
 
+/* Stride-2 data gradient by output parity (3x3 / stride 2 / pad 1, even input grid; resnet18 layer2.0.conv1,
+ * resnet_encoder.py / torchvision BasicBlock): pd_dgrad_s2_filters turns the transposed filter wt [Cin][3][3][Cout] into
+ * four 2x2 sub-filters wsub [4][Cin][2][2][Cout] (class = 2*(ih%2) + iw%2); each class is pd_conv2d(mode 2, KH = KW = 2,
+ * stride 1, pad 1) of dY onto the [N,Ho,Wo,Cin] sub-grid; pd_interleave4 scatters the four sub-grids
+ * [4][N][Ho][Wo][C] into dX [N][2Ho][2Wo][C].  16 tap-units instead of the 36 of the masked transposed gather. */
+int pd_dgrad_s2_filters(const void* wt, void* wsub, int Cin, int Cout, void* stream);
+int pd_interleave4(const void* sub, void* dx, int N, int Ho, int Wo, int C, void* stream);
+
 /* y = conv(x, w) + addend: the same convolution (no bias / scale / activation / statistics) with an NHWC tensor of the
  * output's shape (row stride ld_add, may alias y) added in the epilogue.  Used for the data gradient of the first
  * convolution of a residual block, which autograd would otherwise sum with the gradient of the skip connection in a

@@ -848,8 +848,10 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
     while ((1 << sshift) < stride) ++sshift;
     if (mode == MODE_TRANSPOSED) {
         PD_REQUIRE((1 << sshift) == stride, "pd_conv2d: transposed mode needs a power-of-two stride");
-        PD_REQUIRE(H == (Ho + 2 * pad - KH) / stride + 1 && W == (Wo + 2 * pad - KW) / stride + 1,
-                   "pd_conv2d: transposed: x grid is not the forward output grid of a %dx%d input", Ho, Wo);
+        // (a SMALLER x grid is the leading part of that output grid: the missing rows / columns read as zero -- the
+        //  sub-filters of a phase-decomposed stride-2 data gradient need exactly that, see pd_dgrad_s2_filters)
+        PD_REQUIRE(H <= (Ho + 2 * pad - KH) / stride + 1 && W <= (Wo + 2 * pad - KW) / stride + 1,
+                   "pd_conv2d: transposed: x grid exceeds the forward output grid of a %dx%d input", Ho, Wo);
     } else {
         // a smaller output grid computes the leading Ho x Wo outputs only (asymmetric bottom/right padding)
         PD_REQUIRE(Ho <= (H + 2 * pad - KH) / stride + 1 && Wo <= (W + 2 * pad - KW) / stride + 1,
@@ -1622,6 +1624,64 @@ extern "C" int pd_weight_transpose_batched(const void* src, void* dst, const voi
     hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
                        (const float*)src, (float*)dst, (const int*)table, (const int*)blk, n);
     return pd::check_launch("pd_weight_transpose_batched");
+}
+
+// ===================================================================== stride-2 data gradient by output parity
+// dX of a 3x3 / stride-2 / pad-1 convolution: an input pixel (ih, iw) receives only the taps with (ih + 1 - kh) and
+// (iw + 1 - kw) even -- 1, 2, 2 or 4 of the 9, by the parity of (ih, iw).  The masked transposed gather multiplies zeros
+// for the other taps (three quarters of its MFMAs).  Per parity class (ph, pw) the gradient on the sub-grid
+// (2i + ph, 2j + pw) is a stride-1 2x2 "pad 1" correlation of dY with a sub-filter (odd classes take taps 0 and 2,
+// even classes tap 1 next to a zero): four uniform-tap launches of 16 tap-units instead of 36, then one interleave.
+namespace {
+// wt [Ci][3][3][Co] (data-gradient operand) -> wsub [4][Ci][2][2][Co]
+__global__ __launch_bounds__(256) void dgrad_s2_filters_kernel(const float* __restrict__ wt, float* __restrict__ wsub,
+                                                               int Ci, int Co) {
+    const long total = 4L * Ci * 4 * Co;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int co = (int)(i % Co);
+        long r = i / Co;
+        const int kw2 = (int)(r & 1), kh2 = (int)((r >> 1) & 1); r >>= 2;
+        const int ci = (int)(r % Ci);
+        const int cls = (int)(r / Ci), ph = cls >> 1, pw = cls & 1;
+        // transposed-mode tap k' reads dY[i + 1 - k']: odd parity: k' = 0 -> filter tap 0 (oh = i + 1), k' = 1 -> tap 2 (oh = i);
+        // even parity: k' = 1 -> tap 1 (oh = i), k' = 0 -> nothing
+        const int kh = ph ? (kh2 ? 2 : 0) : (kh2 ? 1 : -1), kw = pw ? (kw2 ? 2 : 0) : (kw2 ? 1 : -1);
+        wsub[i] = (kh < 0 || kw < 0) ? 0.f : wt[(((long)ci * 3 + kh) * 3 + kw) * Co + co];
+    }
+}
+// sub [4][N][Ho][Wo][C] -> dx [N][2 Ho][2 Wo][C]
+__global__ __launch_bounds__(256) void interleave4_kernel(const float* __restrict__ sub, float* __restrict__ dx, int N, int Ho,
+                                                          int Wo, int C) {
+    const int cq = C >> 2;
+    const long per = (long)N * Ho * Wo * cq, total = 4 * per;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % cq) * 4;
+        long r = i / cq;
+        const int pw = (int)(r & 1); r >>= 1;                      // output-major order: consecutive threads write consecutive pixels
+        const int j = (int)(r % Wo); r /= Wo;
+        const int ph = (int)(r & 1); r >>= 1;
+        const int ii = (int)(r % Ho);
+        const long n = r / Ho;
+        const float4 v = ldg4(sub + ((long)(ph * 2 + pw) * N * Ho * Wo + (n * Ho + ii) * (long)Wo + j) * C + c4);
+        *reinterpret_cast<float4*>(dx + ((n * 2 * Ho + 2 * ii + ph) * (long)(2 * Wo) + 2 * j + pw) * C + c4) = v;
+    }
+}
+}  // namespace
+
+extern "C" int pd_dgrad_s2_filters(const void* wt, void* wsub, int Ci, int Co, void* stream) {
+    PD_REQUIRE(wt && wsub && Ci > 0 && Co > 0, "pd_dgrad_s2_filters: bad arguments");
+    const long total = 16L * Ci * Co, blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(dgrad_s2_filters_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)wt, (float*)wsub, Ci, Co);
+    return pd::check_launch("pd_dgrad_s2_filters");
+}
+
+extern "C" int pd_interleave4(const void* sub, void* dx, int N, int Ho, int Wo, int C, void* stream) {
+    PD_REQUIRE(sub && dx && N > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "pd_interleave4: bad arguments");
+    const long total = 4L * N * Ho * Wo * (C / 4), blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(interleave4_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)sub, (float*)dx, N, Ho, Wo, C);
+    return pd::check_launch("pd_interleave4");
 }
 
 // ===================================================================== 7x7 / stride-2 stems as 4x4 / stride-1

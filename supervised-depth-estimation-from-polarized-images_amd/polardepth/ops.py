@@ -124,6 +124,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
 # are valid until the next forward convolution: FWD_EPOCH counts conv2d_fwd calls, and weights cannot change between a
 # forward pass and its backward pass without invalidating the gradients anyway -- no reliance on version counters
 # (writes through ``p.data`` or raw pointers do not bump any).
+USE_S2_PHASES = os.environ.get("PD_S2_PHASES", "1") != "0"   # stride-2 data gradient as four parity-class sub-convolutions
 USE_CONV16 = os.environ.get("PD_CONV16", "1") != "0"     # halo-tile kernel for the 16-channel decoder tail
 WT_PROVIDERS = []
 FWD_EPOCH = 0
@@ -157,6 +158,22 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
         wt = weight_transposed(w)
     dx = empty_nhwc(N, Ci, H, W, dy.device)
     sN, sC, sH, sW = dy.stride()
+    if (USE_S2_PHASES and addend is None and stride == 2 and KH == 3 and KW == 3 and pad == 1 and H == 2 * Hy and W == 2 * Wy
+            and Co % 32 == 0 and Ci % 4 == 0 and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0):
+        # stride-2 data gradient by output parity: four stride-1 2x2 sub-filter launches + one interleave
+        def _phases():
+            wsub = torch.empty((4, Ci, Co, 2, 2), dtype=torch.float32, device=dy.device).as_strided(
+                (4, Ci, Co, 2, 2), (Ci * 4 * Co, 4 * Co, 1, 2 * Co, Co))          # [4][Ci][2][2][Co] storage
+            check(lib.pd_dgrad_s2_filters(ptr(wt), ptr(wsub), Ci, Co, stream_ptr()), "pd_dgrad_s2_filters")
+            sub = torch.empty((4, N, Hy, Wy, Ci), dtype=torch.float32, device=dy.device)
+            for c in range(4):
+                check(lib.pd_conv2d(ptr(dy), ptr(wsub[c]), None, None, ptr(sub[c]), None, N, Hy, Wy, Co, sN, sH, sW, sC,
+                                    Hy, Wy, Ci, 2, 2, 1, 1, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci, stream_ptr()),
+                      "pd_conv2d(dgrad s2 phase)")
+            check(lib.pd_interleave4(ptr(sub), ptr(dx), N, Hy, Wy, Ci, stream_ptr()), "pd_interleave4")
+        _profiled("conv_dgrad_s2_phases", 2.0 * N * Hy * Wy * Co * Ci * KH * KW, _phases,
+                  shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))
+        return dx
     c16_mode = 1 if (pad == 0 and H == Hy + 2 and W == Wy + 2) else (2 if (pad == 1 and H == Hy and W == Wy) else 0)
     if (USE_CONV16 and addend is None and Co == 16 and Ci in (16, 32) and KH == 3 and KW == 3 and stride == 1 and c16_mode
             and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0 and Hy >= 2 and Wy >= 2):
