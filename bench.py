@@ -54,6 +54,7 @@ def build_trainer(batch, height, width, log_dir):
         "--weights_init", "scratch", "--num_workers", "0", "--log_dir", log_dir, "--data_path", "synthetic",
         "--data_path_val", "synthetic", "--model_name", "bench"] +
         (["--dropout_rate", os.environ["PD_BENCH_DROPOUT"]] if "PD_BENCH_DROPOUT" in os.environ else []))   # tuning aid only
+    torch.manual_seed(0)        # reproducible random-init weights (final_loss is then comparable across runs and builds)
     return Trainer(opts)
 
 
