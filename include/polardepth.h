@@ -239,6 +239,9 @@ int pd_maxpool3s2_bwd(const void* idx, const void* dy, void* dx, int N, int H, i
 int pd_upcat_fwd(const void* a, const void* skip, long ld_skip, void* out, int N, int H, int W, int Ca, int Cs,
                  void* stream);
 int pd_up_bwd(const void* dout, long ld_d, void* da, int N, int H, int W, int Ca, void* stream);
+/* same with the ELU derivative folded in: a = elu_y [N,H,W,Ca] is the output of a ConvBlock (layers.py:329-342), da
+ * leaves multiplied by (a > 0 ? 1 : a + 1), i.e. as the gradient of the convolution output. elu_y NULL = pd_up_bwd. */
+int pd_up_bwd_elu(const void* dout, long ld_d, const void* elu_y, void* da, int N, int H, int W, int Ca, void* stream);
 
 /* dz = dy * f'(.) through the activation OUTPUT y: act 1 ReLU, 2 ELU (layers.py:337), 3 sigmoid. */
 int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int act, void* stream);
@@ -340,13 +343,20 @@ int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o,
  * pd_disphead_bwd_data:   dx [N,H,W,C] = gradient w.r.t. x given dy (gradient w.r.t. y) and y; the fold of the
  *                         reflection padding is built in
  * pd_disphead_bwd_weight: dw [3][3][C] (+)= , dbias [1] (+)= (NULL to skip); workspace >= pd_disphead_workspace(C)
- *                         bytes, 16-byte aligned; deterministic two-stage summation */
+ *                         bytes, 16-byte aligned; deterministic two-stage summation
+ * pd_disphead_bwd:        both gradients in one pass over x (dx may be NULL): what the training step calls.
+ *                         add [N,H,W,C] or NULL is summed into dx (the gradient x receives from its other consumer,
+ *                         depth_decoder.py:64 reads the same x); elu != 0: x is the ELU output of a ConvBlock
+ *                         (layers.py:329-342) and dx leaves multiplied by ELU'(.) = (x > 0 ? 1 : x + 1) */
 int pd_disphead_fwd(const void* x, const void* w, const void* bias, void* y, int N, int H, int W, int C, void* stream);
 int pd_disphead_bwd_data(const void* dy, const void* y, const void* w, void* dx, int N, int H, int W, int C,
                          void* stream);
 size_t pd_disphead_workspace(int C);
 int pd_disphead_bwd_weight(const void* dy, const void* y, const void* x, void* dw, void* dbias, void* workspace,
                            size_t ws_bytes, int N, int H, int W, int C, int accumulate, void* stream);
+int pd_disphead_bwd(const void* dy, const void* y, const void* x, const void* w, const void* add, int elu, void* dx,
+                    void* dw, void* dbias, void* workspace, size_t ws_bytes, int N, int H, int W, int C, int accumulate,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,8 +41,10 @@ __device__ __forceinline__ Pix decode(int p, int npix, int H, int W) {
     return r;
 }
 
+// Forward, direct form (64 and 128 channels: the lane groups are wide, the cross-lane sums of the tile form cost more
+// than the cached re-reads).
 template <int L>   // lanes per pixel, C = 4 L
-__global__ __launch_bounds__(256) void disphead_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void disphead_fwd_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y,
                                                            int npix, int H, int W) {
     constexpr int C = 4 * L, PPW = 64 / L;
@@ -69,6 +71,64 @@ __global__ __launch_bounds__(256) void disphead_fwd_kernel(const float* __restri
 #pragma unroll
         for (int m = L / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
         if (c4 == 0 && q.valid) y[p] = 1.f / (1.f + expf(-(acc + b)));
+    }
+}
+
+constexpr int TR = 8, TW = 64, HR = TR + 2, HC = TW + 2, HP = HR * HC;   // output tile and its one-pixel halo
+
+__device__ __forceinline__ int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+
+// Forward, tile form: every pixel of the (reflected) halo is read ONCE; its nine tap products x[p].w[t] go to LDS and
+// an output pixel is the sum of nine LDS words.  (One pixel per lane group and nine global reads per pixel, the first
+// version, ran at 1.6 TB/s: the texture path, not HBM, was the limit.)
+template <int L>   // lanes per pixel, C = 4 L
+__global__ __launch_bounds__(256) void disphead_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int H, int W, int tiles_h, int tiles_w, int ntiles) {
+    constexpr int C = 4 * L, PPR = 256 / L;          // halo pixels per staging round
+    __shared__ float D[9][HR][HC];
+    const int tid = threadIdx.x, c4 = tid % L, ps = tid / L;
+    float4 wr[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t] = ld4(w + t * C + 4 * c4);
+    const float b = bias ? bias[0] : 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
+        const int h0 = th * TR, w0 = tw * TW;
+        const float* xn = x + (long)n * H * W * C + 4 * c4;
+        __syncthreads();                              // the previous tile's outputs have read D
+        for (int base = 0; base < HP; base += PPR) {
+            const int s = base + ps;
+            const bool in = s < HP;
+            const int sc = in ? s : HP - 1;
+            const int r = sc / HC, c = sc - r * HC;
+            // slot (r, c) stands for the virtual pixel (h0 - 1 + r, w0 - 1 + c) of the reflection-padded image
+            const int hh = clampi(refl(h0 - 1 + r, H), 0, H - 1), ww = clampi(refl(w0 - 1 + c, W), 0, W - 1);
+            const float4 v = ld4(xn + ((long)hh * W + ww) * C);
+            float p[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) p[t] = dot4(v, wr[t], 0.f);
+#pragma unroll
+            for (int m = 1; m < L; m <<= 1) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) p[t] += __shfl_xor(p[t], m);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (in && (t % L) == c4) D[t][r][c] = p[t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = tid; o < TR * TW; o += 256) {
+            const int r = o / TW, c = o - r * TW;
+            float acc = b;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc += D[kh * 3 + kw][r + kh][c + kw];
+            const int h = h0 + r, wq = w0 + c;
+            if (h < H && wq < W) y[((long)n * H + h) * W + wq] = 1.f / (1.f + expf(-acc));
+        }
     }
 }
 
@@ -178,6 +238,112 @@ __global__ __launch_bounds__(256) void disphead_bwd_weight_kernel(const float* _
     if (threadIdx.x == 0) bpart[blockIdx.x] = (bred[0] + bred[1]) + (bred[2] + bred[3]);
 }
 
+// Data and weight gradient in one pass: both are built from the same nine folded neighbour sums g_t[p]
+// (dx[p] = sum_t g_t[p] w[t], dw[t] = sum_p g_t[p] x[p]), so x is read once, dx written once, and dz = dy y (1 - y)
+// is evaluated once per pixel into an LDS halo tile instead of eighteen scalar loads per lane.
+template <int L>
+__global__ __launch_bounds__(256, 4) void disphead_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ add, int elu,
+                                                           float* __restrict__ dx, float* __restrict__ part,
+                                                           float* __restrict__ bpart, int H, int W, int tiles_h,
+                                                           int tiles_w, int ntiles) {
+    constexpr int C = 4 * L, PPW = 64 / L;
+    __shared__ float dzs[HR][HC];
+    __shared__ float4 red[4][9][L];
+    __shared__ float bred[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c4 = lane % L, pl = lane / L;
+    float4 wr[9], acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wr[t] = ld4(w + t * C + 4 * c4); acc[t] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    float bsum = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
+        const int h0 = th * TR, w0 = tw * TW;
+        __syncthreads();
+        for (int i = tid; i < HP; i += 256) {
+            const int r = i / HC, c = i - r * HC;
+            dzs[r][c] = dz_at(dy, y, n, h0 - 1 + r, w0 - 1 + c, H, W);
+        }
+        __syncthreads();
+        // a wave owns two rows of the tile
+        for (int j = 0; j < 2 * TW / PPW; ++j) {
+            const int pi = j * PPW + pl, r = 2 * wv + pi / TW, c = pi % TW;
+            const int h = h0 + r, wq = w0 + c;
+            const bool valid = h < H && wq < W;
+            float nb[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bq = 0; bq < 3; ++bq) nb[a][bq] = dzs[r + a][c + bq];      // dz at (h - 1 + a, wq - 1 + bq)
+            // rows: tap kh reads dz row h - kh + 1; next to a border the padded line folds onto the pixel too
+            float rs[3][3];
+            const bool top = h == 1, bot = h == H - 2, lef = wq == 1, rig = wq == W - 2;
+#pragma unroll
+            for (int bq = 0; bq < 3; ++bq) {
+                rs[0][bq] = nb[2][bq] + (top ? nb[0][bq] : 0.f);
+                rs[1][bq] = nb[1][bq];
+                rs[2][bq] = nb[0][bq] + (bot ? nb[2][bq] : 0.f);
+            }
+            float g[9];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                g[kh * 3 + 0] = rs[kh][2] + (lef ? rs[kh][0] : 0.f);
+                g[kh * 3 + 1] = rs[kh][1];
+                g[kh * 3 + 2] = rs[kh][0] + (rig ? rs[kh][2] : 0.f);
+            }
+            if (valid) {
+                const long off = (((long)n * H + h) * W + wq) * C + 4 * c4;
+                const float4 v = ld4(x + off);
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    o.x = fmaf(g[t], wr[t].x, o.x); o.y = fmaf(g[t], wr[t].y, o.y);
+                    o.z = fmaf(g[t], wr[t].z, o.z); o.w = fmaf(g[t], wr[t].w, o.w);
+                    acc[t].x = fmaf(g[t], v.x, acc[t].x); acc[t].y = fmaf(g[t], v.y, acc[t].y);
+                    acc[t].z = fmaf(g[t], v.z, acc[t].z); acc[t].w = fmaf(g[t], v.w, acc[t].w);
+                }
+                if (dx) {
+                    if (add) {                       // the other consumer's gradient of x (autograd's sum, done here)
+                        const float4 a = ld4(add + off);
+                        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                    }
+                    if (elu) {                       // x is an ELU output: hand back the gradient of its pre-activation
+                        o.x = v.x > 0.f ? o.x : o.x * (v.x + 1.f); o.y = v.y > 0.f ? o.y : o.y * (v.y + 1.f);
+                        o.z = v.z > 0.f ? o.z : o.z * (v.z + 1.f); o.w = v.w > 0.f ? o.w : o.w * (v.w + 1.f);
+                    }
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    f4v ov = {o.x, o.y, o.z, o.w};
+                    __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(dx + off));
+                }
+                bsum += nb[1][1];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = L; m < 64; m <<= 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            acc[t].x += __shfl_xor(acc[t].x, m); acc[t].y += __shfl_xor(acc[t].y, m);
+            acc[t].z += __shfl_xor(acc[t].z, m); acc[t].w += __shfl_xor(acc[t].w, m);
+        }
+        bsum += __shfl_xor(bsum, m);
+    }
+    if (pl == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[wv][t][c4] = acc[t];
+        if (c4 == 0) bred[wv] = bsum;
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * L; i += 256) {
+        const int t = i / L, c = i - t * L;
+        float4 s = red[0][t][c];
+        for (int k = 1; k < 4; ++k) { s.x += red[k][t][c].x; s.y += red[k][t][c].y; s.z += red[k][t][c].z; s.w += red[k][t][c].w; }
+        *reinterpret_cast<float4*>(part + (long)blockIdx.x * 9 * C + t * C + 4 * c) = s;
+    }
+    if (tid == 0) bpart[blockIdx.x] = (bred[0] + bred[1]) + (bred[2] + bred[3]);
+}
+
 // out[i] (+)= sum_s part[s][i]: 16 columns x 16 slice lanes per workgroup, lane partials combined in a fixed order
 __global__ __launch_bounds__(256) void disphead_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S,
                                                               int n, int accumulate) {
@@ -232,9 +398,18 @@ extern "C" int pd_disphead_fwd(const void* x, const void* w, const void* bias, v
     if (N == 0) return PD_OK;
     PD_REQUIRE(x && w && y, "pd_disphead_fwd: null tensor");
     PD_REQUIRE(pd::aligned16(x) && pd::aligned16(w), "pd_disphead_fwd: x and w must be 16-byte aligned");
-    const int npix = N * H * W;
-    PD_DISPATCH_L(C, hipLaunchKernelGGL(disphead_fwd_kernel<L>, dim3(grid_for(npix, C)), dim3(256), 0, (hipStream_t)stream,
-                                        (const float*)x, (const float*)w, (const float*)bias, (float*)y, npix, H, W));
+    if (C >= 64) {
+        const int npix = N * H * W;
+        PD_DISPATCH_L(C, hipLaunchKernelGGL(disphead_fwd_direct_kernel<L>, dim3(grid_for(npix, C)), dim3(256), 0,
+                                            (hipStream_t)stream, (const float*)x, (const float*)w, (const float*)bias,
+                                            (float*)y, npix, H, W));
+        return pd::check_launch("pd_disphead_fwd");
+    }
+    const int tiles_h = (H + TR - 1) / TR, tiles_w = (W + TW - 1) / TW;
+    const long ntiles = (long)N * tiles_h * tiles_w;
+    PD_DISPATCH_L(C, hipLaunchKernelGGL(disphead_fwd_kernel<L>, dim3((unsigned)(ntiles > 4096 ? 4096 : ntiles)), dim3(256), 0,
+                                        (hipStream_t)stream, (const float*)x, (const float*)w, (const float*)bias, (float*)y,
+                                        H, W, tiles_h, tiles_w, (int)ntiles));
     return pd::check_launch("pd_disphead_fwd");
 }
 
@@ -276,4 +451,32 @@ extern "C" int pd_disphead_bwd_weight(const void* dy, const void* y, const void*
                        9 * C, accumulate);
     if (dbias) hipLaunchKernelGGL(disphead_reduce_kernel, dim3(1), dim3(256), 0, st, bpart, (float*)dbias, (int)blocks, 1, accumulate);
     return pd::check_launch("pd_disphead_bwd_weight/reduce");
+}
+
+extern "C" int pd_disphead_bwd(const void* dy, const void* y, const void* x, const void* w, const void* add, int elu, void* dx,
+                               void* dw, void* dbias, void* workspace, size_t ws_bytes, int N, int H, int W, int C,
+                               int accumulate, void* stream) {
+    int rc = check_dims("pd_disphead_bwd", N, H, W, C);
+    if (rc) return rc;
+    if (N == 0) return PD_OK;
+    PD_REQUIRE(dy && y && x && w && dw && workspace, "pd_disphead_bwd: null tensor");
+    PD_REQUIRE(ws_bytes >= pd_disphead_workspace(C), "pd_disphead_bwd: workspace too small");
+    PD_REQUIRE(pd::aligned16(x) && pd::aligned16(w) && pd::aligned16(dx) && pd::aligned16(workspace) && pd::aligned16(add),
+               "pd_disphead_bwd: x, w, add, dx and workspace must be 16-byte aligned");
+    PD_REQUIRE(dx || (!add && !elu), "pd_disphead_bwd: add / elu modify dx, which is NULL");
+    const int tiles_h = (H + TR - 1) / TR, tiles_w = (W + TW - 1) / TW;
+    const long ntiles = (long)N * tiles_h * tiles_w;
+    const unsigned blocks = (unsigned)(ntiles > kWgradBlocks ? kWgradBlocks : ntiles);
+    float* part = (float*)workspace;
+    float* bpart = part + (size_t)kWgradBlocks * 9 * C;
+    hipStream_t st = (hipStream_t)stream;
+    PD_DISPATCH_L(C, hipLaunchKernelGGL(disphead_bwd_kernel<L>, dim3(blocks), dim3(256), 0, st, (const float*)dy,
+                                        (const float*)y, (const float*)x, (const float*)w, (const float*)add, elu, (float*)dx,
+                                        part, bpart, H, W, tiles_h, tiles_w, (int)ntiles));
+    rc = pd::check_launch("pd_disphead_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(disphead_reduce_kernel, dim3((9 * C + 15) / 16), dim3(256), 0, st, part, (float*)dw, (int)blocks,
+                       9 * C, accumulate);
+    if (dbias) hipLaunchKernelGGL(disphead_reduce_kernel, dim3(1), dim3(256), 0, st, bpart, (float*)dbias, (int)blocks, 1, accumulate);
+    return pd::check_launch("pd_disphead_bwd/reduce");
 }

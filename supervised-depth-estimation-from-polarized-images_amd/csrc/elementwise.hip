@@ -7,6 +7,7 @@
 // torchvision BasicBlock bn/relu/add, resnet maxpool (resnet_encoder.py:813-818),
 // layers.py:446-449 upsample + depth_decoder.py:64-67 cat, trainer.py:238-240,442 Adam.
 #include "pd_common.h"
+#include <cstdlib>
 #include <cstdint>
 
 namespace {
@@ -558,7 +559,8 @@ __global__ __launch_bounds__(EW_T) void upcat_fwd_kernel(const float* __restrict
 }
 
 // da[n,h,w,:] = sum over the (up to 4x4) output pixels that read a[h,w], times their bilinear weights
-__global__ __launch_bounds__(EW_T) void up_bwd_kernel(const float* __restrict__ dout, long ld_d,
+// elu_y != NULL: a = ELU(z) came from a ConvBlock; da is multiplied by ELU'(z) (through a) and leaves as dz
+__global__ __launch_bounds__(EW_T) void up_bwd_kernel(const float* __restrict__ dout, long ld_d, const float* __restrict__ elu_y,
                                                       float* __restrict__ da, int N, int H, int W, int Ca) {
     const int cq = Ca >> 2;
     const int Ho = 2 * H, Wo = 2 * W;
@@ -588,6 +590,11 @@ __global__ __launch_bounds__(EW_T) void up_bwd_kernel(const float* __restrict__ 
                 const float ww = wy * wx;
                 acc.x += ww * g.x; acc.y += ww * g.y; acc.z += ww * g.z; acc.w += ww * g.w;
             }
+        }
+        if (elu_y) {
+            const float4 o = ld4(elu_y + i * 4);
+            acc.x = o.x > 0.f ? acc.x : acc.x * (o.x + 1.f); acc.y = o.y > 0.f ? acc.y : acc.y * (o.y + 1.f);
+            acc.z = o.z > 0.f ? acc.z : acc.z * (o.z + 1.f); acc.w = o.w > 0.f ? acc.w : acc.w * (o.w + 1.f);
         }
         st4(da + i * 4, acc);
     }
@@ -819,7 +826,8 @@ static int chain_check(int N, int H, int W, int C, int pool) {
 extern "C" long pd_chain_bwd_rows(int N, int H, int W, int C) {
     const long items = (long)N * H * W * (C / 4);
     long b = (items + EW_T - 1) / EW_T;
-    if (b > 2048) b = 2048;
+    static const long cap = getenv("PD_CHAIN_ROWS") ? atol(getenv("PD_CHAIN_ROWS")) : 1024;
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return b;
 }
@@ -925,13 +933,18 @@ extern "C" int pd_upcat_fwd(const void* a, const void* skip, long ld_skip, void*
     return pd::check_launch("pd_upcat_fwd");
 }
 
-extern "C" int pd_up_bwd(const void* dout, long ld_d, void* da, int N, int H, int W, int Ca, void* stream) {
+extern "C" int pd_up_bwd_elu(const void* dout, long ld_d, const void* elu_y, void* da, int N, int H, int W, int Ca,
+                             void* stream) {
     PD_REQUIRE(dout && da && N >= 0 && H > 0 && W > 0 && Ca > 0 && Ca % 4 == 0 && ld_d >= Ca && ld_d % 4 == 0,
                "pd_up_bwd: bad arguments");
     if (N == 0) return PD_OK;
     hipLaunchKernelGGL(up_bwd_kernel, dim3(ew_grid((long)N * H * W * (Ca / 4))), dim3(EW_T), 0, (hipStream_t)stream,
-                       (const float*)dout, ld_d, (float*)da, N, H, W, Ca);
+                       (const float*)dout, ld_d, (const float*)elu_y, (float*)da, N, H, W, Ca);
     return pd::check_launch("pd_up_bwd");
+}
+
+extern "C" int pd_up_bwd(const void* dout, long ld_d, void* da, int N, int H, int W, int Ca, void* stream) {
+    return pd_up_bwd_elu(dout, ld_d, nullptr, da, N, H, W, Ca, stream);
 }
 
 extern "C" int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int act, void* stream) {

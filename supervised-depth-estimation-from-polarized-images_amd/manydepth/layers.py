@@ -33,8 +33,8 @@ class Conv3x3(nn.Module):
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
         self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x, act=ops.ACT_NONE):
-        return PF.reflect_conv_act(x, self.conv, act)
+    def forward(self, x, act=ops.ACT_NONE, **mails):
+        return PF.reflect_conv_act(x, self.conv, act, **mails)
 
 
 class ConvBlock(nn.Module):
@@ -45,8 +45,8 @@ class ConvBlock(nn.Module):
         self.conv = Conv3x3(in_channels, out_channels)
         self.nonlin = nn.ELU(inplace=True)
 
-    def forward(self, x):
-        return self.conv(x, act=ops.ACT_ELU)
+    def forward(self, x, **mails):
+        return self.conv(x, act=ops.ACT_ELU, **mails)
 
 
 def upsample(x):

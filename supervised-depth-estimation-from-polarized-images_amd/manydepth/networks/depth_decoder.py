@@ -43,11 +43,18 @@ class DepthDecoder(nn.Module):
     def forward(self, input_features):
         self.outputs = {}
         x = input_features[-1]
+        # ActGrad mailboxes: the ELU derivative of every ConvBlock is applied by the kernel that produces its output
+        # gradient (upsample gradient / disparity head), and the head sums the two gradients of upconv(i,1)'s output
+        fuse = PF.USE_ACT_FUSION and torch.is_grad_enabled()
+        pend = None
         for i in range(4, -1, -1):
-            x = self.convs[("upconv", i, 0)](x)
+            m0 = PF.ActGrad() if fuse else None
+            x = self.convs[("upconv", i, 0)](x, act_mail=m0, dx_mail=pend)
             skip = input_features[i - 1] if self.use_skips and i > 0 else None
-            x = PF.upcat(x, skip)
-            x = self.convs[("upconv", i, 1)](x)
+            x = PF.upcat(x, skip, act_mail=m0)
+            m1 = PF.ActGrad(expect_deposit=i > 0) if fuse and i in self.scales else None
+            x = self.convs[("upconv", i, 1)](x, act_mail=m1)
             if i in self.scales:
-                self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act=ops.ACT_SIGMOID)
+                self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act=ops.ACT_SIGMOID, head_mail=m1)
+            pend = m1
         return self.outputs

@@ -60,6 +60,7 @@ SIGNATURES = {
     "pd_maxpool3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_upcat_fwd": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),
     "pd_up_bwd": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp]),
+    "pd_up_bwd_elu": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_act_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "pd_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_reflect_dgrad_border": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "pd_disphead_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_disphead_workspace": (_sz, [_i]),
     "pd_disphead_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
+    "pd_disphead_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "pd_ssim_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pd_depth_metrics": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _l, _f, _f, _vp]),
 }

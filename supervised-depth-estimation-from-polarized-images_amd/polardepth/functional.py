@@ -156,7 +156,28 @@ class SkipGrad:
         self.grad = None
 
 
+class ActGrad:
+    """Hand-over between the backward nodes around one ELU output y of the depth decoder (depth_decoder.py:60-71).
+    The node that produced y (ReflectConvActFn) needs dL/dz = dL/dy * ELU'(z); the consumers of y can deliver exactly
+    that from their own kernels instead of a separate pass over the tensor:
+      * y has ONE consumer (upconv(i,0) -> upsample): pd_up_bwd_elu multiplies by ELU'(.) and sets `activated`;
+      * y has two (upconv(i,1) -> disparity head and next level's first convolution): the convolution deposits its
+        data gradient in `grad` instead of returning it, the head (which autograd runs later, its node is older) adds
+        it, multiplies by ELU'(.) and sets `activated` -- autograd's add kernel and pd_act_bwd are both gone.
+    Any other order falls back to the plain route: a head that finds no deposit although one is expected sets
+    `closed`, after which the convolution returns its gradient to autograd as usual."""
+    __slots__ = ("grad", "activated", "closed", "expect_deposit")
+
+    def __init__(self, expect_deposit=False):
+        self.grad = None
+        self.activated = False
+        self.closed = False
+        self.expect_deposit = expect_deposit
+
+
+USE_ACT_FUSION = os.environ.get("PD_ACT_FUSION", "1") != "0"
 USE_SKIP_FUSION = os.environ.get("PD_SKIP_FUSION", "1") != "0"
+USE_DISPHEAD_FUSED = os.environ.get("PD_DISPHEAD_FUSED", "1") != "0"   # disparity heads: data + weight gradient in one pass
 USE_REFLECT_BORDER = os.environ.get("PD_REFLECT_BORDER", "1") != "0"   # reflect-conv dX = pad-1 dgrad + border strips (no fold pass)
 
 
@@ -352,10 +373,11 @@ class ReflectConvActFn(torch.autograd.Function):
     """layers.Conv3x3 (ReflectionPad2d(1) + Conv2d(3)) followed by ELU (ConvBlock) or sigmoid (dispconv)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, act_mail=None, dx_mail=None):
         x = ops.as_nhwc(x)
         y = ops.conv2d_fwd(x, weight, bias, 1, 1, mode=ops.MODE_REFLECT, act=act)
         ctx.act = act
+        ctx.mails = (act_mail, dx_mail)         # ActGrad of this node's output / of its input
         ctx.params = (weight, bias)
         ctx.save_for_backward(x, y)
         return y
@@ -368,7 +390,11 @@ class ReflectConvActFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=CL) if not (dy.is_contiguous(memory_format=CL) or Co == 1) else dy
         if Co == 1 and not dy.is_contiguous():
             dy = dy.contiguous()
-        if ctx.act != ops.ACT_NONE:
+        act_mail, dx_mail = ctx.mails
+        pre_activated = act_mail is not None and act_mail.activated
+        if pre_activated:
+            act_mail.activated = False          # the consumer already multiplied by the activation derivative
+        if ctx.act != ops.ACT_NONE and not pre_activated:
             dz = torch.empty_like(y)
             check(lib.pd_act_bwd(ptr(dy), ptr(y), ptr(dz), y.numel(), ctx.act, stream_ptr()), "pd_act_bwd")
         else:
@@ -395,10 +421,14 @@ class ReflectConvActFn(torch.autograd.Function):
                 dxp = ops.conv2d_dgrad(dz, weight, (H + 2, W + 2), 1, 0)
                 dx = ops.empty_nhwc(N, Ci, H, W, dy.device)
                 check(lib.pd_reflect_fold(ptr(dxp), ptr(dx), N, H, W, Ci, stream_ptr()), "pd_reflect_fold")
+            if dx_mail is not None and not dx_mail.closed:
+                if dx_mail.grad is not None:
+                    raise RuntimeError("ActGrad: a data gradient was deposited twice")
+                dx_mail.grad, dx = dx, None     # the disparity head of the same tensor sums and activates it
         for p in (weight, bias):
             if p is not None:
                 _ready(p)
-        return dx, None, None, None
+        return dx, None, None, None, None, None
 
 
 class DispHeadFn(torch.autograd.Function):
@@ -406,12 +436,13 @@ class DispHeadFn(torch.autograd.Function):
     (pd_disphead_*) instead of an MFMA tile with a single useful column."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, head_mail=None):
         x = ops.as_nhwc(x)
         N, C, H, W = x.shape
         y = torch.empty((N, 1, H, W), dtype=torch.float32, device=x.device)
         check(lib.pd_disphead_fwd(ptr(x), ptr(ops.weight_cl(weight)), ptr(bias), ptr(y), N, H, W, C, stream_ptr()),
               "pd_disphead_fwd")
+        ctx.mail = head_mail                    # ActGrad of x (an ELU output with, possibly, a second consumer)
         ctx.params = (weight, bias)
         ctx.save_for_backward(x, y)
         return y
@@ -422,6 +453,31 @@ class DispHeadFn(torch.autograd.Function):
         weight, bias = ctx.params
         N, C, H, W = x.shape
         dy = dy.contiguous()
+        mail = ctx.mail
+        if weight.requires_grad and USE_DISPHEAD_FUSED:
+            # one pass: x read once, dx written once, dw / dbias from the same folded neighbour sums
+            db = grad_buf(bias) if bias is not None and bias.requires_grad else None
+            gw = grad_buf(weight)
+            dx = ops.empty_nhwc(N, C, H, W, x.device) if ctx.needs_input_grad[0] else None
+            add, elu = None, 0
+            if mail is not None and dx is not None:
+                if mail.grad is not None:
+                    add, mail.grad = mail.grad, None
+                    if tuple(add.shape) != tuple(x.shape) or not add.is_contiguous(memory_format=CL):
+                        raise RuntimeError("ActGrad: the deposited gradient does not match the head's input")
+                if add is not None or not mail.expect_deposit:
+                    elu, mail.activated = 1, True
+                else:
+                    mail.closed = True          # the other consumer has not run yet: autograd sums, pd_act_bwd activates
+            ws = ops._workspace(lib.pd_disphead_workspace(C), x.device)
+            check(lib.pd_disphead_bwd(ptr(dy), ptr(y), ptr(x), ptr(ops.weight_cl(weight)), ptr(add), elu, ptr(dx), ptr(gw),
+                                      ptr(db), ptr(ws), ws.numel(), N, H, W, C, 1, stream_ptr()), "pd_disphead_bwd")
+            for p in (weight, bias):
+                if p is not None:
+                    _ready(p)
+            return dx, None, None, None
+        if mail is not None:
+            mail.closed = True                  # unfused kernels: plain route (a gradient already deposited is added below)
         if weight.requires_grad:
             db = grad_buf(bias) if bias is not None and bias.requires_grad else None
             gw = grad_buf(weight)
@@ -437,25 +493,35 @@ class DispHeadFn(torch.autograd.Function):
             dx = ops.empty_nhwc(N, C, H, W, x.device)
             check(lib.pd_disphead_bwd_data(ptr(dy), ptr(y), ptr(ops.weight_cl(weight)), ptr(dx), N, H, W, C, stream_ptr()),
                   "pd_disphead_bwd_data")
+            if mail is not None and mail.grad is not None:
+                dx, mail.grad = dx + mail.grad, None
+        elif mail is not None and mail.grad is not None:
+            raise RuntimeError("ActGrad: a gradient was deposited but the head's input needs none")
         for p in (weight, bias):
             if p is not None:
                 _ready(p)
-        return dx, None, None
+        return dx, None, None, None
 
 
-def reflect_conv_act(x, conv, act):
+def reflect_conv_act(x, conv, act, act_mail=None, dx_mail=None, head_mail=None):
+    """act_mail / dx_mail / head_mail: ActGrad mailboxes wired by DepthDecoder.forward (None = plain autograd route);
+    act_mail belongs to this convolution's ELU output, dx_mail and head_mail to its input."""
     w = conv.weight
+    if act_mail is not None and act != ops.ACT_ELU:
+        raise ValueError("ActGrad hand-over is implemented for ELU outputs")
     if (act == ops.ACT_SIGMOID and w.shape[0] == 1 and w.shape[1] in (16, 32, 64, 128) and USE_DISP_HEADS
             and x.shape[2] >= 2 and x.shape[3] >= 2):
-        return DispHeadFn.apply(x, w, conv.bias)
-    return ReflectConvActFn.apply(x, w, conv.bias, act)
+        return DispHeadFn.apply(x, w, conv.bias, head_mail)
+    if head_mail is not None:
+        head_mail.closed = True                 # no direct head kernel for this shape: plain route
+    return ReflectConvActFn.apply(x, w, conv.bias, act, act_mail, dx_mail)
 
 
 class UpCatFn(torch.autograd.Function):
     """cat([bilinear_x2(a), skip], 1)  (layers.upsample + depth_decoder.py:64-67)."""
 
     @staticmethod
-    def forward(ctx, a, skip):
+    def forward(ctx, a, skip, act_mail=None):
         a = ops.as_nhwc(a)
         N, Ca, H, W = a.shape
         Cs, ld_s = 0, 0
@@ -465,6 +531,9 @@ class UpCatFn(torch.autograd.Function):
         out = ops.empty_nhwc(N, Ca + Cs, 2 * H, 2 * W, a.device)
         check(lib.pd_upcat_fwd(ptr(a), ptr(skip), ld_s, ptr(out), N, H, W, Ca, Cs, stream_ptr()), "pd_upcat_fwd")
         ctx.dims = (N, Ca, Cs, H, W)
+        ctx.mail = act_mail                     # ActGrad of a (ELU output whose only consumer this node is)
+        if act_mail is not None:
+            ctx.save_for_backward(a)            # the same tensor the producing convolution keeps: no extra memory
         return out
 
     @staticmethod
@@ -472,13 +541,17 @@ class UpCatFn(torch.autograd.Function):
         N, Ca, Cs, H, W = ctx.dims
         dout, ld = nhwc_view(dout)
         da = ops.empty_nhwc(N, Ca, H, W, dout.device)
-        check(lib.pd_up_bwd(ptr(dout), ld, ptr(da), N, H, W, Ca, stream_ptr()), "pd_up_bwd")
+        elu_y = None
+        if ctx.mail is not None:
+            (elu_y,) = ctx.saved_tensors
+            ctx.mail.activated = True
+        check(lib.pd_up_bwd_elu(ptr(dout), ld, ptr(elu_y), ptr(da), N, H, W, Ca, stream_ptr()), "pd_up_bwd")
         dskip = dout[:, Ca:] if Cs and ctx.needs_input_grad[1] else None
-        return da, dskip
+        return da, dskip, None
 
 
-def upcat(a, skip=None):
-    return UpCatFn.apply(a, skip)
+def upcat(a, skip=None, act_mail=None):
+    return UpCatFn.apply(a, skip, act_mail)
 
 
 class MaxPool3s2Fn(torch.autograd.Function):

@@ -285,12 +285,15 @@ def test_stem_as_space_to_depth_conv(C):
     _close(dw.cpu(), wr.grad)
 
 
-@pytest.mark.parametrize("case", [(2, 16, 7, 9), (1, 32, 2, 2), (3, 64, 3, 5), (1, 128, 6, 4), (2, 16, 33, 21)])
-def test_disparity_head_direct_kernels(case):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("case", [(2, 16, 7, 9), (1, 32, 2, 2), (3, 64, 3, 5), (1, 128, 6, 4), (2, 16, 33, 21), (2, 16, 19, 131),
+                                  (1, 32, 64, 80)])
+def test_disparity_head_direct_kernels(case, fused, monkeypatch):
     """pd_disphead_{fwd,bwd_data,bwd_weight} (sigmoid(Conv3x3) with one output channel, reflection padding and its
     gradient fold built in) vs autograd through a PyTorch fp32 CPU reference, including the smallest legal images
     (H or W of 2 and 3, where both borders fold onto the same pixel) and ragged pixel counts."""
     from polardepth import functional as PF
+    monkeypatch.setattr(PF, "USE_DISPHEAD_FUSED", fused)     # pd_disphead_bwd, or pd_disphead_bwd_data + _bwd_weight
     N, C, H, W = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, C, H, W, generator=g)

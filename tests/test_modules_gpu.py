@@ -108,6 +108,35 @@ def test_depth_decoder_matches_reference():
     assert n == 28
 
 
+@pytest.mark.parametrize("scales", [[0, 1, 2, 3], [0, 2]])
+def test_decoder_activation_gradient_handover_is_bit_exact(scales, monkeypatch):
+    """ActGrad mailboxes (ELU derivative applied by pd_up_bwd_elu / pd_disphead_bwd, the head summing the two
+    gradients of upconv(i,1)'s output) against the plain route (autograd add + pd_act_bwd): identical bits, for all
+    heads present and for levels without a head."""
+    from manydepth import networks
+    from polardepth import functional as PF
+
+    def run(fuse):
+        monkeypatch.setattr(PF, "USE_ACT_FUSION", fuse)
+        feats = [T(G4[f"dec.feat.{i}"]).cuda().requires_grad_(True) for i in range(5)]
+        torch.manual_seed(3)
+        dd = networks.DepthDecoder(np.array([64, 64, 128, 256, 512]), scales).cuda()
+        res = dd(feats)
+        obj = 0
+        for s in scales:
+            w = torch.randn(res[("disp", s)].shape, generator=torch.Generator().manual_seed(200 + s)).cuda()
+            obj = obj + (res[("disp", s)] * w).sum()
+        obj.backward()
+        PF.sync_wgrad_stream()
+        torch.cuda.synchronize()
+        return [f.grad.clone() for f in feats] + [p.grad.clone() for p in dd.parameters()]
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) and len(a) > 20
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_resnet_stem_matches_oracle():
     """No reference fixture possible (torchvision absent): HIP façade vs the CPU restatement."""
     from manydepth import networks
