@@ -149,10 +149,16 @@ int pd_conv16_wgrad(const void* x, const void* dz, void* dw, void* dbias, void* 
 
 /* Stride-2 data gradient by output parity (3x3 / stride 2 / pad 1, even input grid; resnet18 layer2.0.conv1,
  * resnet_encoder.py / torchvision BasicBlock): pd_dgrad_s2_filters turns the transposed filter wt [Cin][3][3][Cout] into
- * four 2x2 sub-filters wsub [4][Cin][2][2][Cout] (class = 2*(ih%2) + iw%2); each class is pd_conv2d(mode 2, KH = KW = 2,
- * stride 1, pad 1) of dY onto the [N,Ho,Wo,Cin] sub-grid; pd_interleave4 scatters the four sub-grids
- * [4][N][Ho][Wo][C] into dX [N][2Ho][2Wo][C].  16 tap-units instead of the 36 of the masked transposed gather. */
+ * the four exact class filters, back to back in wsub (9*Cin*Cout floats): class c = 2*(ih%2) + iw%2 is
+ * [Cin][1 + ih%2][1 + iw%2][Cout] at float offset Cin*Cout*{0,1,3,5}[c]; each class is pd_conv2d_rect(mode 2,
+ * KH = 1 + ih%2, KW = 1 + iw%2, pad_h = ih%2, pad_w = iw%2) of dY onto the [N,Ho,Wo,Cin] sub-grid; pd_interleave4
+ * scatters the four sub-grids [4][N][Ho][Wo][C] into dX [N][2Ho][2Wo][C].  9 tap-units instead of the 36 of the masked
+ * transposed gather.
+ * pd_conv2d_rect: stride-1 convolution (mode 0) / data gradient (mode 2) with a KH x KW filter and separate row /
+ * column padding, no bias / activation; needs C % 32 == 0 and 16-byte aligned NHWC operands (uniform-tap kernel). */
 int pd_dgrad_s2_filters(const void* wt, void* wsub, int Cin, int Cout, void* stream);
+int pd_conv2d_rect(const void* x, const void* w, void* y, int N, int H, int W, int C, long sN, long sH, long sW, long sC,
+                   int Ho, int Wo, int Cout, int KH, int KW, int pad_h, int pad_w, int mode, long ldy, void* stream);
 int pd_interleave4(const void* sub, void* dx, int N, int Ho, int Wo, int C, void* stream);
 
 /* y = conv(x, w) + addend: the same convolution (no bias / scale / activation / statistics) with an NHWC tensor of the

@@ -49,6 +49,7 @@ struct ConvArgs {
     long sN, sH, sW, sC;     // element strides of x
     int Ho, Wo, Co;          // output grid / channels
     int KH, KW, stride, pad;
+    int pad_w;               // column padding when it differs from `pad` (rows); uniform-tap kernel only
     int mode, act;
     int affine;
     float sub, div;
@@ -548,8 +549,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
     // Descriptor of the activation: first image of the tile, moved back by the padding (zero mode) or by the part of
     // the filter extent the padding does not cover (data gradient, taps walk backwards) -- see the offsets below.
     const int img0 = (int)(m0 / hw);
-    const long shift = MODE == MODE_REFLECT ? 0L : MODE == MODE_ZERO ? (long)a.pad * (a.sH + a.sW)
-                                         : (long)(a.KH - 1 - a.pad) * a.sH + (long)(a.KW - 1 - a.pad) * a.sW;
+    const long shift = MODE == MODE_REFLECT ? 0L : MODE == MODE_ZERO ? (long)a.pad * a.sH + (long)a.pad_w * a.sW
+                                         : (long)(a.KH - 1 - a.pad) * a.sH + (long)(a.KW - 1 - a.pad_w) * a.sW;
     const long rest = (((long)a.N - img0) * a.sN + shift) * 4;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
     const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, a.w_bytes);
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
         const int ow = (int)rem - oh * a.Wo;
         if constexpr (MODE == MODE_REFLECT) {
             va[i] = (unsigned)((int)dn * (int)a.sN) * 4u + col4;      // image base; the pixel part follows the tap
-            rfh[i] = oh * a.stride - a.pad; rfw[i] = ow * a.stride - a.pad;
+            rfh[i] = oh * a.stride - a.pad; rfw[i] = ow * a.stride - a.pad_w;
             inv[i] = m < a.M ? 0u : 0xffffffffu;
             continue;
         }
@@ -579,10 +580,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
         int lo_h, hi_h, lo_w, hi_w;
         if (MODE == MODE_ZERO) {            // ih = oh*stride - pad + kh
             lo_h = a.pad - oh * a.stride; hi_h = a.H + lo_h;
-            lo_w = a.pad - ow * a.stride; hi_w = a.W + lo_w;
+            lo_w = a.pad_w - ow * a.stride; hi_w = a.W + lo_w;
         } else {                            // ih = oh + pad - kh
             hi_h = oh + a.pad + 1; lo_h = hi_h - a.H;
-            hi_w = ow + a.pad + 1; lo_w = hi_w - a.W;
+            hi_w = ow + a.pad_w + 1; lo_w = hi_w - a.W;
         }
         lo_h = min(max(lo_h, 0), a.KH); hi_h = min(max(hi_h, 0), a.KH);
         lo_w = min(max(lo_w, 0), a.KW); hi_w = min(max(hi_w, 0), a.KW);
@@ -758,7 +759,7 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
     static const bool dma = !(getenv("PD_CONV_DMA") && getenv("PD_CONV_DMA")[0] == '0');   // direct-to-LDS staging (default on)
     static const bool uni_on = !(getenv("PD_CONV_UNI") && getenv("PD_CONV_UNI")[0] == '0');  // uniform-tap kernel (default on)
     if constexpr (BN % 32 == 0 && WN == 32) {
-        const bool uni = vec && dma && uni_on && a.C % BK == 0 && a.KH * a.KW <= 31 && a.pad < a.KH && a.pad < a.KW &&
+        const bool uni = vec && dma && uni_on && a.C % BK == 0 && a.KH * a.KW <= 31 && a.pad < a.KH && a.pad_w < a.KW &&
                          (a.mode == MODE_ZERO || a.mode == MODE_REFLECT || (a.mode == MODE_TRANSPOSED && a.sshift == 0));
         if (uni && a.mode == MODE_REFLECT) {       // (pad < H, W is checked by pd_conv2d)
             hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_REFLECT, 2>), grid, block, 0, st, a);
@@ -779,6 +780,7 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
             return pd::check_launch("pd_conv2d");
         }
     }
+    if (a.pad_w != a.pad) return pd::fail(PD_EINVAL, "pd_conv2d_rect: shape outside the uniform-tap kernel (C %% 32, 16-byte aligned NHWC)");
     if (vec && dma) {
         if (a.mode == MODE_ZERO) PD_LAUNCH_DMA(MODE_ZERO);
         else if (a.mode == MODE_REFLECT) PD_LAUNCH_DMA(MODE_REFLECT);
@@ -815,7 +817,7 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
                        const void* addend, long ld_add,
                        int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                        int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
-                       int affine, float sub, float div, long ldy, void* stream);
+                       int affine, float sub, float div, long ldy, void* stream, int pad_w = -1);
 
 extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
                          int N, int H, int W, int C, long sN, long sH, long sW, long sC,
@@ -833,11 +835,22 @@ extern "C" int pd_conv2d_add(const void* x, const void* w, const void* addend, l
                        stride, pad, mode, ACT_NONE, 0, 0.f, 1.f, ldy, stream);
 }
 
+// rows x columns filter with its own column padding: the exact sub-filters (1x1, 1x2, 2x1, 2x2) of a stride-2 data
+// gradient split by output parity (pd_dgrad_s2_filters); stride 1, no bias / activation, uniform-tap kernel only
+extern "C" int pd_conv2d_rect(const void* x, const void* w, void* y, int N, int H, int W, int C, long sN, long sH, long sW,
+                              long sC, int Ho, int Wo, int Co, int KH, int KW, int pad_h, int pad_w, int mode, long ldy,
+                              void* stream) {
+    PD_REQUIRE(pad_w >= 0 && mode != MODE_REFLECT, "pd_conv2d_rect: bad padding / mode");
+    return conv2d_impl(x, w, nullptr, nullptr, y, nullptr, nullptr, 0, N, H, W, C, sN, sH, sW, sC, Ho, Wo, Co, KH, KW, 1,
+                       pad_h, mode, ACT_NONE, 0, 0.f, 1.f, ldy, stream, pad_w);
+}
+
 static int conv2d_impl(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
                        const void* addend, long ld_add,
                        int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                        int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
-                       int affine, float sub, float div, long ldy, void* stream) {
+                       int affine, float sub, float div, long ldy, void* stream, int pad_w) {
+    if (pad_w < 0) pad_w = pad;
     PD_REQUIRE(x && w && y, "pd_conv2d: null tensor");
     PD_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && Co > 0, "pd_conv2d: bad dims");
     PD_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "pd_conv2d: bad filter geometry");
@@ -850,11 +863,11 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
         PD_REQUIRE((1 << sshift) == stride, "pd_conv2d: transposed mode needs a power-of-two stride");
         // (a SMALLER x grid is the leading part of that output grid: the missing rows / columns read as zero -- the
         //  sub-filters of a phase-decomposed stride-2 data gradient need exactly that, see pd_dgrad_s2_filters)
-        PD_REQUIRE(H <= (Ho + 2 * pad - KH) / stride + 1 && W <= (Wo + 2 * pad - KW) / stride + 1,
+        PD_REQUIRE(H <= (Ho + 2 * pad - KH) / stride + 1 && W <= (Wo + 2 * pad_w - KW) / stride + 1,
                    "pd_conv2d: transposed: x grid exceeds the forward output grid of a %dx%d input", Ho, Wo);
     } else {
         // a smaller output grid computes the leading Ho x Wo outputs only (asymmetric bottom/right padding)
-        PD_REQUIRE(Ho <= (H + 2 * pad - KH) / stride + 1 && Wo <= (W + 2 * pad - KW) / stride + 1,
+        PD_REQUIRE(Ho <= (H + 2 * pad - KH) / stride + 1 && Wo <= (W + 2 * pad_w - KW) / stride + 1,
                    "pd_conv2d: output grid does not match input/filter geometry");
     }
     if (N == 0) return PD_OK;
@@ -862,7 +875,7 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
     a.x = (const float*)x; a.w = (const float*)w; a.bias = (const float*)bias; a.oscale = (const float*)out_scale; a.y = (float*)y; a.stats = (float*)stats;
     a.add = (const float*)addend; a.ld_add = ld_add;
     a.N = N; a.H = H; a.W = W; a.C = C; a.sN = sN; a.sH = sH; a.sW = sW; a.sC = sC;
-    a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_w = pad_w;
     a.mode = mode; a.act = act; a.affine = affine; a.sub = sub; a.div = div;
     a.K = KH * KW * C; a.M = (long)N * Ho * Wo; a.ldy = ldy; a.sshift = sshift;
     auto magic = [](long d, unsigned& mg, unsigned& sh) {       // n / d == mulhi(n, mg) >> sh for 0 <= n < 2^31, d >= 2
@@ -1630,23 +1643,27 @@ extern "C" int pd_weight_transpose_batched(const void* src, void* dst, const voi
 // dX of a 3x3 / stride-2 / pad-1 convolution: an input pixel (ih, iw) receives only the taps with (ih + 1 - kh) and
 // (iw + 1 - kw) even -- 1, 2, 2 or 4 of the 9, by the parity of (ih, iw).  The masked transposed gather multiplies zeros
 // for the other taps (three quarters of its MFMAs).  Per parity class (ph, pw) the gradient on the sub-grid
-// (2i + ph, 2j + pw) is a stride-1 2x2 "pad 1" correlation of dY with a sub-filter (odd classes take taps 0 and 2,
-// even classes tap 1 next to a zero): four uniform-tap launches of 16 tap-units instead of 36, then one interleave.
+// (2i + ph, 2j + pw) is a stride-1 correlation of dY with a (1 + ph) x (1 + pw) sub-filter (odd parity: taps 0 and 2
+// with padding 1, even parity: tap 1 alone): four uniform-tap launches (pd_conv2d_rect) of exactly the 9 tap-units
+// instead of 36, then one interleave.
 namespace {
-// wt [Ci][3][3][Co] (data-gradient operand) -> wsub [4][Ci][2][2][Co]
+// wt [Ci][3][3][Co] (data-gradient operand) -> wsub: the four class filters back to back, class (ph, pw) =
+// [Ci][1 + ph][1 + pw][Co] at float offset Ci*Co*{0, 1, 3, 5}[2 ph + pw]  (9 Ci Co floats in all)
 __global__ __launch_bounds__(256) void dgrad_s2_filters_kernel(const float* __restrict__ wt, float* __restrict__ wsub,
                                                                int Ci, int Co) {
-    const long total = 4L * Ci * 4 * Co;
+    const long cc = (long)Ci * Co, total = 9 * cc;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int co = (int)(i % Co);
-        long r = i / Co;
-        const int kw2 = (int)(r & 1), kh2 = (int)((r >> 1) & 1); r >>= 2;
-        const int ci = (int)(r % Ci);
-        const int cls = (int)(r / Ci), ph = cls >> 1, pw = cls & 1;
-        // transposed-mode tap k' reads dY[i + 1 - k']: odd parity: k' = 0 -> filter tap 0 (oh = i + 1), k' = 1 -> tap 2 (oh = i);
-        // even parity: k' = 1 -> tap 1 (oh = i), k' = 0 -> nothing
-        const int kh = ph ? (kh2 ? 2 : 0) : (kh2 ? 1 : -1), kw = pw ? (kw2 ? 2 : 0) : (kw2 ? 1 : -1);
-        wsub[i] = (kh < 0 || kw < 0) ? 0.f : wt[(((long)ci * 3 + kh) * 3 + kw) * Co + co];
+        const int cls = i < cc ? 0 : i < 3 * cc ? 1 : i < 5 * cc ? 2 : 3, ph = cls >> 1, pw = cls & 1;
+        const long base = cc * (cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5);
+        long r = i - base;
+        const int co = (int)(r % Co); r /= Co;
+        const int kw2 = pw ? (int)(r & 1) : 0; r >>= pw;
+        const int kh2 = ph ? (int)(r & 1) : 0; r >>= ph;
+        const int ci = (int)r;
+        // transposed-mode tap k' reads dY[i + pad - k']: odd parity (2 taps, pad 1): k' = 0 -> filter tap 0 (oh = i + 1),
+        // k' = 1 -> tap 2 (oh = i); even parity (1 tap, pad 0): filter tap 1 (oh = i)
+        const int kh = ph ? (kh2 ? 2 : 0) : 1, kw = pw ? (kw2 ? 2 : 0) : 1;
+        wsub[i] = wt[(((long)ci * 3 + kh) * 3 + kw) * Co + co];
     }
 }
 // sub [4][N][Ho][Wo][C] -> dx [N][2 Ho][2 Wo][C]
@@ -1670,7 +1687,7 @@ __global__ __launch_bounds__(256) void interleave4_kernel(const float* __restric
 
 extern "C" int pd_dgrad_s2_filters(const void* wt, void* wsub, int Ci, int Co, void* stream) {
     PD_REQUIRE(wt && wsub && Ci > 0 && Co > 0, "pd_dgrad_s2_filters: bad arguments");
-    const long total = 16L * Ci * Co, blocks = (total + 255) / 256;
+    const long total = 9L * Ci * Co, blocks = (total + 255) / 256;
     hipLaunchKernelGGL(dgrad_s2_filters_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)wt, (float*)wsub, Ci, Co);
     return pd::check_launch("pd_dgrad_s2_filters");

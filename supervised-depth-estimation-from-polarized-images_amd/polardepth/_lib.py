@@ -38,6 +38,7 @@ SIGNATURES = {
     "pd_conv16_wgrad_workspace": (_sz, [_i]),
     "pd_conv16_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _l, _l, _l, _l, _i, _vp]),
     "pd_dgrad_s2_filters": (_i, [_vp, _vp, _i, _i, _vp]),
+    "pd_conv2d_rect": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _l, _vp]),
     "pd_interleave4": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_conv2d_add": (_i, [_vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _l, _vp]),
     "pd_conv2d_wgrad_workspace": (_sz, [_l, _i, _i]),

@@ -162,14 +162,14 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
             and Co % 32 == 0 and Ci % 4 == 0 and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0):
         # stride-2 data gradient by output parity: four stride-1 2x2 sub-filter launches + one interleave
         def _phases():
-            wsub = torch.empty((4, Ci, Co, 2, 2), dtype=torch.float32, device=dy.device).as_strided(
-                (4, Ci, Co, 2, 2), (Ci * 4 * Co, 4 * Co, 1, 2 * Co, Co))          # [4][Ci][2][2][Co] storage
+            wsub = torch.empty(9 * Ci * Co, dtype=torch.float32, device=dy.device)     # class filters 1x1, 1x2, 2x1, 2x2
             check(lib.pd_dgrad_s2_filters(ptr(wt), ptr(wsub), Ci, Co, stream_ptr()), "pd_dgrad_s2_filters")
             sub = torch.empty((4, N, Hy, Wy, Ci), dtype=torch.float32, device=dy.device)
-            for c in range(4):
-                check(lib.pd_conv2d(ptr(dy), ptr(wsub[c]), None, None, ptr(sub[c]), None, N, Hy, Wy, Co, sN, sH, sW, sC,
-                                    Hy, Wy, Ci, 2, 2, 1, 1, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci, stream_ptr()),
-                      "pd_conv2d(dgrad s2 phase)")
+            for c, off in enumerate((0, 1, 3, 5)):
+                ph, pw = c >> 1, c & 1
+                check(lib.pd_conv2d_rect(ptr(dy), wsub.data_ptr() + 4 * off * Ci * Co, ptr(sub[c]), N, Hy, Wy, Co, sN, sH, sW,
+                                         sC, Hy, Wy, Ci, 1 + ph, 1 + pw, ph, pw, MODE_TRANSPOSED, Ci, stream_ptr()),
+                      "pd_conv2d_rect(dgrad s2 phase)")
             check(lib.pd_interleave4(ptr(sub), ptr(dx), N, Hy, Wy, Ci, stream_ptr()), "pd_interleave4")
         _profiled("conv_dgrad_s2_phases", 2.0 * N * Hy * Wy * Co * Ci * KH * KW, _phases,
                   shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))

@@ -183,6 +183,36 @@ def test_data_gradient_with_addend_in_the_epilogue(case):
     _close(dx2.cpu(), expect)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 32, 40, 128), (1, 32, 6, 10, 64), (2, 64, 16, 20, 32), (3, 32, 4, 4, 32),
+                                  (1, 128, 34, 18, 64)])
+def test_stride2_data_gradient_by_output_parity(case):
+    """3x3 / stride 2 / pad 1 data gradient as four exact sub-filter launches (pd_dgrad_s2_filters + pd_conv2d_rect:
+    1x1, 1x2, 2x1, 2x2 taps with their own row / column padding) + pd_interleave4, against autograd on the CPU and
+    against the masked transposed gather of the same library."""
+    N, C, H, W, Co = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    ref = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    assert ops.USE_S2_PHASES
+    ops.PROFILE = []
+    dx = ops.conv2d_dgrad(dyd, wd, (H, W), stride=2, pad=1)
+    labels = [p[0] for p in ops.PROFILE]
+    ops.PROFILE = None
+    assert labels == ["conv_dgrad_s2_phases"], labels
+    _close(dx.cpu(), x.grad)
+    ops.USE_S2_PHASES = False
+    try:
+        dx2 = ops.conv2d_dgrad(dyd, wd, (H, W), stride=2, pad=1)
+    finally:
+        ops.USE_S2_PHASES = True
+    _close(dx2.cpu(), x.grad)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32, 40), (1, 32, 16, 20), (2, 16, 9, 35), (1, 32, 13, 7), (3, 16, 2, 2),
                                   (1, 16, 64, 96), (1, 32, 3, 70)])
 def test_sixteen_channel_tail_halo_kernel(case):
