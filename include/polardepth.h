@@ -277,10 +277,15 @@ int pd_loss_rows(long n);
 int pd_disp_to_depth(const void* disp, void* depth, void* updisp, int N, int hs, int ws, int H, int W,
                      float min_depth, float max_depth, void* stream);
 int pd_up_gather_bwd(const void* gup, void* gdisp, int N, int hs, int ws, int H, int W, int accumulate, void* stream);
-int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, void* partial, int N, int H, int W,
-                    float min_depth, float max_depth, int with_normals, void* stream);
-int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* wts, const void* sums,
-                    void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
+/* gt_normals (optional, NULL = recompute per call): [N,H,W,4] floats written by pd_gt_normals -- the unit normal of the
+ * ground-truth depth at every in-range pixel (trainer.py:1298-1309 evaluates it once per scale; it does not depend on
+ * the scale, so a step computes it once and its eight consumers read it back). */
+int pd_gt_normals(const void* gt, const void* K, void* gt_normals, int N, int H, int W, float min_depth, float max_depth,
+                  void* stream);
+int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, const void* gt_normals, void* partial, int N, int H,
+                    int W, float min_depth, float max_depth, int with_normals, void* stream);
+int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* gt_normals, const void* wts,
+                    const void* sums, void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
                     int with_normals, int to_disp, void* stream);
 int pd_smooth_fwd(const void* disp, const void* img, void* mean, void* partial, int N, int h, int w, void* stream);
 int pd_smooth_bwd(const void* disp, const void* img, const void* mean, const void* wts, void* g_ws, void* gd_acc,

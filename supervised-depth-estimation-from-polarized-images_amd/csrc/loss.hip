@@ -146,9 +146,34 @@ __device__ __forceinline__ V3 normalize12(V3 v, float& nv) {
     return V3{v.x * inv, v.y * inv, v.z * inv};
 }
 
+// gtn[p] = normalised (A x B) of the ground-truth depth at every masked pixel (xyz, w unused): the same value for all
+// scales and for the forward and backward kernels of a step, which otherwise each rebuild it from nine depths
+__global__ __launch_bounds__(LT) void gt_normals_kernel(const float* __restrict__ gt, const float* __restrict__ K,
+                                                        float4* __restrict__ gtn, int N, int H, int W, float min_d,
+                                                        float max_d) {
+    const long total = (long)N * H * W;
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const long n = t / H;
+        const float g = gt[i];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g >= min_d && g <= max_d) {
+            const Cam c = load_cam(K, n);
+            V3 A, B; float nv;
+            sobel_xyz(gt + n * H * W, H, W, x, y, c, A, B);
+            const V3 ng = normalize12(cross(A, B), nv);
+            o = make_float4(ng.x, ng.y, ng.z, 0.f);
+        }
+        gtn[i] = o;
+    }
+}
+
 // partial[block][3] = (sum |gt - d| m, sum (2 - cos) m, sum m)
 __global__ __launch_bounds__(LT) void sup_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                     const float* __restrict__ K, float* __restrict__ partial, int N,
+                                                     const float* __restrict__ K, const float4* __restrict__ gtn,
+                                                     float* __restrict__ partial, int N,
                                                      int H, int W, float min_d, float max_d, int with_normals) {
     __shared__ float sm[4 * 3];
     const long total = (long)N * H * W;
@@ -168,8 +193,9 @@ __global__ __launch_bounds__(LT) void sup_fwd_kernel(const float* __restrict__ p
             V3 A, B; float nv;
             sobel_xyz(pred + n * H * W, H, W, x, y, c, A, B);
             const V3 np_ = normalize12(cross(A, B), nv);
-            sobel_xyz(gt + n * H * W, H, W, x, y, c, A, B);
-            const V3 ng = normalize12(cross(A, B), nv);
+            V3 ng;
+            if (gtn) { const float4 q = gtn[i]; ng = V3{q.x, q.y, q.z}; }
+            else { sobel_xyz(gt + n * H * W, H, W, x, y, c, A, B); ng = normalize12(cross(A, B), nv); }
             const float n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f), n2 = fmaxf(sqrtf(dot(np_, np_)), 1e-8f);
             const float cs = (ng.x / n1) * (np_.x / n2) + (ng.y / n1) * (np_.y / n2) + (ng.z / n1) * (np_.z / n2);
             acc[1] += 2.f - cs;
@@ -182,7 +208,8 @@ __global__ __launch_bounds__(LT) void sup_fwd_kernel(const float* __restrict__ p
 // pass A: per pixel p, (dL/dA_p, dL/dB_p) of the normals term  -> ab [N,H,W,6]
 // wts = (w_L1, w_LN, w_sm) for this scale (device), sums = (.., .., sum mask) of the forward
 __global__ __launch_bounds__(LT) void sup_bwd_a_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                       const float* __restrict__ K, const float* __restrict__ wts,
+                                                       const float* __restrict__ K, const float4* __restrict__ gtn,
+                                                       const float* __restrict__ wts,
                                                        const double* __restrict__ sums, float* __restrict__ ab, int N,
                                                        int H, int W, float min_d, float max_d) {
     const long total = (long)N * H * W;
@@ -200,8 +227,9 @@ __global__ __launch_bounds__(LT) void sup_bwd_a_kernel(const float* __restrict__
             sobel_xyz(pred + n * H * W, H, W, x, y, c, A, B);
             const V3 v = cross(A, B);
             const V3 nn = normalize12(v, nv);
-            sobel_xyz(gt + n * H * W, H, W, x, y, c, Ag, Bg);
-            const V3 ng = normalize12(cross(Ag, Bg), nvg);
+            V3 ng;
+            if (gtn) { const float4 q = gtn[i]; ng = V3{q.x, q.y, q.z}; }
+            else { sobel_xyz(gt + n * H * W, H, W, x, y, c, Ag, Bg); ng = normalize12(cross(Ag, Bg), nvg); }
             const float n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f);
             const V3 gh{ng.x / n1, ng.y / n1, ng.z / n1};
             // cos = gh . (nn / max(|nn|, eps));  loss = -wln * cos (+ const)
@@ -481,26 +509,36 @@ extern "C" int pd_up_gather_bwd(const void* gup, void* gdisp, int N, int hs, int
     return pd::check_launch("pd_up_gather_bwd");
 }
 
-extern "C" int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, void* partial, int N, int H, int W,
-                               float min_depth, float max_depth, int with_normals, void* stream) {
-    PD_REQUIRE(pred && gt && partial && (K || !with_normals) && N > 0 && H > 0 && W > 0, "pd_sup_loss_fwd: bad arguments");
+extern "C" int pd_gt_normals(const void* gt, const void* K, void* gtn, int N, int H, int W, float min_depth,
+                             float max_depth, void* stream) {
+    PD_REQUIRE(gt && K && gtn && N > 0 && H > 0 && W > 0 && pd::aligned16(gtn), "pd_gt_normals: bad arguments");
+    hipLaunchKernelGGL(gt_normals_kernel, dim3(lgrid((long)N * H * W)), dim3(LT), 0, (hipStream_t)stream, (const float*)gt,
+                       (const float*)K, (float4*)gtn, N, H, W, min_depth, max_depth);
+    return pd::check_launch("pd_gt_normals");
+}
+
+extern "C" int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, const void* gt_normals, void* partial, int N,
+                               int H, int W, float min_depth, float max_depth, int with_normals, void* stream) {
+    PD_REQUIRE(pred && gt && partial && (K || !with_normals) && N > 0 && H > 0 && W > 0 && pd::aligned16(gt_normals),
+               "pd_sup_loss_fwd: bad arguments");
     hipLaunchKernelGGL(sup_fwd_kernel, dim3(lgrid((long)N * H * W)), dim3(LT), 0, (hipStream_t)stream,
-                       (const float*)pred, (const float*)gt, (const float*)K, (float*)partial, N, H, W, min_depth,
-                       max_depth, with_normals);
+                       (const float*)pred, (const float*)gt, (const float*)K, (const float4*)gt_normals, (float*)partial, N,
+                       H, W, min_depth, max_depth, with_normals);
     return pd::check_launch("pd_sup_loss_fwd");
 }
 
-extern "C" int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* wts, const void* sums,
-                               void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
+extern "C" int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* gt_normals, const void* wts,
+                               const void* sums, void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
                                int with_normals, int to_disp, void* stream) {
-    PD_REQUIRE(pred && gt && wts && sums && gout && N > 0 && H > 0 && W > 0, "pd_sup_loss_bwd: bad arguments");
+    PD_REQUIRE(pred && gt && wts && sums && gout && N > 0 && H > 0 && W > 0 && pd::aligned16(gt_normals),
+               "pd_sup_loss_bwd: bad arguments");
     PD_REQUIRE(!with_normals || (K && ab_ws), "pd_sup_loss_bwd: normals term needs K and the [N,H,W,6] workspace");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = lgrid((long)N * H * W);
     if (with_normals)
         hipLaunchKernelGGL(sup_bwd_a_kernel, dim3(grid), dim3(LT), 0, st, (const float*)pred, (const float*)gt,
-                           (const float*)K, (const float*)wts, (const double*)sums, (float*)ab_ws, N, H, W, min_depth,
-                           max_depth);
+                           (const float*)K, (const float4*)gt_normals, (const float*)wts, (const double*)sums, (float*)ab_ws,
+                           N, H, W, min_depth, max_depth);
     hipLaunchKernelGGL(sup_bwd_b_kernel, dim3(grid), dim3(LT), 0, st, (const float*)pred, (const float*)gt,
                        (const float*)K, (const float*)wts, (const double*)sums, (const float*)ab_ws, (float*)gout, N, H,
                        W, min_depth, max_depth, 1.f / min_depth - 1.f / max_depth, with_normals, to_disp);

@@ -354,7 +354,7 @@ class Trainer:
         rows = lib.pd_loss_rows(N * H * W)
         part = torch.empty((rows, 3), dtype=torch.float32, device=depth_gt.device)
         check(lib.pd_sup_loss_fwd(ptr(depth_pred.contiguous().float()), ptr(depth_gt.contiguous().float()),
-                                  ptr(K.contiguous()), ptr(part), N, H, W, self.opt.min_depth, self.opt.max_depth, 1,
+                                  ptr(K.contiguous()), None, ptr(part), N, H, W, self.opt.min_depth, self.opt.max_depth, 1,
                                   stream_ptr()), "pd_sup_loss_fwd")
         s = part.double().sum(0)
         return (s[1] / s[2]).float()

@@ -176,6 +176,7 @@ class ActGrad:
 
 
 USE_ACT_FUSION = os.environ.get("PD_ACT_FUSION", "1") != "0"
+USE_GT_NORMAL_CACHE = os.environ.get("PD_GT_NORMAL_CACHE", "1") != "0"
 USE_SKIP_FUSION = os.environ.get("PD_SKIP_FUSION", "1") != "0"
 USE_DISPHEAD_FUSED = os.environ.get("PD_DISPHEAD_FUSED", "1") != "0"   # disparity heads: data + weight gradient in one pass
 USE_REFLECT_BORDER = os.environ.get("PD_REFLECT_BORDER", "1") != "0"   # reflect-conv dX = pad-1 dgrad + border strips (no fold pass)
@@ -760,13 +761,18 @@ class MultiScaleLossFn(torch.autograd.Function):
         sup_rows, sm_rows, dims = [], [], []
         depths, means = [], []
         with_n = 1
+        # unit normals of the ground truth: once per step instead of once per scale and direction
+        gtn = None
+        if USE_GT_NORMAL_CACHE and S > 1:
+            gtn = _f32(dev, N, H, W, 4)
+            check(lib.pd_gt_normals(ptr(gt), ptr(K), ptr(gtn), N, H, W, cfg.min_depth, cfg.max_depth, st), "pd_gt_normals")
         for i, s in enumerate(cfg.scales):
             d = disps[i]
             hs, ws = d.shape[2], d.shape[3]
             depth = _f32(dev, N, 1, H, W)
             check(lib.pd_disp_to_depth(ptr(d), ptr(depth), None, N, hs, ws, H, W, cfg.min_depth, cfg.max_depth, st),
                   "pd_disp_to_depth")
-            check(lib.pd_sup_loss_fwd(ptr(depth), ptr(gt), ptr(K), ptr(sup_part[i]), N, H, W, cfg.min_depth,
+            check(lib.pd_sup_loss_fwd(ptr(depth), ptr(gt), ptr(K), ptr(gtn), ptr(sup_part[i]), N, H, W, cfg.min_depth,
                                       cfg.max_depth, with_n, st), "pd_sup_loss_fwd")
             mean = _f32(dev, N)
             check(lib.pd_smooth_fwd(ptr(d), ptr(colors[i]), ptr(mean), ptr(sm_part[i]), N, hs, ws, st), "pd_smooth_fwd")
@@ -783,6 +789,7 @@ class MultiScaleLossFn(torch.autograd.Function):
             check(lib.pd_loss_from_sums(ptr(sums_val), _iarr(dims), _iarr(cfg.scales), S, cfg.w_normals, cfg.w_smooth,
                                         ptr(vals), st), "pd_loss_from_sums")
         ctx.cfg, ctx.S = cfg, S
+        ctx.gtn = gtn
         ctx.save_for_backward(gt, K, sums, *disps, *colors, *depths, *means)
         ctx.mark_non_differentiable(*depths)
         return (vals, *depths)
@@ -807,7 +814,7 @@ class MultiScaleLossFn(torch.autograd.Function):
         for i in range(S):
             d = disps[i]
             hs, ws = d.shape[2], d.shape[3]
-            check(lib.pd_sup_loss_bwd(ptr(depths[i]), ptr(gt), ptr(K), ptr(wts[3 * i:]), ptr(sums[5 * i:]), ptr(ab),
+            check(lib.pd_sup_loss_bwd(ptr(depths[i]), ptr(gt), ptr(K), ptr(ctx.gtn), ptr(wts[3 * i:]), ptr(sums[5 * i:]), ptr(ab),
                                       ptr(gup), N, H, W, cfg.min_depth, cfg.max_depth, 1, 1, st), "pd_sup_loss_bwd")
             gd = torch.empty_like(d)
             check(lib.pd_up_gather_bwd(ptr(gup), ptr(gd), N, hs, ws, H, W, 0, st), "pd_up_gather_bwd")
