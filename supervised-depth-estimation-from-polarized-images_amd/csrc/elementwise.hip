@@ -571,24 +571,25 @@ __global__ __launch_bounds__(EW_T) void up_bwd_kernel(const float* __restrict__ 
         const int w = (int)(pix % W); pix /= W;
         const int h = (int)(pix % H);
         const long n = pix / H;
+        // a[h] feeds output rows 2h-1 .. 2h+2 with weights 1/4, 3/4, 3/4, 1/4; at the image border the clamped source row
+        // takes the whole weight (rows 0 and 2H-1) and the outer neighbour does not exist.  Same weights, products and
+        // summation order as the generic source-index form.
+        float wy[4], wx[4];
+        wy[0] = h > 0 ? 0.25f : 0.f; wy[1] = h > 0 ? 0.75f : 1.f; wy[2] = h < H - 1 ? 0.75f : 1.f; wy[3] = h < H - 1 ? 0.25f : 0.f;
+        wx[0] = w > 0 ? 0.25f : 0.f; wx[1] = w > 0 ? 0.75f : 1.f; wx[2] = w < W - 1 ? 0.75f : 1.f; wx[3] = w < W - 1 ? 0.25f : 0.f;
         float4 acc = f4(0.f);
-        for (int y = 2 * h - 2; y <= 2 * h + 2; ++y) {
-            if (y < 0 || y >= Ho) continue;
-            const float sy = fmaxf(0.5f * (y + 0.5f) - 0.5f, 0.f);
-            const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
-            const float ly1 = sy - y0;
-            const float wy = (y0 == h ? 1.f - ly1 : 0.f) + (y1 == h ? ly1 : 0.f);
-            if (wy == 0.f) continue;
-            for (int x = 2 * w - 2; x <= 2 * w + 2; ++x) {
-                if (x < 0 || x >= Wo) continue;
-                const float sx = fmaxf(0.5f * (x + 0.5f) - 0.5f, 0.f);
-                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
-                const float lx1 = sx - x0;
-                const float wx = (x0 == w ? 1.f - lx1 : 0.f) + (x1 == w ? lx1 : 0.f);
-                if (wx == 0.f) continue;
-                const float4 g = ld4(dout + ((n * Ho + y) * (long)Wo + x) * ld_d + c4);
-                const float ww = wy * wx;
-                acc.x += ww * g.x; acc.y += ww * g.y; acc.z += ww * g.z; acc.w += ww * g.w;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int y = min(max(2 * h - 1 + a, 0), Ho - 1);          // weight 0 where clamped
+            const float* row = dout + ((n * Ho + y) * (long)Wo) * ld_d + c4;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int x = min(max(2 * w - 1 + b, 0), Wo - 1);
+                const float ww = wy[a] * wx[b];
+                if (ww != 0.f) {
+                    const float4 g = ld4(row + (long)x * ld_d);
+                    acc.x += ww * g.x; acc.y += ww * g.y; acc.z += ww * g.z; acc.w += ww * g.w;
+                }
             }
         }
         if (elu_y) {
