@@ -1748,6 +1748,39 @@ __global__ __launch_bounds__(256) void s2d_weight_kernel(const float* __restrict
     }
 }
 
+// Row-contiguous planes (sW == 1): a workgroup reads the two source rows of 64 output pixels plane by plane (coalesced),
+// regroups them in LDS and writes 64 x 4C contiguous floats.  (One thread per output element read 4-byte words a plane
+// apart: 0.25 ms per step for 0.6 GB.)
+constexpr int S2D_TW = 64;
+__global__ __launch_bounds__(256) void s2d_input_tile_kernel(const float* __restrict__ x, float* __restrict__ out, int N,
+                                                             int C, int H, int W, long sN, long sC, long sH, int affine,
+                                                             float sub, float div, int tiles_w) {
+    extern __shared__ float s2d_lds[];                     // [S2D_TW][4C + 1]
+    const int H2 = H >> 1, W2 = W >> 1, C4 = 4 * C, LDP = C4 + 1;
+    const int tw = blockIdx.x % tiles_w;
+    long r = blockIdx.x / tiles_w;
+    const int ii = (int)(r % H2);
+    const long n = r / H2;
+    const int j0 = tw * S2D_TW, nj = min(S2D_TW, W2 - j0);
+    const float* xb = x + n * sN + (long)(2 * ii) * sH + 2 * j0;
+    for (int e = threadIdx.x; e < 2 * C * 2 * S2D_TW; e += 256) {
+        const int col = e & (2 * S2D_TW - 1), cd = e >> 7;          // 128 source columns per (c, dy)
+        const int dy = cd & 1, c = cd >> 1;
+        const int j = col >> 1, dx = col & 1;
+        if (j < nj) {
+            float v = xb[c * sC + dy * sH + col];
+            if (affine) v = (v - sub) / div;
+            s2d_lds[j * LDP + (dy * 2 + dx) * C + c] = v;
+        }
+    }
+    __syncthreads();
+    float* ob = out + ((n * H2 + ii) * (long)W2 + j0) * C4;
+    for (int t = threadIdx.x; t < nj * C4; t += 256) {
+        const int j = t / C4, q = t - j * C4;
+        ob[t] = s2d_lds[j * LDP + q];
+    }
+}
+
 }  // namespace
 
 extern "C" int pd_stem_s2d_input(const void* x, void* out, int N, int C, int H, int W, long sN, long sC, long sH,
@@ -1755,6 +1788,14 @@ extern "C" int pd_stem_s2d_input(const void* x, void* out, int N, int C, int H, 
     PD_REQUIRE(x && out && N >= 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "pd_stem_s2d_input: bad arguments");
     if (N == 0) return PD_OK;
     const long total = (long)N * H * W * C;
+    const int tiles_w = (W / 2 + S2D_TW - 1) / S2D_TW;
+    const long blocks = (long)N * (H / 2) * tiles_w;
+    const size_t lds = (size_t)S2D_TW * (4 * C + 1) * sizeof(float);
+    if (sW == 1 && lds <= 48 * 1024 && blocks < (1L << 31)) {
+        hipLaunchKernelGGL(s2d_input_tile_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, (const float*)x,
+                           (float*)out, N, C, H, W, sN, sC, sH, affine, sub, div, tiles_w);
+        return pd::check_launch("pd_stem_s2d_input");
+    }
     hipLaunchKernelGGL(s2d_input_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256),
                        0, (hipStream_t)stream, (const float*)x, (float*)out, N, C, H, W, sN, sC, sH, sW, affine, sub, div);
     return pd::check_launch("pd_stem_s2d_input");

@@ -315,6 +315,23 @@ def test_stem_as_space_to_depth_conv(C):
     _close(dw.cpu(), wr.grad)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 8, 140), (1, 9, 4, 128), (3, 2, 6, 20), (1, 3, 2, 260)])
+def test_space_to_depth_input_layouts(case):
+    """pd_stem_s2d_input: the LDS-tiled kernel (row-contiguous planes; full and partial 64-pixel tiles) and the
+    element-wise kernel (any strides) against the permutation written in PyTorch -- bit-exact, with and without the
+    input normalisation."""
+    N, C, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.rand(N, C, H, W, generator=g)
+
+    def expect(t):
+        return t.reshape(N, C, H // 2, 2, W // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(N, 4 * C, H // 2, W // 2)
+
+    for xd in (x.cuda(), x.cuda().contiguous(memory_format=torch.channels_last)):       # tile kernel / strided kernel
+        assert torch.equal(ops.s2d_input(xd).cpu(), expect(x))
+        assert torch.equal(ops.s2d_input(xd, (0.45, 0.225)).cpu(), expect((x - 0.45) / 0.225))
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("case", [(2, 16, 7, 9), (1, 32, 2, 2), (3, 64, 3, 5), (1, 128, 6, 4), (2, 16, 33, 21), (2, 16, 19, 131),
                                   (1, 32, 64, 80)])
