@@ -12,6 +12,7 @@
 // All sums are reduced per wavefront (shuffles), then per workgroup, written as fp32 partials and
 // finished in fp64 by a one-block kernel -- no float atomics, run-to-run deterministic.
 #include "pd_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -104,6 +105,46 @@ __global__ __launch_bounds__(LT) void up_gather_bwd_kernel(const float* __restri
                 const float wx = (x0 == xs ? 1.f - lx1 : 0.f) + (x1 == xs ? lx1 : 0.f);
                 if (wx != 0.f) acc += wy * wx * g[x];
             }
+        }
+        gdisp[i] = accumulate ? gdisp[i] + acc : acc;
+    }
+}
+
+// Same sum for an isotropic zoom F in {1, 2, 4, 8}: the 3F column weights of a thread do not depend on the row, so they are
+// evaluated once (same expressions, hence the same bits) and the 3F x 3F footprint is unrolled; the generic kernel
+// re-derived both source indices for every element of the footprint (~25 instructions per element).
+template <int F>
+__global__ __launch_bounds__(LT) void up_gather_bwd_f_kernel(const float* __restrict__ gup, float* __restrict__ gdisp,
+                                                             int N, int hs, int ws, int H, int W, int accumulate) {
+    const long total = (long)N * hs * ws;
+    const float sh = (float)hs / H, sw = (float)ws / W;
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const int xs = (int)(i % ws);
+        const long t = i / ws;
+        const int ys = (int)(t % hs);
+        const long n = t / hs;
+        float wx[3 * F];
+#pragma unroll
+        for (int b = 0; b < 3 * F; ++b) {
+            const int x = (xs - 1) * F + b;
+            int x0, x1; float lx1;
+            src_index(x, sw, ws, x0, x1, lx1);
+            const float w = (x0 == xs ? 1.f - lx1 : 0.f) + (x1 == xs ? lx1 : 0.f);
+            wx[b] = (x >= 0 && x < W) ? w : 0.f;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3 * F; ++a) {
+            const int y = (ys - 1) * F + a;
+            if (y < 0 || y >= H) continue;
+            int y0, y1; float ly1;
+            src_index(y, sh, hs, y0, y1, ly1);
+            const float wy = (y0 == ys ? 1.f - ly1 : 0.f) + (y1 == ys ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            const float* g = gup + (n * H + y) * (long)W + (long)(xs - 1) * F;
+#pragma unroll
+            for (int b = 0; b < 3 * F; ++b)
+                if (wx[b] != 0.f) acc += wy * wx[b] * g[b];
         }
         gdisp[i] = accumulate ? gdisp[i] + acc : acc;
     }
@@ -513,8 +554,19 @@ extern "C" int pd_up_gather_bwd(const void* gup, void* gdisp, int N, int hs, int
     PD_REQUIRE(gup && gdisp && N >= 0 && hs > 0 && ws > 0, "pd_up_gather_bwd: bad arguments");
     PD_REQUIRE(H % hs == 0 && W % ws == 0, "pd_up_gather_bwd: full size must be an integer multiple of the scale size");
     if (N == 0) return PD_OK;
-    hipLaunchKernelGGL(up_gather_bwd_kernel, dim3(lgrid((long)N * hs * ws)), dim3(LT), 0, (hipStream_t)stream,
-                       (const float*)gup, (float*)gdisp, N, hs, ws, H, W, accumulate);
+    const char* gen = getenv("PD_UP_GATHER_GENERIC");                 // A/B and test switch: the generic kernel
+    const int f = (gen && gen[0] == '1') ? 0 : H / hs;
+    const unsigned grid = lgrid((long)N * hs * ws);
+#define PD_UPG(F) hipLaunchKernelGGL(up_gather_bwd_f_kernel<F>, dim3(grid), dim3(LT), 0, (hipStream_t)stream, \
+                                     (const float*)gup, (float*)gdisp, N, hs, ws, H, W, accumulate)
+    if (W / ws == f && f == 1) PD_UPG(1);
+    else if (W / ws == f && f == 2) PD_UPG(2);
+    else if (W / ws == f && f == 4) PD_UPG(4);
+    else if (W / ws == f && f == 8) PD_UPG(8);
+    else
+        hipLaunchKernelGGL(up_gather_bwd_kernel, dim3(grid), dim3(LT), 0, (hipStream_t)stream, (const float*)gup,
+                           (float*)gdisp, N, hs, ws, H, W, accumulate);
+#undef PD_UPG
     return pd::check_launch("pd_up_gather_bwd");
 }
 

@@ -55,6 +55,29 @@ def test_ground_truth_normal_cache_is_bit_exact(monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("f", [1, 2, 4, 8])
+def test_upsample_gradient_gather_specialisations_are_bit_exact(f, monkeypatch):
+    """pd_up_gather_bwd: the unrolled power-of-two-zoom kernels against the generic footprint kernel (same bits), and
+    both against autograd through F.interpolate on the CPU."""
+    import torch.nn.functional as F
+    from polardepth._lib import lib, check, ptr
+    N, hs, ws = 2, 6, 10
+    H, W = hs * f, ws * f
+    g = torch.Generator().manual_seed(f)
+    gup = torch.randn(N, 1, H, W, generator=g)
+    d = torch.zeros(N, 1, hs, ws, requires_grad=True)
+    F.interpolate(d, size=(H, W), mode="bilinear", align_corners=False).backward(gup)
+    out = []
+    for generic in ("0", "1"):
+        monkeypatch.setenv("PD_UP_GATHER_GENERIC", generic)
+        gd = torch.empty(N, 1, hs, ws, device="cuda")
+        check(lib.pd_up_gather_bwd(ptr(gup.cuda()), ptr(gd), N, hs, ws, H, W, 0, None), "pd_up_gather_bwd")
+        torch.cuda.synchronize()
+        out.append(gd.cpu())
+    assert torch.equal(out[0], out[1])
+    _close(out[0], d.grad, 1e-6, "up gather")
+
+
 def test_loss_vs_oracle_other_geometry_and_partial_scales():
     from oracle import losses as ol
     g = torch.Generator().manual_seed(21)
