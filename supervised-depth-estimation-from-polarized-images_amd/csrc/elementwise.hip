@@ -436,6 +436,15 @@ __global__ __launch_bounds__(EW_T) void chain_bwd_kernel(const ChainArgs a) {
     }
 }
 
+// i -> (i / d, i % d) for a positive divisor: 32-bit unsigned arithmetic whenever the index fits (every grid-stride index
+// of the training step does); a 64-bit division is ~5x the instructions, and the pixel decode below needs three
+__device__ __forceinline__ long divmod(long i, int d, int& rem) {
+    if (i >> 32) { const long q = i / d; rem = (int)(i - q * d); return q; }
+    const unsigned u = (unsigned)i, q = u / (unsigned)d;
+    rem = (int)(u - q * (unsigned)d);
+    return (long)q;
+}
+
 // grad of the residual input of a post-add ReLU block: dres = dy * (out > 0)
 __global__ __launch_bounds__(EW_T) void relu_mask_kernel(const float* __restrict__ dy, long ld_dy,
                                                          const float* __restrict__ out, long ld_out,
@@ -443,8 +452,8 @@ __global__ __launch_bounds__(EW_T) void relu_mask_kernel(const float* __restrict
     const int cq = C >> 2;
     const long total = npix * cq;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int c4 = (int)(i % cq) * 4;
-        const long pix = i / cq;
+        int c4;
+        const long pix = divmod(i, cq, c4); c4 *= 4;
         const float4 g = ld4(dy + pix * ld_dy + c4), o = ld4(out + pix * ld_out + c4);
         st4(d + pix * C + c4, make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f,
                                           o.w > 0.f ? g.w : 0.f));
@@ -460,11 +469,10 @@ __global__ __launch_bounds__(EW_T) void maxpool3_fwd_kernel(const float* __restr
     const int cq = C >> 2;
     const long total = (long)N * Ho * Wo * cq;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int c4 = (int)(i % cq) * 4;
-        long pix = i / cq;
-        const int wo = (int)(pix % Wo); pix /= Wo;
-        const int ho = (int)(pix % Ho);
-        const long n = pix / Ho;
+        int c4, wo, ho;
+        long pix = divmod(i, cq, c4); c4 *= 4;
+        pix = divmod(pix, Wo, wo);
+        const long n = divmod(pix, Ho, ho);
         float4 m = f4(-INFINITY);
         uint32_t ix = 0, iy = 0, iz = 0, iw = 0;
 #pragma unroll
@@ -497,11 +505,10 @@ __global__ __launch_bounds__(EW_T) void maxpool3_bwd_kernel(const uint32_t* __re
     const int cq = C >> 2;
     const long total = (long)N * H * W * cq;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int cqi = (int)(i % cq);
-        long pix = i / cq;
-        const int w = (int)(pix % W); pix /= W;
-        const int h = (int)(pix % H);
-        const long n = pix / H;
+        int cqi, w, h;
+        long pix = divmod(i, cq, cqi);
+        pix = divmod(pix, W, w);
+        const long n = divmod(pix, H, h);
         float4 acc = f4(0.f);
         for (int ho = h >> 1; ho <= (h + 1) >> 1; ++ho) {
             if (ho >= Ho) continue;
@@ -531,12 +538,11 @@ __global__ __launch_bounds__(EW_T) void upcat_fwd_kernel(const float* __restrict
     const int Ho = 2 * H, Wo = 2 * W;
     const long total = (long)N * Ho * Wo * cq;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int c4 = (int)(i % cq) * 4;
-        long pix = i / cq;
+        int c4, x, y;
+        long pix = divmod(i, cq, c4); c4 *= 4;
         const long opix = pix;
-        const int x = (int)(pix % Wo); pix /= Wo;
-        const int y = (int)(pix % Ho);
-        const long n = pix / Ho;
+        pix = divmod(pix, Wo, x);
+        const long n = divmod(pix, Ho, y);
         float4 v;
         if (c4 < Ca) {
             // torch: src = max(0, 0.5*(dst+0.5)-0.5); i0 = floor(src); i1 = min(i0+1, size-1); l1 = src-i0
@@ -566,11 +572,10 @@ __global__ __launch_bounds__(EW_T) void up_bwd_kernel(const float* __restrict__ 
     const int Ho = 2 * H, Wo = 2 * W;
     const long total = (long)N * H * W * cq;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int c4 = (int)(i % cq) * 4;
-        long pix = i / cq;
-        const int w = (int)(pix % W); pix /= W;
-        const int h = (int)(pix % H);
-        const long n = pix / H;
+        int c4, w, h;
+        long pix = divmod(i, cq, c4); c4 *= 4;
+        pix = divmod(pix, W, w);
+        const long n = divmod(pix, H, h);
         // a[h] feeds output rows 2h-1 .. 2h+2 with weights 1/4, 3/4, 3/4, 1/4; at the image border the clamped source row
         // takes the whole weight (rows 0 and 2H-1) and the outer neighbour does not exist.  Same weights, products and
         // summation order as the generic source-index form.
@@ -624,11 +629,10 @@ __global__ __launch_bounds__(EW_T) void reflect_fold_kernel(const float* __restr
     const long total = (long)N * H * W * cq;
     const int Hp = H + 2, Wp = W + 2;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
-        const int c = (int)(i % cq) * V;
-        long pix = i / cq;
-        const int w = (int)(pix % W); pix /= W;
-        const int h = (int)(pix % H);
-        const long n = pix / H;
+        int c, w, h;
+        long pix = divmod(i, cq, c); c *= V;
+        pix = divmod(pix, W, w);
+        const long n = divmod(pix, H, h);
         // padded rows that map to h: h+1 always; 0 if h == 1; Hp-1 if h == H-2
         int hs[3], ws[3], nh = 0, nw = 0;
         hs[nh++] = h + 1; if (h == 1) hs[nh++] = 0; if (h == H - 2) hs[nh++] = Hp - 1;

@@ -46,6 +46,15 @@ inline unsigned lgrid(long n) {
     return (unsigned)b;
 }
 
+// i -> (i / d, i % d) for a positive divisor: 32-bit unsigned arithmetic whenever the index fits; a 64-bit division is ~5x
+// the instructions and every per-pixel kernel below decodes (n, y, x) with two of them
+__device__ __forceinline__ long divmod(long i, int d, int& rem) {
+    if (i >> 32) { const long q = i / d; rem = (int)(i - q * d); return q; }
+    const unsigned u = (unsigned)i, q = u / (unsigned)d;
+    rem = (int)(u - q * (unsigned)d);
+    return (long)q;
+}
+
 // torch upsample_bilinear2d source index (align_corners=False)
 __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
     const float s = fmaxf(scale * (dst + 0.5f) - 0.5f, 0.f);
@@ -62,10 +71,9 @@ __global__ __launch_bounds__(LT) void disp_to_depth_kernel(const float* __restri
     const long total = (long)N * H * W;
     const float sh = (float)hs / H, sw = (float)ws / W;
     for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
-        const int x = (int)(i % W);
-        const long t = i / W;
-        const int y = (int)(t % H);
-        const long n = t / H;
+        int x, y;
+        const long t = divmod(i, W, x);
+        const long n = divmod(t, H, y);
         int y0, y1, x0, x1; float ly1, lx1;
         src_index(y, sh, hs, y0, y1, ly1);
         src_index(x, sw, ws, x0, x1, lx1);
@@ -86,10 +94,9 @@ __global__ __launch_bounds__(LT) void up_gather_bwd_kernel(const float* __restri
     const float sh = (float)hs / H, sw = (float)ws / W;
     const int fh = H / hs, fw = W / ws;   // integer zoom factors (checked on the host)
     for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
-        const int xs = (int)(i % ws);
-        const long t = i / ws;
-        const int ys = (int)(t % hs);
-        const long n = t / hs;
+        int xs, ys;
+        const long t = divmod(i, ws, xs);
+        const long n = divmod(t, hs, ys);
         float acc = 0.f;
         const int ylo = max(0, (ys - 1) * fh), yhi = min(H - 1, (ys + 2) * fh - 1);
         const int xlo = max(0, (xs - 1) * fw), xhi = min(W - 1, (xs + 2) * fw - 1);
@@ -119,10 +126,9 @@ __global__ __launch_bounds__(LT) void up_gather_bwd_f_kernel(const float* __rest
     const long total = (long)N * hs * ws;
     const float sh = (float)hs / H, sw = (float)ws / W;
     for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
-        const int xs = (int)(i % ws);
-        const long t = i / ws;
-        const int ys = (int)(t % hs);
-        const long n = t / hs;
+        int xs, ys;
+        const long t = divmod(i, ws, xs);
+        const long n = divmod(t, hs, ys);
         float wx[3 * F];
 #pragma unroll
         for (int b = 0; b < 3 * F; ++b) {
@@ -194,10 +200,9 @@ __global__ __launch_bounds__(LT) void gt_normals_kernel(const float* __restrict_
                                                         float max_d) {
     const long total = (long)N * H * W;
     for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
-        const int x = (int)(i % W);
-        const long t = i / W;
-        const int y = (int)(t % H);
-        const long n = t / H;
+        int x, y;
+        const long t = divmod(i, W, x);
+        const long n = divmod(t, H, y);
         const float g = gt[i];
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g >= min_d && g <= max_d) {
@@ -220,10 +225,9 @@ __global__ __launch_bounds__(LT) void sup_fwd_kernel(const float* __restrict__ p
     const long total = (long)N * H * W;
     float acc[3] = {0.f, 0.f, 0.f};
     for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
-        const int x = (int)(i % W);
-        const long t = i / W;
-        const int y = (int)(t % H);
-        const long n = t / H;
+        int x, y;
+        const long t = divmod(i, W, x);
+        const long n = divmod(t, H, y);
         const float g = gt[i];
         const float m = (g >= min_d && g <= max_d) ? 1.f : 0.f;
         if (m == 0.f) continue;   // every term is multiplied by the mask
@@ -256,10 +260,9 @@ __global__ __launch_bounds__(LT) void sup_bwd_a_kernel(const float* __restrict__
     const long total = (long)N * H * W;
     const float wln = (float)((double)wts[1] / sums[2]);
     for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
-        const int x = (int)(i % W);
-        const long t = i / W;
-        const int y = (int)(t % H);
-        const long n = t / H;
+        int x, y;
+        const long t = divmod(i, W, x);
+        const long n = divmod(t, H, y);
         const float g = gt[i];
         V3 dA{0, 0, 0}, dB{0, 0, 0};
         if (g >= min_d && g <= max_d) {
@@ -316,10 +319,9 @@ __global__ __launch_bounds__(LT) void sup_bwd_b_kernel(const float* __restrict__
     const long total = (long)N * H * W;
     const float wl1 = (float)((double)wts[0] / sums[2]);
     for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
-        const int x = (int)(i % W);
-        const long t = i / W;
-        const int y = (int)(t % H);
-        const long n = t / H;
+        int x, y;
+        const long t = divmod(i, W, x);
+        const long n = divmod(t, H, y);
         const float g = gt[i], d = pred[i];
         float gd = 0.f;
         if (g >= min_d && g <= max_d) gd = wl1 * (d > g ? 1.f : (d < g ? -1.f : 0.f));
@@ -383,10 +385,9 @@ __global__ __launch_bounds__(LT) void smooth_fwd_kernel(const float* __restrict_
     const long P = (long)h * w, total = N * P;
     float acc[2] = {0.f, 0.f};
     for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
-        const int x = (int)(i % w);
-        const long t = i / w;
-        const int y = (int)(t % h);
-        const long n = t / h;
+        int x, y;
+        const long t = divmod(i, w, x);
+        const long n = divmod(t, h, y);
         const float inv = 1.f / (mean[n] + 1e-7f);
         const float v = disp[i] * inv;
         const long ib = n * 3 * P, p = (long)y * w + x;
@@ -410,10 +411,9 @@ __global__ __launch_bounds__(LT) void smooth_bwd_g_kernel(const float* __restric
         const long i = i0 + threadIdx.x;
         float gsum = 0.f; long n = 0; float gi = 0.f;
         if (i < total) {
-            const int x = (int)(i % w);
-            const long t = i / w;
-            const int y = (int)(t % h);
-            n = t / h;
+            int x, y;
+            const long t = divmod(i, w, x);
+            n = divmod(t, h, y);
             const float inv = 1.f / (mean[n] + 1e-7f);
             const float v = disp[i] * inv;
             const long ib = n * 3 * P, p = (long)y * w + x;
@@ -685,10 +685,9 @@ __global__ __launch_bounds__(LT) void ssim_kernel(const float* __restrict__ x, c
                                                   int no_ssim) {
     const long P = (long)H * W, total = N * P;
     for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
-        const int px = (int)(i % W);
-        const long t = i / W;
-        const int py = (int)(t % H);
-        const long n = t / H;
+        int px, py;
+        const long t = divmod(i, W, px);
+        const long n = divmod(t, H, py);
         float s_ssim = 0.f, s_l1 = 0.f;
         for (int c = 0; c < C; ++c) {
             const float* xp = x + (n * C + c) * P;
