@@ -289,7 +289,7 @@ __global__ __launch_bounds__(EW_T) void chain_fwd_kernel(const ChainArgs a) {
 // gradient w.r.t. the BN output z at input pixel (n,h,w), channels c4..c4+3; also returns xhat.
 // Recomputes the forward masks from x (and `out` for the post-add ReLU).
 __device__ __forceinline__ float4 chain_grad(const ChainArgs& a, unsigned n, unsigned h, unsigned w, int c4, float4 xv,
-                                             float4 s, float4 b) {
+                                             float4 s, float4 b, float4* g_post = nullptr) {
     const unsigned Ho = a.pool ? a.H >> 1 : a.H, Wo = a.pool ? a.W >> 1 : a.W;
     const unsigned ho = a.pool ? h >> 1 : h, wo = a.pool ? w >> 1 : w;
     if (a.pool && (ho >= Ho || wo >= Wo)) return f4(0.f);   // odd trailing row/col is dropped by the pool
@@ -299,6 +299,7 @@ __device__ __forceinline__ float4 chain_grad(const ChainArgs& a, unsigned n, uns
         const float4 o = ld4(a.out + (size_t)opix * a.ld_out + c4);
         g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
     }
+    if (g_post) *g_post = g;            // gradient behind the post-add ReLU = gradient of the residual input
     if (a.drop_p > 0.f) g = mul4(g, dropout_scale(opix * (a.C >> 2) + (c4 >> 2), a.seed, a.offset, a.drop_p));
     float4 z = affine4(xv, s, b);
     if (a.pool) {
@@ -401,7 +402,9 @@ __global__ __launch_bounds__(EW_T) void chain_bwd_kernel(const ChainArgs a) {
         const unsigned n = t / a.H;
         const unsigned h = t - n * a.H;
         const float4 xv = ld4(a.x + (size_t)pix * a.C + c4);
-        const float4 g = chain_grad(a, n, h, w, c4, xv, s, b);
+        float4 gp;
+        const float4 g = chain_grad(a, n, h, w, c4, xv, s, b, &gp);
+        if (APPLY && a.dres) st4(a.dres + (size_t)pix * a.C + c4, gp);     // (unpooled chains only, see the launcher)
         float4 xh = f4(0.f);
         if (a.mean) xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
         if (!APPLY) {
@@ -899,9 +902,12 @@ extern "C" int pd_chain_bwd_apply(const void* dy, long ld_dy, const void* x, con
     PD_REQUIRE(!dres || relu_post, "pd_chain_bwd_apply: dres is only produced for post-add ReLU blocks");
     if (N == 0) return PD_OK;
     a.coef = (const float*)coef; a.dx = (float*)dx;
+    // the residual gradient dy * [out > 0] is a by-product of the apply pass (same loads); pooled chains keep the
+    // separate pass over the output grid
+    a.dres = pool ? nullptr : (float*)dres;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(chain_bwd_kernel<true>, dim3((unsigned)pd_chain_bwd_rows(N, H, W, C)), dim3(EW_T), 0, st, a);
-    if (dres) {
+    if (dres && pool) {
         const long npix = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W);
         hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(npix * (C / 4))), dim3(EW_T), 0, st, (const float*)dy, ld_dy,
                            (const float*)out, ld_out, (float*)dres, npix, C);
