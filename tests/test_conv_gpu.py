@@ -213,6 +213,30 @@ def test_stride2_data_gradient_by_output_parity(case):
     _close(dx2.cpu(), x.grad)
 
 
+@pytest.mark.parametrize("geom", [(1, 2, 0, 1), (2, 1, 1, 0), (2, 3, 0, 2), (3, 1, 1, 0), (1, 1, 0, 0)])
+def test_rectangular_filter_with_separate_padding(geom):
+    """pd_conv2d_rect, mode 0: KH x KW filter with its own row / column zero padding (uniform-tap kernel) against
+    F.conv2d(padding=(ph, pw)); mode 2 is covered by the parity-split stride-2 data gradient."""
+    from polardepth._lib import lib, check, ptr
+    KH, KW, ph, pw = geom
+    N, C, H, W, Co = 2, 64, 12, 20, 64
+    g = torch.Generator().manual_seed(KH * 10 + KW)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, KH, KW, generator=g) / (C * KH * KW) ** 0.5
+    ref = F.conv2d(x, w, None, stride=1, padding=(ph, pw))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    if KH * KW == 1:
+        wd = wd.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = torch.empty(N, Co, Ho, Wo, device="cuda").contiguous(memory_format=torch.channels_last)
+    sN, sC, sH, sW = xd.stride()
+    check(lib.pd_conv2d_rect(ptr(xd), ptr(wd), ptr(y), N, H, W, C, sN, sH, sW, sC, Ho, Wo, Co, KH, KW, ph, pw, 0, Co, None),
+          "pd_conv2d_rect")
+    torch.cuda.synchronize()
+    _close(y.cpu(), ref)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32, 40), (1, 32, 16, 20), (2, 16, 9, 35), (1, 32, 13, 7), (3, 16, 2, 2),
                                   (1, 16, 64, 96), (1, 32, 3, 70)])
 def test_sixteen_channel_tail_halo_kernel(case):
