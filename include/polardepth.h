@@ -284,6 +284,9 @@ int pd_gt_normals(const void* gt, const void* K, void* gt_normals, int N, int H,
                   void* stream);
 int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, const void* gt_normals, void* partial, int N, int H,
                     int W, float min_depth, float max_depth, int with_normals, void* stream);
+/* pd_sup_loss_bwd: ab_ws ([N,H,W,6] floats) is only read by the two-pass form (PD_SUP_BWD_TWO_PASS=1, kept for A/B runs);
+ * by default one kernel evaluates the per-pixel normal gradients for the halo of an 8 x 64 tile into LDS and gathers
+ * from there, so ab_ws may be NULL. */
 int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* gt_normals, const void* wts,
                     const void* sums, void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
                     int with_normals, int to_disp, void* stream);

@@ -250,6 +250,43 @@ __global__ __launch_bounds__(LT) void sup_fwd_kernel(const float* __restrict__ p
     if (threadIdx.x == 0) { partial[blockIdx.x * 3] = acc[0]; partial[blockIdx.x * 3 + 1] = acc[1]; partial[blockIdx.x * 3 + 2] = acc[2]; }
 }
 
+// (dL/dA_p, dL/dB_p) of the normals term at pixel p = (x, y) of one image (pass A of the backward pass); zero outside the
+// depth-range mask.  i = flat pixel index of p (for the cached ground-truth normal).
+__device__ __forceinline__ void normals_grad_ab(const float* __restrict__ pred_n, const float* __restrict__ gt_n,
+                                                const float4* __restrict__ gtn, long i, float g, Cam c, int H, int W, int x,
+                                                int y, float wln, float min_d, float max_d, V3& dA, V3& dB) {
+    dA = V3{0, 0, 0}; dB = V3{0, 0, 0};
+    if (g >= min_d && g <= max_d) {
+        V3 A, B, Ag, Bg; float nv, nvg;
+        sobel_xyz(pred_n, H, W, x, y, c, A, B);
+        const V3 v = cross(A, B);
+        const V3 nn = normalize12(v, nv);
+        V3 ng;
+        if (gtn) { const float4 q = gtn[i]; ng = V3{q.x, q.y, q.z}; }
+        else { sobel_xyz(gt_n, H, W, x, y, c, Ag, Bg); ng = normalize12(cross(Ag, Bg), nvg); }
+        const float n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f);
+        const V3 gh{ng.x / n1, ng.y / n1, ng.z / n1};
+        // cos = gh . (nn / max(|nn|, eps));  loss = -wln * cos (+ const)
+        const float nl = sqrtf(dot(nn, nn));
+        V3 wn;   // dL/d nn
+        if (nl > 1e-8f) {
+            const float inv = 1.f / nl, pr = dot(gh, nn) * inv * inv * inv;
+            wn = V3{-wln * (gh.x * inv - pr * nn.x), -wln * (gh.y * inv - pr * nn.y), -wln * (gh.z * inv - pr * nn.z)};
+        } else {
+            wn = V3{-wln * gh.x * 1e8f, -wln * gh.y * 1e8f, -wln * gh.z * 1e8f};
+        }
+        V3 wv;   // dL/d v, v -> nn = v / max(|v|, 1e-12)
+        if (nv > 1e-12f) {
+            const float inv = 1.f / nv, pr = dot(wn, nn);
+            wv = V3{(wn.x - pr * nn.x) * inv, (wn.y - pr * nn.y) * inv, (wn.z - pr * nn.z) * inv};
+        } else {
+            wv = V3{wn.x * 1e12f, wn.y * 1e12f, wn.z * 1e12f};
+        }
+        dA = cross(B, wv);   // d(A x B).w / dA = B x w
+        dB = cross(wv, A);   // d(A x B).w / dB = w x A
+    }
+}
+
 // pass A: per pixel p, (dL/dA_p, dL/dB_p) of the normals term  -> ab [N,H,W,6]
 // wts = (w_L1, w_LN, w_sm) for this scale (device), sums = (.., .., sum mask) of the forward
 __global__ __launch_bounds__(LT) void sup_bwd_a_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
@@ -264,37 +301,8 @@ __global__ __launch_bounds__(LT) void sup_bwd_a_kernel(const float* __restrict__
         const long t = divmod(i, W, x);
         const long n = divmod(t, H, y);
         const float g = gt[i];
-        V3 dA{0, 0, 0}, dB{0, 0, 0};
-        if (g >= min_d && g <= max_d) {
-            const Cam c = load_cam(K, n);
-            V3 A, B, Ag, Bg; float nv, nvg;
-            sobel_xyz(pred + n * H * W, H, W, x, y, c, A, B);
-            const V3 v = cross(A, B);
-            const V3 nn = normalize12(v, nv);
-            V3 ng;
-            if (gtn) { const float4 q = gtn[i]; ng = V3{q.x, q.y, q.z}; }
-            else { sobel_xyz(gt + n * H * W, H, W, x, y, c, Ag, Bg); ng = normalize12(cross(Ag, Bg), nvg); }
-            const float n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f);
-            const V3 gh{ng.x / n1, ng.y / n1, ng.z / n1};
-            // cos = gh . (nn / max(|nn|, eps));  loss = -wln * cos (+ const)
-            const float nl = sqrtf(dot(nn, nn));
-            V3 wn;   // dL/d nn
-            if (nl > 1e-8f) {
-                const float inv = 1.f / nl, pr = dot(gh, nn) * inv * inv * inv;
-                wn = V3{-wln * (gh.x * inv - pr * nn.x), -wln * (gh.y * inv - pr * nn.y), -wln * (gh.z * inv - pr * nn.z)};
-            } else {
-                wn = V3{-wln * gh.x * 1e8f, -wln * gh.y * 1e8f, -wln * gh.z * 1e8f};
-            }
-            V3 wv;   // dL/d v, v -> nn = v / max(|v|, 1e-12)
-            if (nv > 1e-12f) {
-                const float inv = 1.f / nv, pr = dot(wn, nn);
-                wv = V3{(wn.x - pr * nn.x) * inv, (wn.y - pr * nn.y) * inv, (wn.z - pr * nn.z) * inv};
-            } else {
-                wv = V3{wn.x * 1e12f, wn.y * 1e12f, wn.z * 1e12f};
-            }
-            dA = cross(B, wv);   // d(A x B).w / dA = B x w
-            dB = cross(wv, A);   // d(A x B).w / dB = w x A
-        }
+        V3 dA, dB;
+        normals_grad_ab(pred + n * H * W, gt + n * H * W, gtn, i, g, load_cam(K, n), H, W, x, y, wln, min_d, max_d, dA, dB);
         float* o = ab + i * 6;
         o[0] = dA.x; o[1] = dA.y; o[2] = dA.z; o[3] = dB.x; o[4] = dB.y; o[5] = dB.z;
     }
@@ -343,6 +351,65 @@ __global__ __launch_bounds__(LT) void sup_bwd_b_kernel(const float* __restrict__
         }
         // depth = 1 / (min_disp + range * up)  ->  d depth / d up = -range * depth^2
         gout[i] = to_disp ? gd * (-disp_range * d * d) : gd;
+    }
+}
+
+// Passes A and B in one kernel: a workgroup evaluates (dA, dB) for the 10 x 66 halo of an 8 x 64 pixel tile into LDS
+// (1.29x the evaluations) and gathers from there -- the [N,H,W,6] intermediate (126 MB written and re-read per scale)
+// never reaches memory.  Same per-pixel arithmetic and summation order as the two-pass form.
+constexpr int SB_TR = 8, SB_TW = 64, SB_HR = SB_TR + 2, SB_HC = SB_TW + 2, SB_HP = SB_HR * SB_HC;
+__global__ __launch_bounds__(LT) void sup_bwd_fused_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                           const float* __restrict__ K, const float4* __restrict__ gtn,
+                                                           const float* __restrict__ wts, const double* __restrict__ sums,
+                                                           float* __restrict__ gout, int N, int H, int W, float min_d,
+                                                           float max_d, float disp_range, int to_disp, int tiles_h,
+                                                           int tiles_w, int ntiles) {
+    __shared__ float abl[6][SB_HP];
+    const float wln = (float)((double)wts[1] / sums[2]);
+    const float wl1 = (float)((double)wts[0] / sums[2]);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h;
+        const long n = tile / (tiles_w * tiles_h);
+        const int h0 = th * SB_TR, w0 = tw * SB_TW;
+        const Cam c = load_cam(K, n);
+        const float* pn = pred + n * H * W;
+        const float* gn = gt + n * H * W;
+        __syncthreads();
+        for (int s = threadIdx.x; s < SB_HP; s += LT) {
+            const int r = s / SB_HC, cc = s - r * SB_HC;
+            const int y = h0 - 1 + r, x = w0 - 1 + cc;
+            V3 dA{0, 0, 0}, dB{0, 0, 0};
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                const long i = (n * H + y) * (long)W + x;
+                normals_grad_ab(pn, gn, gtn, i, gt[i], c, H, W, x, y, wln, min_d, max_d, dA, dB);
+            }
+            abl[0][s] = dA.x; abl[1][s] = dA.y; abl[2][s] = dA.z; abl[3][s] = dB.x; abl[4][s] = dB.y; abl[5][s] = dB.z;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < SB_TR * SB_TW; o += LT) {
+            const int r = o / SB_TW, cc = o - r * SB_TW;
+            const int y = h0 + r, x = w0 + cc;
+            if (y >= H || x >= W) continue;
+            const long i = (n * H + y) * (long)W + x;
+            const float g = gt[i], d = pred[i];
+            float gd = 0.f;
+            if (g >= min_d && g <= max_d) gd = wl1 * (d > g ? 1.f : (d < g ? -1.f : 0.f));
+            V3 s{0, 0, 0};
+            for (int py = max(y - 1, 0); py <= min(y + 1, H - 1); ++py) {
+                float dyw, syw;
+                tap_weights(y, py, H, dyw, syw);
+                for (int px = max(x - 1, 0); px <= min(x + 1, W - 1); ++px) {
+                    float dxw, sxw;
+                    tap_weights(x, px, W, dxw, sxw);
+                    const float ka = syw * dxw * 0.125f, kb = dyw * sxw * 0.125f;
+                    const int q = (py - h0 + 1) * SB_HC + (px - w0 + 1);
+                    s.x += ka * abl[0][q] + kb * abl[3][q]; s.y += ka * abl[1][q] + kb * abl[4][q];
+                    s.z += ka * abl[2][q] + kb * abl[5][q];
+                }
+            }
+            gd += (x - c.cx) / c.fx * s.x + (y - c.cy) / c.fy * s.y + s.z;
+            gout[i] = to_disp ? gd * (-disp_range * d * d) : gd;
+        }
     }
 }
 
@@ -593,9 +660,22 @@ extern "C" int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, 
                                int with_normals, int to_disp, void* stream) {
     PD_REQUIRE(pred && gt && wts && sums && gout && N > 0 && H > 0 && W > 0 && pd::aligned16(gt_normals),
                "pd_sup_loss_bwd: bad arguments");
-    PD_REQUIRE(!with_normals || (K && ab_ws), "pd_sup_loss_bwd: normals term needs K and the [N,H,W,6] workspace");
+    PD_REQUIRE(!with_normals || K, "pd_sup_loss_bwd: the normals term needs K");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = lgrid((long)N * H * W);
+    const char* tp = getenv("PD_SUP_BWD_TWO_PASS");                    // A/B and test switch: the two-pass form
+    const bool two_pass = tp && tp[0] == '1';
+    if (with_normals && !two_pass) {
+        const int tiles_h = (H + SB_TR - 1) / SB_TR, tiles_w = (W + SB_TW - 1) / SB_TW;
+        const long ntiles = (long)N * tiles_h * tiles_w;
+        PD_REQUIRE(ntiles < (1L << 31), "pd_sup_loss_bwd: too many tiles");
+        hipLaunchKernelGGL(sup_bwd_fused_kernel, dim3((unsigned)(ntiles > 4096 ? 4096 : ntiles)), dim3(LT), 0, st,
+                           (const float*)pred, (const float*)gt, (const float*)K, (const float4*)gt_normals, (const float*)wts,
+                           (const double*)sums, (float*)gout, N, H, W, min_depth, max_depth, 1.f / min_depth - 1.f / max_depth,
+                           to_disp, tiles_h, tiles_w, (int)ntiles);
+        return pd::check_launch("pd_sup_loss_bwd");
+    }
+    PD_REQUIRE(!with_normals || ab_ws, "pd_sup_loss_bwd: the two-pass form needs the [N,H,W,6] workspace");
     if (with_normals)
         hipLaunchKernelGGL(sup_bwd_a_kernel, dim3(grid), dim3(LT), 0, st, (const float*)pred, (const float*)gt,
                            (const float*)K, (const float4*)gt_normals, (const float*)wts, (const double*)sums, (float*)ab_ws,

@@ -808,7 +808,8 @@ class MultiScaleLossFn(torch.autograd.Function):
         wts = _f32(dev, 3 * S)
         check(lib.pd_loss_weights(ptr(gvals), _iarr(cfg.scales), S, cfg.w_normals, cfg.w_smooth, ptr(wts), st),
               "pd_loss_weights")
-        ab = _f32(dev, N, H, W, 6)
+        # (the [N,H,W,6] intermediate of the two-pass form; the fused kernel keeps it in LDS)
+        ab = _f32(dev, N, H, W, 6) if os.environ.get("PD_SUP_BWD_TWO_PASS") == "1" else None
         gup = _f32(dev, N, H, W)
         grads = []
         for i in range(S):

@@ -55,6 +55,32 @@ def test_ground_truth_normal_cache_is_bit_exact(monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("geom", [(2, 64, 96), (1, 21, 70), (3, 8, 130)])
+def test_fused_supervised_backward_equals_the_two_pass_form(geom, monkeypatch):
+    """pd_sup_loss_bwd: passes A and B through an LDS halo tile == pass A to memory + pass B (same bits), on grids that
+    are and are not multiples of the 8 x 64 tile."""
+    N, H, W = geom
+    g = torch.Generator().manual_seed(H + W)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    gt = (1.0 + 0.5 * torch.sin(xx / 9.0) * torch.cos(yy / 7.0))[None, None].repeat(N, 1, 1, 1)
+    gt = (gt + 0.02 * torch.rand(N, 1, H, W, generator=g)).cuda()
+    gt[:, :, :2, :3] = 5.0                                      # out-of-range pixels (masked)
+    K = torch.eye(4)[None].repeat(N, 1, 1)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = 0.9 * W, 1.1 * H, 0.5 * W, 0.5 * H
+    K = K.cuda()
+    cfg = PF.LossCfg([0], 0.1, 2.0, 0.35, 1e-3, H, W)
+    color = torch.rand(N, 3, H, W, generator=g).cuda()
+    out = []
+    for two_pass in ("0", "1"):
+        monkeypatch.setenv("PD_SUP_BWD_TWO_PASS", two_pass)
+        disp = torch.rand(N, 1, H, W, generator=torch.Generator().manual_seed(5)).cuda().requires_grad_(True)
+        vals, _ = PF.multiscale_loss(cfg, gt, K, [disp], [color])
+        vals[0].backward()
+        out.append(disp.grad.clone())
+    assert out[0].abs().max() > 0
+    assert torch.equal(out[0], out[1])
+
+
 @pytest.mark.parametrize("f", [1, 2, 4, 8])
 def test_upsample_gradient_gather_specialisations_are_bit_exact(f, monkeypatch):
     """pd_up_gather_bwd: the unrolled power-of-two-zoom kernels against the generic footprint kernel (same bits), and
