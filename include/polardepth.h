@@ -290,9 +290,12 @@ int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, const void*
 int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* gt_normals, const void* wts,
                     const void* sums, void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
                     int with_normals, int to_disp, void* stream);
-int pd_smooth_fwd(const void* disp, const void* img, void* mean, void* partial, int N, int h, int w, void* stream);
-int pd_smooth_bwd(const void* disp, const void* img, const void* mean, const void* wts, void* g_ws, void* gd_acc,
-                  void* gdisp, int N, int h, int w, int accumulate, void* stream);
+/* edge_w (optional, NULL = recompute in the backward pass): [N,h,w,2] floats, the image-only edge weights
+ * e^{-|dx I|}, e^{-|dy I|} (layers.py:452-465) written by the forward pass and read by the backward pass. */
+int pd_smooth_fwd(const void* disp, const void* img, void* mean, void* partial, void* edge_w, int N, int h, int w,
+                  void* stream);
+int pd_smooth_bwd(const void* disp, const void* img, const void* mean, const void* wts, const void* edge_w, void* g_ws,
+                  void* gd_acc, void* gdisp, int N, int h, int w, int accumulate, void* stream);
 int pd_loss_finalize(const void* sup_part, const int* sup_rows, const void* sm_part, const int* sm_rows,
                      const int* dims, const int* scale_ids, int S, int part_stride, float w_normals,
                      float w_smooth, void* sums, void* vals, void* stream);

@@ -72,8 +72,8 @@ SIGNATURES = {
     "pd_gt_normals": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "pd_sup_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "pd_sup_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
-    "pd_smooth_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "pd_smooth_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_smooth_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pd_smooth_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_loss_finalize": (_i, [_vp, _ip, _vp, _ip, _ip, _ip, _i, _i, _f, _f, _vp, _vp, _vp]),
     "pd_loss_from_sums": (_i, [_vp, _ip, _ip, _i, _f, _f, _vp, _vp]),
     "pd_loss_weights": (_i, [_vp, _ip, _i, _f, _f, _vp, _vp]),

@@ -177,6 +177,7 @@ class ActGrad:
 
 USE_ACT_FUSION = os.environ.get("PD_ACT_FUSION", "1") != "0"
 USE_GT_NORMAL_CACHE = os.environ.get("PD_GT_NORMAL_CACHE", "1") != "0"
+USE_EDGE_WEIGHT_CACHE = os.environ.get("PD_EDGE_WEIGHT_CACHE", "1") != "0"   # smoothness edge weights: forward -> backward
 USE_SKIP_FUSION = os.environ.get("PD_SKIP_FUSION", "1") != "0"
 USE_DISPHEAD_FUSED = os.environ.get("PD_DISPHEAD_FUSED", "1") != "0"   # disparity heads: data + weight gradient in one pass
 USE_REFLECT_BORDER = os.environ.get("PD_REFLECT_BORDER", "1") != "0"   # reflect-conv dX = pad-1 dgrad + border strips (no fold pass)
@@ -759,7 +760,7 @@ class MultiScaleLossFn(torch.autograd.Function):
         stride = 2048
         sup_part, sm_part = _f32(dev, S, stride, 3), _f32(dev, S, stride, 2)
         sup_rows, sm_rows, dims = [], [], []
-        depths, means = [], []
+        depths, means, edge_ws = [], [], []
         with_n = 1
         # unit normals of the ground truth: once per step instead of once per scale and direction
         gtn = None
@@ -775,7 +776,9 @@ class MultiScaleLossFn(torch.autograd.Function):
             check(lib.pd_sup_loss_fwd(ptr(depth), ptr(gt), ptr(K), ptr(gtn), ptr(sup_part[i]), N, H, W, cfg.min_depth,
                                       cfg.max_depth, with_n, st), "pd_sup_loss_fwd")
             mean = _f32(dev, N)
-            check(lib.pd_smooth_fwd(ptr(d), ptr(colors[i]), ptr(mean), ptr(sm_part[i]), N, hs, ws, st), "pd_smooth_fwd")
+            ew = _f32(dev, N, hs, ws, 2) if (USE_EDGE_WEIGHT_CACHE and ctx.needs_input_grad[3 + i]) else None
+            check(lib.pd_smooth_fwd(ptr(d), ptr(colors[i]), ptr(mean), ptr(sm_part[i]), ptr(ew), N, hs, ws, st), "pd_smooth_fwd")
+            edge_ws.append(ew)
             sup_rows.append(lib.pd_loss_rows(N * H * W)); sm_rows.append(lib.pd_loss_rows(N * hs * ws))
             dims += [N, hs, ws]
             depths.append(depth); means.append(mean)
@@ -790,6 +793,7 @@ class MultiScaleLossFn(torch.autograd.Function):
                                         ptr(vals), st), "pd_loss_from_sums")
         ctx.cfg, ctx.S = cfg, S
         ctx.gtn = gtn
+        ctx.edge_ws = edge_ws
         ctx.save_for_backward(gt, K, sums, *disps, *colors, *depths, *means)
         ctx.mark_non_differentiable(*depths)
         return (vals, *depths)
@@ -821,7 +825,7 @@ class MultiScaleLossFn(torch.autograd.Function):
             check(lib.pd_up_gather_bwd(ptr(gup), ptr(gd), N, hs, ws, H, W, 0, st), "pd_up_gather_bwd")
             gws = _f32(dev, N, hs, ws)
             gacc = torch.empty(N, dtype=torch.float64, device=dev)
-            check(lib.pd_smooth_bwd(ptr(d), ptr(colors[i]), ptr(means[i]), ptr(wts[3 * i:]), ptr(gws), ptr(gacc),
+            check(lib.pd_smooth_bwd(ptr(d), ptr(colors[i]), ptr(means[i]), ptr(wts[3 * i:]), ptr(ctx.edge_ws[i]), ptr(gws), ptr(gacc),
                                     ptr(gd), N, hs, ws, 1, st), "pd_smooth_bwd")
             grads.append(gd)
         return (None, None, None, *grads, *([None] * S))

@@ -38,15 +38,17 @@ def test_loss_matches_reference_trainer(tag, lam):
         _close(disps[s].grad, T(G5[f"{tag}.ddisp.{s}"]), 1e-4, f"ddisp{s}")
 
 
-def test_ground_truth_normal_cache_is_bit_exact(monkeypatch):
+@pytest.mark.parametrize("switch", ["USE_GT_NORMAL_CACHE", "USE_EDGE_WEIGHT_CACHE"])
+def test_input_only_caches_are_bit_exact(switch, monkeypatch):
     """pd_gt_normals once per step + cached reads in the eight consumers == recomputing the ground-truth normals in
-    every kernel: identical loss values and disparity gradients."""
+    every kernel; smoothness edge weights handed from the forward to the backward kernel == recomputing them:
+    identical loss values and disparity gradients."""
     cfg = PF.LossCfg([0, 1, 2, 3], 0.1, 2.0, 0.35, 1e-3, 64, 96)
     gt, K = T(G5["in.depth"]).cuda(), T(G5["in.K_0"]).cuda()
     colors = [T(G5[f"in.color_0_{s}"]).cuda() for s in range(4)]
     out = []
     for cache in (True, False):
-        monkeypatch.setattr(PF, "USE_GT_NORMAL_CACHE", cache)
+        monkeypatch.setattr(PF, switch, cache)
         disps = [T(G5[f"disp.{s}"]).cuda().requires_grad_(True) for s in range(4)]
         vals, _ = PF.multiscale_loss(cfg, gt, K, disps, colors)
         vals[0].backward()
