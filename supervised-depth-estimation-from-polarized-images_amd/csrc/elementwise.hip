@@ -476,22 +476,33 @@ __global__ __launch_bounds__(EW_T) void maxpool3_fwd_kernel(const float* __restr
         long pix = divmod(i, cq, c4); c4 *= 4;
         pix = divmod(pix, Wo, wo);
         const long n = divmod(pix, Ho, ho);
+        // all nine loads are issued before the first comparison (clamped addresses, taps outside the image are skipped
+        // by predicate): behind a branch each load waited for the previous compare -- nine HBM latencies in a row
+        float4 v[9];
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int h = min(max(2 * ho - 1 + dh, 0), H - 1);
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int w = min(max(2 * wo - 1 + dw, 0), W - 1);
+                v[dh * 3 + dw] = ld4(x + ((n * H + h) * W + w) * C + c4);
+            }
+        }
         float4 m = f4(-INFINITY);
         uint32_t ix = 0, iy = 0, iz = 0, iw = 0;
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
             const int h = 2 * ho - 1 + dh;
-            if (h < 0 || h >= H) continue;
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
                 const int w = 2 * wo - 1 + dw;
-                if (w < 0 || w >= W) continue;
-                const float4 v = ld4(x + ((n * H + h) * W + w) * C + c4);
+                const bool in = h >= 0 && h < H && w >= 0 && w < W;
+                const float4 t = v[dh * 3 + dw];
                 const uint32_t id = (uint32_t)(dh * 3 + dw);
-                if (v.x > m.x) { m.x = v.x; ix = id; }
-                if (v.y > m.y) { m.y = v.y; iy = id; }
-                if (v.z > m.z) { m.z = v.z; iz = id; }
-                if (v.w > m.w) { m.w = v.w; iw = id; }
+                if (in && t.x > m.x) { m.x = t.x; ix = id; }
+                if (in && t.y > m.y) { m.y = t.y; iy = id; }
+                if (in && t.z > m.z) { m.z = t.z; iz = id; }
+                if (in && t.w > m.w) { m.w = t.w; iw = id; }
             }
         }
         st4(y + i * 4, m);
@@ -512,21 +523,29 @@ __global__ __launch_bounds__(EW_T) void maxpool3_bwd_kernel(const uint32_t* __re
         long pix = divmod(i, cq, cqi);
         pix = divmod(pix, W, w);
         const long n = divmod(pix, H, h);
+        // the (up to) four covering windows: ho in {h/2, (h+1)/2}, wo likewise; all loads first (clamped, duplicates and
+        // windows beyond the grid are masked out), same summation order as the nested loops
+        const int hoa = h >> 1, hob = (h + 1) >> 1, woa = w >> 1, wob = (w + 1) >> 1;
+        uint32_t ids[4]; float4 gs[4]; bool use[4]; uint32_t mes[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ho = (k >> 1) ? hob : hoa, wo = (k & 1) ? wob : woa;
+            use[k] = ho < Ho && wo < Wo && !((k >> 1) && hob == hoa) && !((k & 1) && wob == woa);
+            const int hc = min(ho, Ho - 1), wc = min(wo, Wo - 1);
+            const long o = ((n * Ho + hc) * Wo + wc) * cq + cqi;
+            ids[k] = idx[o];
+            gs[k] = ld4(dy + o * 4);
+            mes[k] = (uint32_t)(h - (2 * ho - 1)) * 3u + (uint32_t)(w - (2 * wo - 1));
+        }
         float4 acc = f4(0.f);
-        for (int ho = h >> 1; ho <= (h + 1) >> 1; ++ho) {
-            if (ho >= Ho) continue;
-            const uint32_t dh = (uint32_t)(h - (2 * ho - 1));
-            for (int wo = w >> 1; wo <= (w + 1) >> 1; ++wo) {
-                if (wo >= Wo) continue;
-                const uint32_t me = dh * 3u + (uint32_t)(w - (2 * wo - 1));
-                const long o = ((n * Ho + ho) * Wo + wo) * cq + cqi;
-                const uint32_t id = idx[o];
-                const float4 g = ld4(dy + o * 4);
-                acc.x += (id & 0xffu) == me ? g.x : 0.f;
-                acc.y += ((id >> 8) & 0xffu) == me ? g.y : 0.f;
-                acc.z += ((id >> 16) & 0xffu) == me ? g.z : 0.f;
-                acc.w += (id >> 24) == me ? g.w : 0.f;
-            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!use[k]) continue;
+            const uint32_t id = ids[k], me = mes[k];
+            acc.x += (id & 0xffu) == me ? gs[k].x : 0.f;
+            acc.y += ((id >> 8) & 0xffu) == me ? gs[k].y : 0.f;
+            acc.z += ((id >> 16) & 0xffu) == me ? gs[k].z : 0.f;
+            acc.w += (id >> 24) == me ? gs[k].w : 0.f;
         }
         st4(dx + i * 4, acc);
     }
@@ -585,21 +604,23 @@ __global__ __launch_bounds__(EW_T) void up_bwd_kernel(const float* __restrict__ 
         float wy[4], wx[4];
         wy[0] = h > 0 ? 0.25f : 0.f; wy[1] = h > 0 ? 0.75f : 1.f; wy[2] = h < H - 1 ? 0.75f : 1.f; wy[3] = h < H - 1 ? 0.25f : 0.f;
         wx[0] = w > 0 ? 0.25f : 0.f; wx[1] = w > 0 ? 0.75f : 1.f; wx[2] = w < W - 1 ? 0.75f : 1.f; wx[3] = w < W - 1 ? 0.25f : 0.f;
-        float4 acc = f4(0.f);
+        float4 gv[16];                                                 // all sixteen loads before the first use
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int y = min(max(2 * h - 1 + a, 0), Ho - 1);          // weight 0 where clamped
             const float* row = dout + ((n * Ho + y) * (long)Wo) * ld_d + c4;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int x = min(max(2 * w - 1 + b, 0), Wo - 1);
-                const float ww = wy[a] * wx[b];
-                if (ww != 0.f) {
-                    const float4 g = ld4(row + (long)x * ld_d);
-                    acc.x += ww * g.x; acc.y += ww * g.y; acc.z += ww * g.z; acc.w += ww * g.w;
-                }
-            }
+            for (int b = 0; b < 4; ++b) gv[a * 4 + b] = ld4(row + (long)min(max(2 * w - 1 + b, 0), Wo - 1) * ld_d);
         }
+        float4 acc = f4(0.f);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float ww = wy[a] * wx[b];
+                const float4 g = gv[a * 4 + b];
+                if (ww != 0.f) { acc.x += ww * g.x; acc.y += ww * g.y; acc.z += ww * g.z; acc.w += ww * g.w; }
+            }
         if (elu_y) {
             const float4 o = ld4(elu_y + i * 4);
             acc.x = o.x > 0.f ? acc.x : acc.x * (o.x + 1.f); acc.y = o.y > 0.f ? acc.y : acc.y * (o.y + 1.f);
