@@ -95,6 +95,14 @@ int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, 
 int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tables, size_t tables_bytes,
                                int B, int H, int W, int flags, void* stream);
 
+/* rho_diffuse / rho_spec as functions of their own (manydepth/normals_vec.py:11-22, 25-50): rho fp32 [n] ->
+ * theta_d, theta_s1, theta_s2 fp64 [n] (each may be NULL) = scipy interp1d(fill_value="extrapolate") of the three
+ * tables, evaluated in scipy's operation order (slope * (rho - x_lo) + y_lo, fp64), so rho beyond a table extrapolates
+ * exactly like the reference (theta_s1 up to +41 rad, theta_s2 down to -135 rad for DoLP ~ 2).  bins: optional int32
+ * [3][n], the clip(searchsorted(x, rho, 'left'), 1, n-1) index of each table.  NaN rho sorts last like numpy. */
+int pd_polar_theta(const void* rho, void* theta_d, void* theta_s1, void* theta_s2, void* bins,
+                   const void* tables, size_t tables_bytes, long n, void* stream);
+
 /* ------------------------------------------------------------------------- K2
  * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
  *
@@ -253,6 +261,8 @@ int pd_up_bwd_elu(const void* dout, long ld_d, const void* elu_y, void* da, int 
 int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int act, void* stream);
 /* Gradient of ReflectionPad2d(1): dxp [N,H+2,W+2,C] -> dx [N,H,W,C]  (layers.py:372). */
 int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, int C, void* stream);
+/* ... of ReflectionPad2d(pad), 1 <= pad < min(H, W): dxp [N,H+2pad,W+2pad,C] -> dx [N,H,W,C]  (layers.py:352, Conv5x5). */
+int pd_reflect_fold_pad(const void* dxp, void* dx, int N, int H, int W, int C, int pad, void* stream);
 /* The same gradient without the padded intermediate: dx (in/out, NHWC [N,H,W,Cin]) already holds the zero-padding
  * (pad 1) data gradient -- the interior of the padded-grid gradient -- and receives the four folded border strips
  * (1x3 / 3x1 filter slices applied to the first / last row and column of dz [N,H,W,Cout], row stride ldd;
@@ -284,6 +294,12 @@ int pd_gt_normals(const void* gt, const void* K, void* gt_normals, int N, int H,
                   void* stream);
 int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, const void* gt_normals, void* partial, int N, int H,
                     int W, float min_depth, float max_depth, int with_normals, void* stream);
+/* Trainer.compute_supervised_normals_losses as a function of its own (trainer.py:1298-1309) with the CALLER's mask:
+ * out[0] = sum((2 - cos(n_gt, n_pred)) * mask) / sum(mask), normals = kornia depth_to_normals of the two depth maps at
+ * every pixel (no depth-range gate), mask fp32 [N,H,W] (any values: it multiplies).  partial_ws: pd_loss_rows(N*H*W) * 2
+ * floats; the ratio is formed on the device from an ordered fp64 sum of the partials. */
+int pd_normals_loss_masked(const void* pred, const void* gt, const void* K, const void* mask, void* partial_ws, void* out,
+                           int N, int H, int W, void* stream);
 /* pd_sup_loss_bwd: ab_ws ([N,H,W,6] floats) is only read by the two-pass form (PD_SUP_BWD_TWO_PASS=1, kept for A/B runs);
  * by default one kernel evaluates the per-pixel normal gradients for the halo of an 8 x 64 tile into LDS and gathers
  * from there, so ab_ws may be NULL. */

@@ -645,22 +645,22 @@ __global__ __launch_bounds__(EW_T) void act_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------- reflection-pad fold
-// dxp [N,H+2,W+2,C] (gradient on the padded grid, pad 1) -> dx [N,H,W,C]; V = channels per thread (4 or 1)
+// dxp [N,H+2p,W+2p,C] (gradient on the padded grid, pad p) -> dx [N,H,W,C]; V = channels per thread (4 or 1)
 template <int V>
 __global__ __launch_bounds__(EW_T) void reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx,
-                                                            int N, int H, int W, int C) {
+                                                            int N, int H, int W, int C, int pad) {
     const int cq = C / V;
     const long total = (long)N * H * W * cq;
-    const int Hp = H + 2, Wp = W + 2;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
         int c, w, h;
         long pix = divmod(i, cq, c); c *= V;
         pix = divmod(pix, W, w);
         const long n = divmod(pix, H, h);
-        // padded rows that map to h: h+1 always; 0 if h == 1; Hp-1 if h == H-2
+        // padded rows that map to h: h+p always; p-h for 1 <= h <= p (top border); 2(H-1)-h+p for H-1-p <= h <= H-2
         int hs[3], ws[3], nh = 0, nw = 0;
-        hs[nh++] = h + 1; if (h == 1) hs[nh++] = 0; if (h == H - 2) hs[nh++] = Hp - 1;
-        ws[nw++] = w + 1; if (w == 1) ws[nw++] = 0; if (w == W - 2) ws[nw++] = Wp - 1;
+        hs[nh++] = h + pad; if (h >= 1 && h <= pad) hs[nh++] = pad - h; if (h >= H - 1 - pad && h <= H - 2) hs[nh++] = 2 * (H - 1) - h + pad;
+        ws[nw++] = w + pad; if (w >= 1 && w <= pad) ws[nw++] = pad - w; if (w >= W - 1 - pad && w <= W - 2) ws[nw++] = 2 * (W - 1) - w + pad;
         float4 acc = f4(0.f);
         for (int a = 0; a < nh; ++a)
             for (int b = 0; b < nw; ++b) {
@@ -987,16 +987,21 @@ extern "C" int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int a
     return pd::check_launch("pd_act_bwd");
 }
 
-extern "C" int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, int C, void* stream) {
+extern "C" int pd_reflect_fold_pad(const void* dxp, void* dx, int N, int H, int W, int C, int pad, void* stream) {
     PD_REQUIRE(dxp && dx && N >= 0 && H >= 2 && W >= 2 && C > 0, "pd_reflect_fold: bad arguments");
+    PD_REQUIRE(pad >= 1 && pad < H && pad < W, "pd_reflect_fold: pad must be in [1, min(H, W))");
     if (N == 0) return PD_OK;
     if (C % 4 == 0)
         hipLaunchKernelGGL(reflect_fold_kernel<4>, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(EW_T), 0,
-                           (hipStream_t)stream, (const float*)dxp, (float*)dx, N, H, W, C);
+                           (hipStream_t)stream, (const float*)dxp, (float*)dx, N, H, W, C, pad);
     else
         hipLaunchKernelGGL(reflect_fold_kernel<1>, dim3(ew_grid((long)N * H * W * C)), dim3(EW_T), 0,
-                           (hipStream_t)stream, (const float*)dxp, (float*)dx, N, H, W, C);
+                           (hipStream_t)stream, (const float*)dxp, (float*)dx, N, H, W, C, pad);
     return pd::check_launch("pd_reflect_fold");
+}
+
+extern "C" int pd_reflect_fold(const void* dxp, void* dx, int N, int H, int W, int C, void* stream) {
+    return pd_reflect_fold_pad(dxp, dx, N, H, W, C, 1, stream);
 }
 
 extern "C" int pd_reflect_dgrad_border(const void* dz, long ldd, const void* w, void* dx, int N, int H, int W, int Co,

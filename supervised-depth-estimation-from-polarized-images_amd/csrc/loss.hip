@@ -250,6 +250,48 @@ __global__ __launch_bounds__(LT) void sup_fwd_kernel(const float* __restrict__ p
     if (threadIdx.x == 0) { partial[blockIdx.x * 3] = acc[0]; partial[blockIdx.x * 3 + 1] = acc[1]; partial[blockIdx.x * 3 + 2] = acc[2]; }
 }
 
+// compute_supervised_normals_losses with an arbitrary mask (the facade method; the training step uses sup_fwd_kernel,
+// whose mask is the depth-range mask the trainer always passes): partial[block][2] = (sum (2 - cos) m, sum m)
+__global__ __launch_bounds__(LT) void normals_loss_masked_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                                 const float* __restrict__ K, const float* __restrict__ mask,
+                                                                 float* __restrict__ partial, int N, int H, int W) {
+    __shared__ float sm[4 * 2];
+    const long total = (long)N * H * W;
+    float acc[2] = {0.f, 0.f};
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const float m = mask[i];
+        if (m == 0.f) continue;
+        int x, y;
+        const long t = divmod(i, W, x);
+        const long n = divmod(t, H, y);
+        const Cam c = load_cam(K, n);
+        V3 A, B; float nv;
+        sobel_xyz(pred + n * H * W, H, W, x, y, c, A, B);
+        const V3 np_ = normalize12(cross(A, B), nv);
+        sobel_xyz(gt + n * H * W, H, W, x, y, c, A, B);
+        const V3 ng = normalize12(cross(A, B), nv);
+        const float n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f), n2 = fmaxf(sqrtf(dot(np_, np_)), 1e-8f);
+        const float cs = (ng.x / n1) * (np_.x / n2) + (ng.y / n1) * (np_.y / n2) + (ng.z / n1) * (np_.z / n2);
+        acc[0] += (2.f - cs) * m;
+        acc[1] += m;
+    }
+    block_sum<2>(acc, sm);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = acc[0]; partial[blockIdx.x * 2 + 1] = acc[1]; }
+}
+
+__global__ __launch_bounds__(256) void ratio_of_partials_kernel(const float* __restrict__ partial, int rows, float* __restrict__ out) {
+    __shared__ double s0[256], s1[256];
+    double a = 0.0, b = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) { a += partial[2 * r]; b += partial[2 * r + 1]; }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { s0[threadIdx.x] += s0[threadIdx.x + k]; s1[threadIdx.x] += s1[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(s0[0] / s1[0]);
+}
+
 // (dL/dA_p, dL/dB_p) of the normals term at pixel p = (x, y) of one image (pass A of the backward pass); zero outside the
 // depth-range mask.  i = flat pixel index of p (for the cached ground-truth normal).
 __device__ __forceinline__ void normals_grad_ab(const float* __restrict__ pred_n, const float* __restrict__ gt_n,
@@ -682,6 +724,18 @@ extern "C" int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, 
                        (const float*)pred, (const float*)gt, (const float*)K, (const float4*)gt_normals, (float*)partial, N,
                        H, W, min_depth, max_depth, with_normals);
     return pd::check_launch("pd_sup_loss_fwd");
+}
+
+extern "C" int pd_normals_loss_masked(const void* pred, const void* gt, const void* K, const void* mask, void* partial_ws,
+                                      void* out, int N, int H, int W, void* stream) {
+    PD_REQUIRE(pred && gt && K && mask && partial_ws && out && N > 0 && H > 0 && W > 0, "pd_normals_loss_masked: bad arguments");
+    const long total = (long)N * H * W;
+    const int rows = (int)lgrid(total);
+    hipLaunchKernelGGL(normals_loss_masked_kernel, dim3(rows), dim3(LT), 0, (hipStream_t)stream, (const float*)pred,
+                       (const float*)gt, (const float*)K, (const float*)mask, (float*)partial_ws, N, H, W);
+    hipLaunchKernelGGL(ratio_of_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial_ws, rows,
+                       (float*)out);
+    return pd::check_launch("pd_normals_loss_masked");
 }
 
 extern "C" int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* gt_normals, const void* wts,

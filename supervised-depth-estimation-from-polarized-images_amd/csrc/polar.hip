@@ -39,7 +39,7 @@
 
 namespace {
 
-constexpr uint32_t kMagic = 0x50444c35u;   // "PDL5"
+constexpr uint32_t kMagic = 0x50444c36u;   // "PDL6"
 constexpr int kNB = 4096;                  // buckets of the one-read search
 constexpr uint32_t kSqrtMagic = 0x1fbd1df5u;   // as_float((bits(x) >> 1) + magic) ~ sqrt(x), monotone, integer-exact
 constexpr int kLutSide = 511;
@@ -59,7 +59,8 @@ struct PolarHeader {   // 64 bytes, little endian
     uint32_t total_bytes;
     float bscale;          // bucket = min(int(approx_sqrt(rho) * bscale), kNB - 1)
     uint32_t n_buckets;
-    uint32_t pad[2];
+    uint32_t off_ylo;          // double[nk]: y_lo of every bin (entry i = y[i-1]), for the theta outputs of pd_polar_theta
+    uint32_t pad;
 };
 static_assert(sizeof(PolarHeader) == 64, "header size");
 
@@ -78,6 +79,7 @@ inline size_t common_bytes_for(int nk) { return size_t(kNB) * 16 + keys_padded(n
 inline size_t lut_bytes() { return round_up(size_t(kLutCount) * 4, 16); }
 inline size_t lut4_bytes() { return size_t(kLutCount) * 16; }
 inline size_t img_bytes_for(int nk, bool precise) { return round_up(common_bytes_for(nk) + size_t(nk) * (precise ? 32 : 16), 1024); }
+inline size_t ylo_bytes_for(int nk) { return round_up(size_t(nk) * 8, 16); }
 
 float floor32(double x) {  // largest fp32 <= x
     float f = static_cast<float>(x);
@@ -111,7 +113,7 @@ __host__ __device__ inline int bucket_of(float rho, float bscale) {
 extern "C" size_t pd_polar_tables_bytes(int n_d, int n_s1, int n_s2) {
     if (n_d < 2 || n_s1 < 2 || n_s2 < 2) return 0;
     const int nk = n_d + n_s1 + n_s2;
-    return sizeof(PolarHeader) + lut_bytes() + lut4_bytes() + img_bytes_for(nk, false) + img_bytes_for(nk, true);
+    return sizeof(PolarHeader) + lut_bytes() + lut4_bytes() + img_bytes_for(nk, false) + img_bytes_for(nk, true) + ylo_bytes_for(nk);
 }
 
 extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_d,
@@ -136,6 +138,7 @@ extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_
     h.off_img_precise = h.off_img_fast + h.img_fast_bytes;
     h.img_precise_bytes = uint32_t(img_bytes_for(nk, true));
     h.common_bytes = uint32_t(common_bytes_for(nk));
+    h.off_ylo = h.off_img_precise + h.img_precise_bytes;
     h.total_bytes = uint32_t(need);
     h.n_buckets = kNB;
     PD_REQUIRE(h.img_precise_bytes <= 160 * 1024, "pd_polar_tables_pack: tables exceed the 160 KB LDS of a CU");
@@ -162,6 +165,7 @@ extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_
     float* keys = reinterpret_cast<float*>(base + h.off_img_fast + size_t(kNB) * 16);
     float* fbins = reinterpret_cast<float*>(base + h.off_img_fast + h.common_bytes);
     double* bins = reinterpret_cast<double*>(base + h.off_img_precise + h.common_bytes);
+    double* ylo = reinterpret_cast<double*>(base + h.off_ylo);
     float kmax = 0.f;
     int o = 0;
     for (int t = 0; t < 3; ++t) {
@@ -175,6 +179,7 @@ extern "C" int pd_polar_tables_pack(const double* x_d, const double* y_d, int n_
                 const double x_lo = xs[t][i - 1], y_lo = ys[t][i - 1];
                 const double slope = (ys[t][i] - y_lo) / (xs[t][i] - x_lo);
                 bin[0] = x_lo; bin[1] = slope; bin[2] = sin(y_lo); bin[3] = cos(y_lo);
+                ylo[o + i] = y_lo;
                 // fast bin: theta - j*pi/2 = slope*(rho - x_lo32) + c,  c = y_lo - slope*(x_lo - x_lo32) - j*pi/2
                 float* fb = fbins + size_t(o + i) * 4;
                 const float x32 = floor32(x_lo);
@@ -771,11 +776,42 @@ __global__ __launch_bounds__(NTH) void normals_from_xolp_kernel(const float* __r
     }
 }
 
+// rho_diffuse / rho_spec of the reference as they stand (manydepth/normals_vec.py:11-50): fp32 rho -> the three fp64
+// angles scipy's interp1d(fill_value="extrapolate") returns, theta = slope * (rho - x_lo) + y_lo evaluated in scipy's
+// operation order (_call_linear; no fused multiply-add: this file is built with -ffp-contract=off), so that rho far
+// outside a table extrapolates to the same +41 / -135 rad the reference produces.  Optional int32 bin indices.
+template <int NTH>
+__global__ __launch_bounds__(NTH) void theta_kernel(const float* __restrict__ rho, double* __restrict__ th_d,
+                                                    double* __restrict__ th_s1, double* __restrict__ th_s2,
+                                                    int* __restrict__ bins_out, const char* __restrict__ blob, long n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Tabs tabs;
+    stage_tables<true>(blob, smem, NTH, tabs);
+    const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
+    const double* ylo = reinterpret_cast<const double*>(blob + h->off_ylo);
+    for (long i = blockIdx.x * (long)NTH + threadIdx.x; i < n; i += (long)gridDim.x * NTH) {
+        const float r = rho[i];
+        int bi[3];
+        lookup3<true>(r, tabs, bi);
+        const int idx[3] = {bi[0], tabs.n_d + bi[1], tabs.n_d + tabs.n_s1 + bi[2]};
+        const double x = static_cast<double>(r);
+        double* outs[3] = {th_d, th_s1, th_s2};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (outs[t]) {
+                const double* bin = tabs.bins + 4 * idx[t];
+                outs[t][i] = bin[1] * (x - bin[0]) + ylo[idx[t]];
+            }
+            if (bins_out) bins_out[t * n + i] = bi[t];
+        }
+    }
+}
+
 // node count implied by the blob size (monotone in nk)
 inline int nk_from_blob_bytes(size_t tables_bytes) {
     const size_t fixed = sizeof(PolarHeader) + lut_bytes() + lut4_bytes();
     for (int nk = 6; nk <= 3 * kMaxNodes; ++nk)
-        if (fixed + img_bytes_for(nk, false) + img_bytes_for(nk, true) == tables_bytes) return nk;
+        if (fixed + img_bytes_for(nk, false) + img_bytes_for(nk, true) + ylo_bytes_for(nk) == tables_bytes) return nk;
     return 0;
 }
 
@@ -832,6 +868,24 @@ extern "C" int pd_polar_normals_from_xolp(const void* xolp, void* normals, const
         hipLaunchKernelGGL((normals_from_xolp_kernel<false, 1024>), dim3((unsigned)blocks), dim3(1024), lds, (hipStream_t)stream,
                            (const float*)xolp, (float*)normals, (const char*)tables, P, qpi, total);
     return pd::check_launch("pd_polar_normals_from_xolp");
+}
+
+extern "C" int pd_polar_theta(const void* rho, void* theta_d, void* theta_s1, void* theta_s2, void* bins,
+                              const void* tables, size_t tables_bytes, long n, void* stream) {
+    PD_REQUIRE(n >= 0, "pd_polar_theta: bad element count");
+    if (n == 0) return PD_OK;
+    PD_REQUIRE(rho && tables && (theta_d || theta_s1 || theta_s2 || bins), "pd_polar_theta: null pointer / no output");
+    const int nk = nk_from_blob_bytes(tables_bytes);
+    PD_REQUIRE(nk > 0, "pd_polar_theta: tables blob has an unexpected size");
+    const size_t lds = img_bytes_for(nk, true);
+    int rc = set_lds_limit(theta_kernel<kThreadsP>, lds);
+    if (rc) return rc;
+    long blocks = (n + kThreadsP - 1) / kThreadsP;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL((theta_kernel<kThreadsP>), dim3((unsigned)blocks), dim3(kThreadsP), lds, (hipStream_t)stream,
+                       (const float*)rho, (double*)theta_d, (double*)theta_s1, (double*)theta_s2, (int*)bins,
+                       (const char*)tables, n);
+    return pd::check_launch("pd_polar_theta");
 }
 
 extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, void* normals,

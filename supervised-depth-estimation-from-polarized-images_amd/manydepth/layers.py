@@ -37,6 +37,21 @@ class Conv3x3(nn.Module):
         return PF.reflect_conv_act(x, self.conv, act, **mails)
 
 
+class Conv5x5(nn.Module):
+    """ReflectionPad2d(2) (or ZeroPad2d(2)) + Conv2d(5) (layers.py:345-362; the decoder's uncertainty heads,
+    depth_decoder.py:49-50)."""
+
+    def __init__(self, in_channels, out_channels, use_refl=True):
+        super().__init__()
+        self.pad = nn.ReflectionPad2d(2) if use_refl else nn.ZeroPad2d(2)
+        self.use_refl = bool(use_refl)
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 5)
+        self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def forward(self, x):
+        return PF.padded_conv(x, self.conv, 2, reflect=self.use_refl)
+
+
 class ConvBlock(nn.Module):
     """Conv3x3 + ELU (layers.py:329-342), one kernel."""
 

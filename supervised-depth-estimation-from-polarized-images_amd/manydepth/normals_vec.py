@@ -1,10 +1,10 @@
-"""manydepth.normals_vec façade (reference manydepth/normals_vec.py:11-60) on the HIP kernel.
+"""manydepth.normals_vec facade (reference manydepth/normals_vec.py:11-60) on the HIP kernels.
 
-``rho_diffuse`` / ``rho_spec`` / ``calc_normals`` keep their signatures; the per-pixel table
-interpolation and trigonometry run in ``pd_polar_normals_from_xolp`` instead of the reference's
-GPU -> CPU(scipy) -> GPU round trip.  The thetas themselves are not materialised by the kernel;
-callers that need them get them by inverting the N3 = cos(theta) channel is NOT offered -- use
-``get_normals`` (pre_encoders.ShallowNormalsEncoder.get_normals) for the fused result.
+``rho_diffuse`` / ``rho_spec`` / ``calc_normals`` keep their signatures and results: the thetas are the reference's fp64
+``scipy.interpolate.interp1d(..., fill_value="extrapolate")`` values (``pd_polar_theta`` evaluates scipy's
+``slope * (rho - x_lo) + y_lo`` in fp64, so DoLP beyond a table extrapolates to the same +41 / -135 rad), returned as
+fp64 CPU tensors of rho's shape exactly like ``torch.from_numpy(f(rho))`` there.  The training path does not call these
+(``ShallowNormalsEncoder.get_normals`` is served by the fused kernel K1); ``get_normals`` below is that fused result.
 """
 import torch
 
@@ -12,30 +12,32 @@ from polardepth import polar as _polar
 
 
 def get_normals(xolp, n=1.5):
-    """[B,2,H,W] fp32 (DoLP, AoLP) -> [B,9,H,W] fp32: cat(N_diff, N_spec1, N_spec2)."""
+    """[B,2,H,W] fp32 (DoLP, AoLP) -> [B,9,H,W] fp32: cat(N_diff, N_spec1, N_spec2)  (pre_encoders.py:99-113)."""
     return _polar.normals_from_xolp(xolp, n)
 
 
-def _normals_of(rho, phi, n):
-    x = torch.stack((rho, phi), 1)
-    return get_normals(x, n)
-
-
-def calc_normals(phi, theta):
-    """N = (cos(phi) sin(theta), sin(phi) sin(theta), cos(theta)); elementwise, on the tensors' device."""
-    N1 = (torch.cos(phi) * torch.sin(theta)).unsqueeze(1)
-    N2 = (torch.sin(phi) * torch.sin(theta)).unsqueeze(1)
-    N3 = torch.cos(theta).unsqueeze(1)
-    return torch.cat((N1, N2, N3), 1)
+def _device(rho):
+    if not torch.cuda.is_available():
+        raise RuntimeError("manydepth.normals_vec runs on the MI355X; there is no CPU fallback")
+    return rho if rho.is_cuda else rho.cuda()
 
 
 def rho_diffuse(rho, n):
-    """theta_diffuse from the fused kernel: N_diff with phi = 0 is (sin(theta), 0, cos(theta))."""
-    nd = _normals_of(rho, torch.zeros_like(rho), n)[:, 0:3].double()
-    return torch.atan2(nd[:, 0], nd[:, 2])
+    """normals_vec.py:11-22: theta_diffuse(rho), fp64 CPU tensor."""
+    return _polar.theta_from_rho(_device(rho), n, want=("d",))["d"].cpu()
 
 
 def rho_spec(rho, n):
-    """(theta_spec1, theta_spec2) modulo 2*pi, recovered the same way (phi' = pi/2 -> N = (~0, sin, cos))."""
-    ns = _normals_of(rho, torch.zeros_like(rho), n).double()
-    return torch.atan2(ns[:, 4], ns[:, 5]), torch.atan2(ns[:, 7], ns[:, 8])
+    """normals_vec.py:25-50: (theta_spec1, theta_spec2), fp64 CPU tensors (branches below / above the DoLP maximum)."""
+    out = _polar.theta_from_rho(_device(rho), n, want=("s1", "s2"))
+    return out["s1"].cpu(), out["s2"].cpu()
+
+
+def calc_normals(phi, theta):
+    """normals_vec.py:53-60: N = (cos(phi) sin(theta), sin(phi) sin(theta), cos(theta)) on the GPU, [B,3,H,W]; the
+    dtype follows torch's promotion (fp32 phi with fp64 theta gives fp64, like the reference)."""
+    phi, theta = _device(phi), _device(theta)
+    N1 = (torch.cos(phi) * torch.sin(theta)).unsqueeze(dim=1)
+    N2 = (torch.sin(phi) * torch.sin(theta)).unsqueeze(dim=1)
+    N3 = torch.cos(theta).unsqueeze(dim=1)
+    return torch.cat((N1, N2, N3), dim=1)

@@ -347,17 +347,21 @@ class Trainer:
         return losses
 
     def compute_supervised_normals_losses(self, depth_gt, depth_pred, intrinsics, mask=None):
-        """trainer.py:1298-1309 (value only): sum((2 - cos) * mask) / sum(mask) with the depth-range mask."""
+        """trainer.py:1298-1309 (value only): sum((2 - cos(n_gt, n_pred)) * mask) / sum(mask) with the CALLER's mask
+        [N,1,H,W] (the reference passes the depth-range mask, trainer.py:1242-1243,1250; None selects it here)."""
         N, _, H, W = depth_gt.shape
-        K = torch.eye(4, device=depth_gt.device)[None].repeat(N, 1, 1)
+        dev = depth_gt.device
+        K = torch.eye(4, device=dev)[None].repeat(N, 1, 1)
         K[:, :3, :3] = intrinsics[:, :3, :3]
-        rows = lib.pd_loss_rows(N * H * W)
-        part = torch.empty((rows, 3), dtype=torch.float32, device=depth_gt.device)
-        check(lib.pd_sup_loss_fwd(ptr(depth_pred.contiguous().float()), ptr(depth_gt.contiguous().float()),
-                                  ptr(K.contiguous()), None, ptr(part), N, H, W, self.opt.min_depth, self.opt.max_depth, 1,
-                                  stream_ptr()), "pd_sup_loss_fwd")
-        s = part.double().sum(0)
-        return (s[1] / s[2]).float()
+        gt, pred = depth_gt.contiguous().float(), depth_pred.detach().contiguous().float()
+        if mask is None:
+            mask = (gt >= self.opt.min_depth) & (gt <= self.opt.max_depth)
+        mask = mask.to(device=dev, dtype=torch.float32).expand(N, 1, H, W).contiguous()
+        part = torch.empty((lib.pd_loss_rows(N * H * W), 2), dtype=torch.float32, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        check(lib.pd_normals_loss_masked(ptr(pred), ptr(gt), ptr(K.contiguous()), ptr(mask), ptr(part), ptr(out), N, H, W,
+                                         stream_ptr()), "pd_normals_loss_masked")
+        return out[0]
 
     # ------------------------------------------------------------------ validation / test
     def _next_val(self):

@@ -30,6 +30,7 @@ SIGNATURES = {
     "pd_polar_tables_build": (_i, [_dbl, _vp, _sz, _c.POINTER(_sz)]),
     "pd_polar_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
     "pd_polar_normals_from_xolp": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "pd_polar_theta": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _l, _vp]),
     "pd_conv2d_tile_m": (_i, [_l, _i]),
     "pd_conv2d_stats_rows": (_l, [_l, _i]),
     "pd_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i,
@@ -64,6 +65,7 @@ SIGNATURES = {
     "pd_up_bwd_elu": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_act_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "pd_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_reflect_fold_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pd_reflect_dgrad_border": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pd_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _i, _vp]),
     "pd_loss_rows": (_i, [_l]),
@@ -71,6 +73,7 @@ SIGNATURES = {
     "pd_up_gather_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pd_gt_normals": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "pd_sup_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    "pd_normals_loss_masked": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pd_sup_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
     "pd_smooth_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pd_smooth_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -519,6 +519,50 @@ def reflect_conv_act(x, conv, act, act_mail=None, dx_mail=None, head_mail=None):
     return ReflectConvActFn.apply(x, w, conv.bias, act, act_mail, dx_mail)
 
 
+class PaddedConvFn(torch.autograd.Function):
+    """ReflectionPad2d(p) / ZeroPad2d(p) + Conv2d(k, bias) for any odd k = 2p + 1 (layers.Conv5x5; not on the training
+    step): general implicit-GEMM forward, data gradient on the padded grid + pd_reflect_fold_pad, general weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad, reflect):
+        x = ops.as_nhwc(x)
+        mode = ops.MODE_REFLECT if reflect else ops.MODE_ZERO
+        y = ops.conv2d_fwd(x, weight, bias, 1, pad, mode=mode)
+        ctx.geom = (pad, mode)
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        weight, bias = ctx.params
+        pad, mode = ctx.geom
+        N, Ci, H, W = x.shape
+        Co = weight.shape[0]
+        dy = dy.contiguous(memory_format=CL) if Co > 1 else dy.contiguous()
+        if weight.requires_grad:
+            db = grad_buf(bias) if bias is not None and bias.requires_grad else None
+            gw = grad_buf(weight)
+            _wgrad_async(x, dy, lambda: ops.conv2d_wgrad(x, dy, weight.shape, 1, pad, mode=mode, dw=gw, dbias=db, accumulate=True))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if mode == ops.MODE_ZERO:
+                dx = ops.conv2d_dgrad(dy, weight, (H, W), 1, pad)
+            else:
+                dxp = ops.conv2d_dgrad(dy, weight, (H + 2 * pad, W + 2 * pad), 1, 0)
+                dx = ops.empty_nhwc(N, Ci, H, W, dy.device)
+                check(lib.pd_reflect_fold_pad(ptr(dxp), ptr(dx), N, H, W, Ci, pad, stream_ptr()), "pd_reflect_fold_pad")
+        for p in (weight, bias):
+            if p is not None:
+                _ready(p)
+        return dx, None, None, None, None
+
+
+def padded_conv(x, conv, pad, reflect=True):
+    return PaddedConvFn.apply(x, conv.weight, conv.bias, int(pad), bool(reflect))
+
+
 class UpCatFn(torch.autograd.Function):
     """cat([bilinear_x2(a), skip], 1)  (layers.upsample + depth_decoder.py:64-67)."""
 

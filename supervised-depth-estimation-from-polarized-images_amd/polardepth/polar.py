@@ -128,3 +128,21 @@ def normals_from_xolp(xolp, n=1.5, precise=False):
         check(lib.pd_polar_normals_from_xolp(ptr(xolp), ptr(out), ptr(tables), tables.numel(), B, H, W,
                                              int(bool(precise)), stream_ptr()), "pd_polar_normals_from_xolp")
     return out
+
+
+def theta_from_rho(rho, n=1.5, want=("d", "s1", "s2"), want_bins=False):
+    """rho_diffuse / rho_spec of the reference on the GPU (normals_vec.py:11-50): fp32 rho of any shape -> dict of fp64
+    tensors theta_d / theta_s1 / theta_s2 of that shape (scipy interp1d 'extrapolate' semantics, evaluated in fp64 in
+    scipy's operation order) and, optionally, "bins": int32 [3, *shape] searchsorted indices."""
+    if not (isinstance(rho, torch.Tensor) and rho.is_cuda):
+        raise RuntimeError("theta_from_rho needs a CUDA(HIP) tensor; there is no CPU fallback")
+    r = rho.float().contiguous()
+    tables = _device_tables(float(n), r.device.index)
+    out = {k: torch.empty(r.shape, dtype=torch.float64, device=r.device) for k in want}
+    bins = torch.empty((3,) + tuple(r.shape), dtype=torch.int32, device=r.device) if want_bins else None
+    with torch.cuda.device(r.device):
+        check(lib.pd_polar_theta(ptr(r), ptr(out.get("d")), ptr(out.get("s1")), ptr(out.get("s2")), ptr(bins), ptr(tables),
+                                 tables.numel(), r.numel(), stream_ptr()), "pd_polar_theta")
+    if want_bins:
+        out["bins"] = bins
+    return out

@@ -50,6 +50,7 @@ def _header(blob):
     d = {k: int(v) for k, v in zip(names, h[:12])}
     d["bscale"] = np.frombuffer(blob[48:52], dtype=np.float32)[0]
     d["n_buckets"] = int(h[13])
+    d["off_ylo"] = int(h[14])
     return d
 
 
@@ -65,7 +66,7 @@ def _bucket_of(rho, bscale):
 def test_table_blob_layout_and_lut():
     blob = pdpolar.pack_tables(pdpolar.theta_tables_numpy(1.5)).numpy().tobytes()
     h = _header(blob)
-    assert h["magic"] == 0x50444c35 and (h["n_d"], h["n_s1"], h["n_s2"]) == (1000, 625, 375)
+    assert h["magic"] == 0x50444c36 and (h["n_d"], h["n_s1"], h["n_s2"]) == (1000, 625, 375)
     assert h["total_bytes"] == len(blob) and h["n_buckets"] == BUCKETS
     assert h["img_fast_bytes"] % 1024 == 0 and h["img_precise_bytes"] % 1024 == 0 and h["img_precise_bytes"] <= 160 * 1024
     lut = np.frombuffer(blob[h["off_lut"]:h["off_lut"] + LUT * 4], dtype=np.float32).reshape(511, 511)
@@ -79,6 +80,14 @@ def test_table_blob_layout_and_lut():
     np.testing.assert_array_equal(lut4[..., 1], np.cos(ref.astype(np.float64)).astype(np.float32))
     np.testing.assert_array_equal(lut4[..., 2], np.sin(ref.astype(np.float64)).astype(np.float32))
     assert not lut4[..., 3].any()
+    # y_lo of every bin (entry i = y[i-1]) behind the two LDS images: the theta outputs of pd_polar_theta
+    assert h["off_ylo"] == h["off_img_precise"] + h["img_precise_bytes"] and h["off_ylo"] + 2000 * 8 == len(blob)
+    ylo = np.frombuffer(blob[h["off_ylo"]:h["off_ylo"] + 2000 * 8], dtype=np.float64)
+    o = 0
+    for k in ("diffuse", "spec1", "spec2"):
+        y = opolar.theta_tables(1.5)[k][1]
+        np.testing.assert_array_equal(ylo[o + 1:o + len(y)], y[:-1])
+        o += len(y)
 
     # one-read search: idx_T = base_T + (key_T < rho) reproduces clip(searchsorted(x_T, rho, 'left'), 1, n_T - 1)
     # for every fp32 rho whose bucket is not flagged; flagged buckets are few and take exact binary searches
