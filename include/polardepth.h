@@ -226,10 +226,11 @@ int pd_weight_transpose_batched(const void* src, void* dst, const void* table, c
  *   = dy * (out > 0) for post-add ReLU blocks).
  */
 int pd_bn_fwd_finalize(const void* partial, long R, int C, double count, const void* gamma, const void* beta,
-                       void* running_mean, void* running_var, float momentum, float eps, void* acc_ws,
+                       void* running_mean, void* running_var, float momentum, float eps, void* acc_ws, long acc_len,
                        void* scale, void* shift, void* save_mean, void* save_invstd, int training, void* stream);
-int pd_bn_bwd_finalize(const void* partial, long R, int C, double count, void* acc_ws, void* dgamma, void* dbeta,
-                       void* coef, int accumulate, void* stream);
+/* acc_len: doubles in acc_ws, checked against 2*C + 1 (the ticket word lives at acc_ws[2*C]). */
+int pd_bn_bwd_finalize(const void* partial, long R, int C, double count, void* acc_ws, long acc_len, void* dgamma,
+                       void* dbeta, void* coef, int accumulate, void* stream);
 long pd_chain_bwd_rows(int N, int H, int W, int C);
 int pd_chain_fwd(const void* x, const void* scale, const void* shift, const void* res, void* out,
                  int N, int H, int W, int C, long ld_res, long ld_out, int relu_pre, int pool,

@@ -108,7 +108,10 @@ typedef __attribute__((address_space(3))) void lds_ptr_t;
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, const void* lds_wave_base, unsigned voff) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t*)lds_wave_base);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                 :: "s"(m0v), "v"(voff), "s"(r) : "memory");     // (m0 is reserved: nothing else in this kernel uses it)
+                 :: "s"(m0v), "v"(voff), "s"(r) : "memory");
+    // (M0 cannot be declared clobbered: the AMDGPU backend treats it as a RESERVED register -- "inline asm clobber list
+    //  contains reserved registers: m0" -- i.e. it never keeps a value in M0 across statements and rewrites M0 right in
+    //  front of each of its own uses (LDS-param / readlane / GWS), so an asm statement that overwrites it is safe.)
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -503,6 +506,9 @@ __device__ __forceinline__ unsigned magic_div(unsigned n, unsigned mg, unsigned 
 __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, unsigned m0v, unsigned voff, unsigned soff) {
     // s_nop 4: the scalar offset may have been written by the SALU instruction right in front (5 wait states to a
     // VMEM read of it); s_nop 0: M0 write -> LDS-DMA
+    // M0: reserved register of the backend, see dma16.  No "memory" clobber on purpose: the LDS rows this piece fills belong to a ring slot that
+    // no ds_read of the current chunk touches, and the s_waitcnt + barrier that publish the slot carry the clobber --
+    // with it here hipcc pins every fragment read behind the issue and the loop loses its overlap
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(m0v), "v"(voff), "s"(r), "s"(soff));
 }

@@ -798,9 +798,10 @@ inline unsigned ew_grid(long work_items) {
 // ============================================================================ C ABI
 extern "C" int pd_bn_fwd_finalize(const void* partial, long R, int C, double count, const void* gamma,
                                   const void* beta, void* running_mean, void* running_var, float momentum, float eps,
-                                  void* acc_ws, void* scale, void* shift, void* save_mean, void* save_invstd,
-                                  int training, void* stream) {
+                                  void* acc_ws, long acc_len, void* scale, void* shift, void* save_mean,
+                                  void* save_invstd, int training, void* stream) {
     PD_REQUIRE(C > 0 && scale && shift, "pd_bn_fwd_finalize: bad arguments");
+    PD_REQUIRE(!training || acc_len >= 2L * C + 1, "pd_bn_fwd_finalize: accumulator needs 2 C + 1 doubles (%ld given)", acc_len);
     PD_REQUIRE(!training || (partial && acc_ws && R > 0 && count > 0), "pd_bn_fwd_finalize: training needs partials");
     PD_REQUIRE(training || (running_mean && running_var), "pd_bn_fwd_finalize: eval needs running stats");
     hipStream_t st = (hipStream_t)stream;
@@ -825,9 +826,10 @@ extern "C" int pd_bn_fwd_finalize(const void* partial, long R, int C, double cou
     return pd::check_launch("pd_bn_fwd_finalize");
 }
 
-extern "C" int pd_bn_bwd_finalize(const void* partial, long R, int C, double count, void* acc_ws, void* dgamma,
-                                  void* dbeta, void* coef, int accumulate, void* stream) {
+extern "C" int pd_bn_bwd_finalize(const void* partial, long R, int C, double count, void* acc_ws, long acc_len,
+                                  void* dgamma, void* dbeta, void* coef, int accumulate, void* stream) {
     PD_REQUIRE(partial && acc_ws && coef && C > 0 && R > 0 && count > 0, "pd_bn_bwd_finalize: bad arguments");
+    PD_REQUIRE(acc_len >= 2L * C + 1, "pd_bn_bwd_finalize: accumulator needs 2 C + 1 doubles (%ld given)", acc_len);
     hipStream_t st = (hipStream_t)stream;
     if (R <= 4096) {
         hipLaunchKernelGGL(bn_stats_small_kernel<false>, dim3((C + 31) / 32), dim3(1024), 0, st, (const float*)partial, R, C,

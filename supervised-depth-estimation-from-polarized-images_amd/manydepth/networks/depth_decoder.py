@@ -57,4 +57,10 @@ class DepthDecoder(nn.Module):
             if i in self.scales:
                 self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act=ops.ACT_SIGMOID, head_mail=m1)
             pend = m1
+        if fuse and len(self.outputs) > 1:
+            # every head an ancestor of every output: a backward pass from a subset of the scales still runs all heads,
+            # which collect the gradients deposited for them (functional.JoinHeadsFn)
+            keys = list(self.outputs)
+            for k, d in zip(keys, PF.join_heads([self.outputs[k] for k in keys])):
+                self.outputs[k] = d
         return self.outputs

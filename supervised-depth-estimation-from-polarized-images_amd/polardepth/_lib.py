@@ -50,8 +50,8 @@ SIGNATURES = {
     "pd_stem_s2d_input": (_i, [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _f, _f, _vp]),
     "pd_stem_s2d_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "pd_stem_s2d_weight_grad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "pd_bn_fwd_finalize": (_i, [_vp, _l, _i, _dbl, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "pd_bn_bwd_finalize": (_i, [_vp, _l, _i, _dbl, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pd_bn_fwd_finalize": (_i, [_vp, _l, _i, _dbl, _vp, _vp, _vp, _vp, _f, _f, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pd_bn_bwd_finalize": (_i, [_vp, _l, _i, _dbl, _vp, _l, _vp, _vp, _vp, _i, _vp]),
     "pd_chain_bwd_rows": (_l, [_i, _i, _i, _i]),
     "pd_chain_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _i, _i, _f, _u64, _u64, _i, _vp]),
     "pd_chain_bwd_reduce": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u64,

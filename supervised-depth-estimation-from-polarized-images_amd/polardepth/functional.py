@@ -175,6 +175,46 @@ class ActGrad:
         self.expect_deposit = expect_deposit
 
 
+_DEPOSITS = []          # ActGrad mailboxes that received a data gradient in the running backward pass
+_deposit_check_queued = False
+
+
+def _check_deposits_after_backward():
+    """Autograd callback at the end of a backward pass: a deposit nobody collected means the disparity head of that tensor
+    did not take part in this pass, and everything upstream of it received no gradient -- fail loudly instead of training
+    on silent zeros.  (DepthDecoder ties its heads together with JoinHeadsFn so that this cannot happen through its
+    outputs; the check covers hand-built graphs.)"""
+    global _deposit_check_queued
+    _deposit_check_queued = False
+    left = [m for m in _DEPOSITS if m.grad is not None]
+    for m in _DEPOSITS:
+        m.grad = None
+    _DEPOSITS.clear()
+    if left:
+        raise RuntimeError("ActGrad: a convolution handed its input gradient to the disparity head of the same tensor, but "
+                           "that head did not run in this backward pass (loss over a subset of the decoder's scales on a "
+                           "hand-built graph?); the gradients upstream of it are missing.  Set PD_ACT_FUSION=0.")
+
+
+class JoinHeadsFn(torch.autograd.Function):
+    """Identity over the disparity maps of one decoder pass.  Its node makes every head an ancestor of every returned map:
+    a backward pass that starts from ANY subset of them (``outputs[("disp", 0)].sum().backward()``, a loss over fewer
+    scales than the decoder has) still runs all heads -- autograd materialises the missing output gradients as zeros --
+    so each head collects the data gradient the next level's first convolution deposited for it (ActGrad)."""
+
+    @staticmethod
+    def forward(ctx, *disps):
+        return tuple(d.view_as(d) for d in disps)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return grads
+
+
+def join_heads(disps):
+    return JoinHeadsFn.apply(*disps) if len(disps) > 1 else tuple(disps)
+
+
 USE_ACT_FUSION = os.environ.get("PD_ACT_FUSION", "1") != "0"
 USE_GT_NORMAL_CACHE = os.environ.get("PD_GT_NORMAL_CACHE", "1") != "0"
 USE_EDGE_WEIGHT_CACHE = os.environ.get("PD_EDGE_WEIGHT_CACHE", "1") != "0"   # smoothness edge weights: forward -> backward
@@ -203,12 +243,12 @@ _BN_ACC = {}
 
 
 def _bn_acc(dev, C):
-    """fp64 accumulator of the BatchNorm partial sums: zero on entry, left zero by pd_bn_{fwd,bwd}_finalize, so one
-    long-lived buffer per (device, stream) replaces a memset per layer and direction."""
+    """fp64 accumulator of the BatchNorm partial sums (2 C sums + the ticket word behind them): zero on entry, left zero by
+    pd_bn_{fwd,bwd}_finalize, so one long-lived buffer per (device, stream) replaces a memset per layer and direction."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     buf = _BN_ACC.get(key)
-    if buf is None or buf.numel() < 2 * C:
-        buf = torch.zeros(max(2 * C, 8192), dtype=torch.float64, device=dev)
+    if buf is None or buf.numel() < 2 * C + 2:
+        buf = torch.zeros(max(2 * C + 2, 8192), dtype=torch.float64, device=dev)
         _BN_ACC[key] = buf
     return buf
 
@@ -248,8 +288,8 @@ class ConvBNChainFn(torch.autograd.Function):
         acc = _bn_acc(dev, Co) if training else None
         check(lib.pd_bn_fwd_finalize(ptr(part), 0 if part is None else part.shape[0], Co, float(N * Hz * Wz),
                                      ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
-                                     bn.momentum, bn.eps, ptr(acc), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                                     int(training), stream_ptr()), "pd_bn_fwd_finalize")
+                                     bn.momentum, bn.eps, ptr(acc), 0 if acc is None else acc.numel(), ptr(scale), ptr(shift),
+                                     ptr(mean), ptr(invstd), int(training), stream_ptr()), "pd_bn_fwd_finalize")
         Ho, Wo = (Hz // 2, Wz // 2) if cfg.pool else (Hz, Wz)
         out = ops.empty_nhwc(N, Co, Ho, Wo, dev)
         ld_res = 0
@@ -275,7 +315,7 @@ class ConvBNChainFn(torch.autograd.Function):
         dev, N, Co = x.device, x.shape[0], w.shape[0]
         scale, shift = _f32(dev, Co), _f32(dev, Co)
         check(lib.pd_bn_fwd_finalize(None, 0, Co, 1.0, ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
-                                     bn.momentum, bn.eps, None, ptr(scale), ptr(shift), None, None, 0, stream_ptr()),
+                                     bn.momentum, bn.eps, None, 0, ptr(scale), ptr(shift), None, None, 0, stream_ptr()),
               "pd_bn_fwd_finalize")
         if bias is not None:
             shift = torch.addcmul(shift, bias.detach(), scale)
@@ -312,8 +352,8 @@ class ConvBNChainFn(torch.autograd.Function):
             acc = _bn_acc(dev, Co)
             dgamma = grad_buf(gamma) if gamma is not None and gamma.requires_grad else None
             dbeta = grad_buf(beta) if beta is not None and beta.requires_grad else None
-            check(lib.pd_bn_bwd_finalize(ptr(part), rows, Co, float(N * Hz * Wz), ptr(acc), ptr(dgamma), ptr(dbeta),
-                                         ptr(coef), 1, st), "pd_bn_bwd_finalize")
+            check(lib.pd_bn_bwd_finalize(ptr(part), rows, Co, float(N * Hz * Wz), ptr(acc), acc.numel(), ptr(dgamma),
+                                         ptr(dbeta), ptr(coef), 1, st), "pd_bn_bwd_finalize")
         dz = ops.empty_nhwc(N, Co, Hz, Wz, dev)
         want_dres = ctx.has_res and cfg.relu_post and ctx.needs_input_grad[5]
         dres = ops.empty_nhwc(*out.shape, dev) if want_dres else None
@@ -427,6 +467,11 @@ class ReflectConvActFn(torch.autograd.Function):
                 if dx_mail.grad is not None:
                     raise RuntimeError("ActGrad: a data gradient was deposited twice")
                 dx_mail.grad, dx = dx, None     # the disparity head of the same tensor sums and activates it
+                global _deposit_check_queued
+                _DEPOSITS.append(dx_mail)
+                if not _deposit_check_queued:
+                    torch.autograd.Variable._execution_engine.queue_callback(_check_deposits_after_backward)
+                    _deposit_check_queued = True
         for p in (weight, bias):
             if p is not None:
                 _ready(p)

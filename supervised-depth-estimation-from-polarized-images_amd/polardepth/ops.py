@@ -159,7 +159,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
     dx = empty_nhwc(N, Ci, H, W, dy.device)
     sN, sC, sH, sW = dy.stride()
     if (USE_S2_PHASES and addend is None and stride == 2 and KH == 3 and KW == 3 and pad == 1 and H == 2 * Hy and W == 2 * Wy
-            and Co % 32 == 0 and Ci % 4 == 0 and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0):
+            and Co % 32 == 0 and Ci % 4 == 0 and Ci > 16 and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0):
         # stride-2 data gradient by output parity: four stride-1 2x2 sub-filter launches + one interleave
         def _phases():
             wsub = torch.empty(9 * Ci * Co, dtype=torch.float32, device=dy.device)     # class filters 1x1, 1x2, 2x1, 2x2

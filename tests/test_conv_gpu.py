@@ -213,6 +213,27 @@ def test_stride2_data_gradient_by_output_parity(case):
     _close(dx2.cpu(), x.grad)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 12, 16, 32), (1, 8, 6, 10, 64), (2, 4, 8, 8, 32)])
+def test_stride2_data_gradient_with_few_input_channels_takes_the_general_kernel(case):
+    """Ci <= 16: the 16-wide tile has no uniform-tap kernel for the rectangular sub-filters, so the parity split must not
+    be chosen (it used to raise PD_EINVAL from pd_conv2d_rect); the masked transposed gather serves these shapes."""
+    N, C, H, W, Co = case
+    g = torch.Generator().manual_seed(sum(case) + 9)
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    ref = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    ops.PROFILE = []
+    dx = ops.conv2d_dgrad(dyd, wd, (H, W), stride=2, pad=1)
+    labels = [p[0] for p in ops.PROFILE]
+    ops.PROFILE = None
+    assert labels and labels != ["conv_dgrad_s2_phases"], labels
+    _close(dx.cpu(), x.grad)
+
+
 @pytest.mark.parametrize("geom", [(1, 2, 0, 1), (2, 1, 1, 0), (2, 3, 0, 2), (3, 1, 1, 0), (1, 1, 0, 0)])
 def test_rectangular_filter_with_separate_padding(geom):
     """pd_conv2d_rect, mode 0: KH x KW filter with its own row / column zero padding (uniform-tap kernel) against

@@ -137,6 +137,59 @@ def test_decoder_activation_gradient_handover_is_bit_exact(scales, monkeypatch):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("used", [[0], [2], [1, 3]])
+def test_backward_through_a_subset_of_the_decoder_outputs(used, monkeypatch):
+    """A decoder built with all four heads, a loss over only some of its outputs (``outputs[("disp", 0)].sum().backward()``):
+    the unused heads still run (JoinHeadsFn hands them zero gradients) and collect the data gradient the next level's first
+    convolution deposited for them -- gradients equal the plain autograd route (PD_ACT_FUSION=0) instead of silently
+    vanishing upstream of the first unused head."""
+    from manydepth import networks
+    from polardepth import functional as PF
+
+    def run(fuse):
+        monkeypatch.setattr(PF, "USE_ACT_FUSION", fuse)
+        feats = [T(G4[f"dec.feat.{i}"]).cuda().requires_grad_(True) for i in range(5)]
+        torch.manual_seed(3)
+        dd = networks.DepthDecoder(np.array([64, 64, 128, 256, 512]), range(4)).cuda()
+        res = dd(feats)
+        obj = 0
+        for s in used:
+            w = torch.randn(res[("disp", s)].shape, generator=torch.Generator().manual_seed(300 + s)).cuda()
+            obj = obj + (res[("disp", s)] * w).sum()
+        obj.backward()
+        PF.sync_wgrad_stream()
+        torch.cuda.synchronize()
+        # (levels below the shallowest used scale are outside the graph on the plain route: None there, zeros here)
+        return [torch.zeros_like(t) if t.grad is None else t.grad.clone() for t in feats + list(dd.parameters())]
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) and len(a) > 20
+    assert a[4].abs().max().item() > 0          # the deepest feature map does receive a gradient
+    for i, (x, y) in enumerate(zip(a, b)):
+        scale = y.abs().max().item()
+        assert (x - y).abs().max().item() <= 1e-6 * scale + 1e-12, f"tensor {i}: {(x - y).abs().max().item():.3e} vs {scale:.3e}"
+
+
+def test_uncollected_activation_gradient_deposit_fails_loudly(monkeypatch):
+    """A hand-built graph in which the head of a tensor never runs: the deposit is detected at the end of the backward
+    pass and raises, instead of leaving everything upstream without a gradient."""
+    from polardepth import functional as PF
+    from polardepth import ops
+    torch.manual_seed(0)
+    conv_a = torch.nn.Conv2d(32, 32, 3).cuda(); conv_b = torch.nn.Conv2d(32, 32, 3).cuda()
+    for c in (conv_a, conv_b):
+        c.weight.data = c.weight.data.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(1, 32, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    mail = PF.ActGrad(expect_deposit=True)
+    y = PF.reflect_conv_act(x, conv_a, ops.ACT_ELU, act_mail=mail)
+    z = PF.reflect_conv_act(y, conv_b, ops.ACT_ELU, dx_mail=mail)      # deposits dL/dy for a head that does not exist
+    with pytest.raises(RuntimeError, match="ActGrad"):
+        z.sum().backward()
+    PF.sync_wgrad_stream()
+    torch.cuda.synchronize()
+    assert mail.grad is None                    # the mailbox does not stay pinned
+
+
 def test_resnet_stem_matches_oracle():
     """No reference fixture possible (torchvision absent): HIP façade vs the CPU restatement."""
     from manydepth import networks

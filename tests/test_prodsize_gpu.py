@@ -159,7 +159,7 @@ def test_batchnorm_finalize_ticket_kernels(R, C):
         rm, rv = torch.from_numpy(rm0.copy()).to(dev), torch.from_numpy(rv0.copy()).to(dev)
         scale, shift, smean, sinv = (torch.empty(C, device=dev) for _ in range(4))
         check(lib.pd_bn_fwd_finalize(ptr(pd_), R, C, count, ptr(gd), ptr(bd),
-                                     ptr(rm), ptr(rv), 0.1, 1e-5, ptr(acc), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), 1,
+                                     ptr(rm), ptr(rv), 0.1, 1e-5, ptr(acc), acc.numel(), ptr(scale), ptr(shift), ptr(smean), ptr(sinv), 1,
                                      stream_ptr()), "pd_bn_fwd_finalize")
         torch.cuda.synchronize()
         np.testing.assert_allclose(smean.cpu().numpy(), mean, rtol=1e-6, atol=1e-9)
@@ -171,13 +171,18 @@ def test_batchnorm_finalize_ticket_kernels(R, C):
         assert acc.abs().max().item() == 0.0, "accumulator / ticket not left zero"
         dgamma, dbeta = torch.ones(C, device=dev), torch.ones(C, device=dev)
         coef = torch.empty(2 * C, device=dev)
-        check(lib.pd_bn_bwd_finalize(ptr(pd_), R, C, count, ptr(acc), ptr(dgamma), ptr(dbeta), ptr(coef), 1, stream_ptr()),
+        check(lib.pd_bn_bwd_finalize(ptr(pd_), R, C, count, ptr(acc), acc.numel(), ptr(dgamma), ptr(dbeta), ptr(coef), 1, stream_ptr()),
               "pd_bn_bwd_finalize")
         torch.cuda.synchronize()
         np.testing.assert_allclose(dbeta.cpu().numpy(), 1.0 + s[:, 0], rtol=1e-6, atol=1e-4)
         np.testing.assert_allclose(dgamma.cpu().numpy(), 1.0 + s[:, 1], rtol=1e-6, atol=1e-4)
         np.testing.assert_allclose(coef.cpu().numpy(), np.concatenate([s[:, 0], s[:, 1]]) / count, rtol=1e-6, atol=1e-9)
         assert acc.abs().max().item() == 0.0
+    # the accumulator length is part of the contract: one double short of the ticket word is refused
+    from polardepth._lib import PolarDepthError
+    with pytest.raises(PolarDepthError):
+        check(lib.pd_bn_bwd_finalize(ptr(pd_), R, C, count, ptr(acc), 2 * C, ptr(dgamma), ptr(dbeta), ptr(coef), 1, stream_ptr()),
+              "pd_bn_bwd_finalize")
 
 
 def test_conv_block_with_more_than_4096_stat_rows_matches_torch():
