@@ -263,6 +263,8 @@ class GradReducer:
             self.counts[self.bucket_of[id(p)]] += 1
         self.cuda = store.grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=store.grad.device) if self.cuda and self.active else None
+        self._events = {}            # (bucket, stream id) -> reusable event: the stream's position behind the bucket's last kernel
+        self._t0 = self._t1 = None   # events around finish(): the part of the exchange the step actually waits for
         self.reset()
 
     def reset(self):
@@ -270,12 +272,38 @@ class GradReducer:
         self.seen = set()
         self.launched = [False] * len(self.buckets)
         self.works = []
+        self.deps = [dict() for _ in self.buckets]      # per bucket: stream id -> event recorded behind its last producer
 
-    def mark_ready(self, p):
+    def _producer_streams(self):
+        """Streams that hold kernels writing the gradient of the parameter being marked: the stream the backward node runs
+        on (BatchNorm / bias / head gradients; autograd replays a node on its forward stream, i.e. an encoder stream for an
+        encoder layer) and the weight-gradient side stream."""
+        from . import functional as PF
+        streams = [torch.cuda.current_stream()]
+        if PF.USE_WGRAD_STREAM:
+            side = PF._WGRAD_STREAMS.get(self.store.grad.device.index)
+            if side is not None:
+                streams.append(side)
+        return streams
+
+    def mark_ready(self, p, streams=None):
+        """Called by the backward node that produced the last gradient kernel of p (after enqueueing it).  Records, per
+        producer stream, an event behind that kernel; the bucket's all-reduce waits for exactly these events -- not for
+        whole streams: an encoder stream that is still busy with layers of another bucket does not hold back a decoder
+        bucket whose kernels have finished."""
         if not self.active or id(p) in self.seen:
             return
         self.seen.add(id(p))
         b = self.bucket_of[id(p)]
+        if self.comm_stream is not None or streams is not None:
+            for st in (streams if streams is not None else self._producer_streams()):
+                key = (b, getattr(st, "cuda_stream", st))
+                ev = self._events.get(key)
+                if ev is None and self.comm_stream is not None:
+                    ev = self._events[key] = torch.cuda.Event()
+                if ev is not None:
+                    ev.record(st)
+                self.deps[b][key[1]] = ev           # a later record on the same stream supersedes the earlier one
         self.pending[b] -= 1
         if self.pending[b] == 0:
             self._launch(b)
@@ -287,9 +315,15 @@ class GradReducer:
         s, e = self.buckets[b]
         view = self.store.grad[s:e]
         if self.comm_stream is not None:
-            from . import functional as PF
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
-            PF.sync_wgrad_stream(self.comm_stream)
+            if self.pending[b] == 0:
+                for ev in self.deps[b].values():
+                    self.comm_stream.wait_event(ev)
+            else:
+                # finish() flushes a bucket with a parameter that received no gradient this step: nothing recorded for
+                # it, wait for everything enqueued so far
+                from . import functional as PF
+                self.comm_stream.wait_stream(torch.cuda.current_stream())
+                PF.sync_wgrad_stream(self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -300,8 +334,20 @@ class GradReducer:
             return
         for b in range(len(self.buckets)):       # buckets holding a parameter that got no gradient this step
             self._launch(b)
+        if self.comm_stream is not None:
+            if self._t0 is None:
+                self._t0, self._t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._t0.record()
         for w in self.works:
             w.wait()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            self._t1.record()
         self.works = []
+
+    def exposed_wait_ms(self):
+        """GPU time the last step's optimizer stream spent waiting for the exchange (after a synchronize): the part of the
+        all-reduce that backward did not hide."""
+        if self._t0 is None:
+            return 0.0
+        return float(self._t0.elapsed_time(self._t1))

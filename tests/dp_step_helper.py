@@ -40,7 +40,34 @@ def main(out_path):
         tr.model_optimizer.step()
         losses.append(L["loss"].detach().cpu())
     torch.cuda.synchronize()
-    info = {"flat": tr.store.flat.cpu(), "losses": torch.stack(losses), "distributed": tr.distributed,
+    probe = None
+    if tr.reducer is not None and tr.reducer.active and os.environ.get("PD_DP_STALL_PROBE") == "1":
+        # A busy encoder stream must not hold back a decoder bucket: bucket 0 (decoder parameters, produced on the main
+        # and weight-gradient streams) is marked ready while an encoder stream sits in a ~0.3 s kernel with one parameter
+        # of a LATER bucket marked behind it; bucket 0's all-reduce has to complete while that kernel still runs.
+        import time
+        red = tr.reducer
+        red.reset()
+        enc = tr._enc_streams[0]
+        last = tr.store.used_params()[-1]
+        assert red.bucket_of[id(last)] == len(red.buckets) - 1 and len(red.buckets) > 1
+        with torch.cuda.stream(enc):
+            torch.cuda._sleep(int(1e8))        # 50 ms at 2 GHz, 1 s if the counter ticks at 100 MHz
+            red.mark_ready(last)
+            enc_done = torch.cuda.Event(); enc_done.record()
+        for p in tr.store.used_params():
+            if red.bucket_of[id(p)] == 0:
+                red.mark_ready(p)
+        assert red.launched[0] and not red.launched[-1]
+        comm_done = torch.cuda.Event(); comm_done.record(red.comm_stream)
+        t0 = time.time()
+        while not comm_done.query() and time.time() - t0 < 5.0:
+            time.sleep(0.001)
+        probe = {"comm_done_while_encoder_busy": bool(comm_done.query() and not enc_done.query()),
+                 "bucket0_streams": len(red.deps[0]), "waited_s": time.time() - t0}
+        red.finish()
+        torch.cuda.synchronize()
+    info = {"probe": probe, "flat": tr.store.flat.cpu(), "losses": torch.stack(losses), "distributed": tr.distributed,
             "reducer_active": bool(tr.reducer is not None and tr.reducer.active),
             "buckets": 0 if tr.reducer is None else len(tr.reducer.buckets),
             "global_norm": tr.loss_cfg.global_norm}

@@ -100,10 +100,20 @@ def _worker_real_models(rank, world, port, ret):
         tail_before = store.grad[store.n_used:].clone()
         local = store.grad[:store.n_used].clone()
         fired = []
+        names = [n for n, _ in store.entries[:store.n_used_params]]
         for i, p in enumerate(store.used_params()):
-            p._pd_grad_ready()
+            # producer streams as the trainer has them: decoder / joint / ResNet layers on the main stream, the two shallow
+            # encoders on their own streams, every weight gradient on the side stream (tokens stand in for HIP streams)
+            own = {"xolp_encoder": "enc0", "normals_encoder": "enc1"}.get(names[i].split(".", 1)[0], "main")
+            red.mark_ready(p, streams=[own, "wgrad"])
             fired.append(sum(red.launched))
         assert fired[len(fired) // 3] >= 1 and fired[-1] == len(red.buckets)
+        # a bucket waits for the streams of its own parameters only: the decoder buckets never for an encoder stream
+        for b in range(len(red.buckets)):
+            models_in_b = {n.split(".", 1)[0] for n, p in store.entries[:store.n_used_params] if red.bucket_of[id(p)] == b}
+            expect = {"wgrad"} | {{"xolp_encoder": "enc0", "normals_encoder": "enc1"}.get(m, "main") for m in models_in_b}
+            assert set(red.deps[b]) == expect, (b, models_in_b, set(red.deps[b]))
+        assert set(red.deps[0]) == {"main", "wgrad"}
         red.finish()
         other = torch.randn(store.n_used, generator=torch.Generator().manual_seed(100 + (1 - rank)))
         assert torch.allclose(store.grad[:store.n_used], local + other, rtol=0, atol=1e-6)

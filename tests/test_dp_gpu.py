@@ -34,3 +34,12 @@ def test_world1_rccl_step_is_bit_equal_to_the_plain_step(tmp_path):
     assert torch.isfinite(plain["losses"]).all()
     assert torch.equal(plain["losses"], dist1["losses"]) and torch.equal(plain["flat"], dist1["flat"])
     assert torch.equal(plain["losses"], glob1["losses"]) and torch.equal(plain["flat"], glob1["flat"])
+
+
+def test_busy_encoder_stream_does_not_stall_a_decoder_bucket(tmp_path):
+    """GradReducer waits for the events recorded behind a bucket's own gradient kernels, not for whole streams: with an
+    encoder stream stuck in a long kernel, the first (decoder) bucket's RCCL all-reduce still completes."""
+    r = _run(tmp_path, "stall", PD_DIST_TEST=1, PD_DP_STALL_PROBE=1)
+    assert r["probe"] is not None
+    assert r["probe"]["comm_done_while_encoder_busy"], r["probe"]
+    assert r["probe"]["bucket0_streams"] <= 2          # main + weight-gradient stream, no encoder stream
