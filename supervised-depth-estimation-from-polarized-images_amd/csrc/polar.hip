@@ -302,7 +302,7 @@ typedef const __attribute__((address_space(1))) void global_void_t;
 // (wave-uniform LDS base + lane * 16), nothing passes through registers and all pieces of a wave are in flight
 // together (a copy loop through registers ran as a chain of L2 round trips: 7 us per launch).
 template <bool PRECISE>
-__device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char* smem, int nthreads, Tabs& t) {
+__device__ __forceinline__ void stage_tables_issue(const char* __restrict__ blob, char* smem, int nthreads, Tabs& t) {
     const PolarHeader* h = reinterpret_cast<const PolarHeader*>(blob);
     t.n_d = h->n_d; t.n_s1 = h->n_s1; t.n_s2 = h->n_s2;
     const char* src = blob + (PRECISE ? h->off_img_precise : h->off_img_fast);
@@ -317,6 +317,10 @@ __device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char
     t.bins = PRECISE ? reinterpret_cast<const double*>(smem + h->common_bytes)
                      : reinterpret_cast<const double*>(blob + h->off_img_precise + h->common_bytes);
     t.bscale = h->bscale;
+}
+template <bool PRECISE>
+__device__ __forceinline__ void stage_tables(const char* __restrict__ blob, char* smem, int nthreads, Tabs& t) {
+    stage_tables_issue<PRECISE>(blob, smem, nthreads, t);
     __syncthreads();
 }
 
@@ -564,7 +568,16 @@ struct PolarGeo {
     int drow, dcq;                 // persistent-loop step (grid * block quads) as rows + quads
     unsigned P, Pout;              // pixels per input / output plane
     int flags;
+#ifdef PD_POLAR_TRACE
+    unsigned long long* trace;     // [grid][8] 100 MHz timestamps of wave 0 (tools/k1_trace.py builds this variant)
+#endif
 };
+
+#ifdef PD_POLAR_TRACE
+#define PD_TRACE(slot) do { if (g.trace && threadIdx.x == 0) g.trace[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PD_TRACE(slot) do { } while (0)
+#endif
 
 struct QuadPos {
     int b, cq;
@@ -583,7 +596,11 @@ __device__ __forceinline__ void advance(QuadPos& q, const PolarGeo& g) {
 
 // HOT: the training step's output set (xolp + normals, nothing else) known at compile time -- no pointer tests
 // around the stores, and a store count the compiler can put into its s_waitcnt vmcnt(N).
-template <int MODE, int OUT, int NTH, bool NT, bool HOT = false>
+// LUT4: AoLP, cos, sin from the 4 MB float4 LUT (no trigonometry for phi); otherwise AoLP from the 1 MB LUT + fp32
+// polynomials.  The small LUT fits every XCD's L2 and is pulled in by a prologue prefetch -- inside the training step K1
+// starts with cold caches, and the scattered first-touch misses of the big LUT (every XCD fetches every line it needs
+// from HBM, behind K1's own write stream) stretched every iteration of the loop, not just the first.
+template <int MODE, int OUT, int NTH, bool NT, bool HOT = false, bool LUT4 = false>
 __global__ __launch_bounds__(NTH) void polar_kernel(
     const uint8_t* __restrict__ pol, const uint8_t* __restrict__ mask, float* __restrict__ xolp,
     float* __restrict__ xolp_std, float* __restrict__ normals, int* __restrict__ ints,
@@ -599,8 +616,8 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
     const bool w_xolp = HOT || xolp != nullptr, w_std = !HOT && xolp_std != nullptr;
     const bool w_normals = HOT || normals != nullptr, w_ints = !HOT && ints != nullptr;
 
-    // Software pipeline, two quads deep: while quad i is computed, the AoLP gathers of quad i+1 and the plane loads
-    // of quad i+2 are in flight.  Inside the training step the LUT is never cache-resident when K1 starts (the
+    // Software pipeline: while quad i is computed, the AoLP gathers of quad i+1 and the plane loads of quads i+2 .. i+4
+    // are in flight.  Inside the training step the LUT is never cache-resident when K1 starts (the
     // step streams gigabytes between two launches) and different image regions need different LUT lines, so a
     // wave meets HBM-latency gathers in every iteration: issued one iteration ahead they cost nothing
     // (tools/membench2.hip d, tools/k1_instep_probe.py).  Queue order per iteration: gathers(i+1), loads(i+2),
@@ -612,10 +629,11 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
         Words w = {0u, 0u, 0u, 0u};
         if (p.b < g.B && p.cq < g.wq_in) {
             const unsigned p4 = static_cast<unsigned>(p.b) * 4u * g.P + p.row * in_row + 4u * p.cq;
-            w.w0 = *reinterpret_cast<const uint32_t*>(pol + p4);
-            w.w45 = *reinterpret_cast<const uint32_t*>(pol + (p4 + g.P));
-            w.w90 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P));
-            w.w135 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P));
+            // read-once stream: nontemporal (no L2 / Infinity-Cache allocation that would push out the LUT and tables)
+            w.w0 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + p4));
+            w.w45 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + (p4 + g.P)));
+            w.w90 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P)));
+            w.w135 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P)));
         }
         return w;
     };
@@ -629,7 +647,7 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
             const float e2 = static_cast<float>((w.w45 >> sh) & 0xffu) - static_cast<float>((w.w135 >> sh) & 0xffu);
             // (d2 + 255) * 511 + (d1 + 255), exact in fp32
             const unsigned idx = static_cast<unsigned>(static_cast<int>(fmaf(e2, 511.f, e1 + 130560.f)));
-            if (FAST) { const float4 L = lut4[idx]; G.phi[j] = L.x; G.cp[j] = L.y; G.sp[j] = L.z; }
+            if (FAST && LUT4) { const float4 L = lut4[idx]; G.phi[j] = L.x; G.cp[j] = L.y; G.sp[j] = L.z; }
             else { G.phi[j] = lut[idx]; G.cp[j] = 1.f; G.sp[j] = 0.f; }
         }
         return G;
@@ -644,13 +662,46 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
         q.b = static_cast<int>(q.row / static_cast<unsigned>(g.Hrows));
         q.row -= static_cast<unsigned>(q.b) * static_cast<unsigned>(g.Hrows);
     }
+    PD_TRACE(0);
+    // Prologue order = order of the memory queue: the table image first (nothing can be computed without it), then the
+    // planes of the first two quads, the LUT prefetch, and the planes of quads three and four.
+    Tabs tabs;
+    if (NORMALS) stage_tables_issue<PRECISE>(blob, smem, NTH, tabs);
     Words wc = load_words(q);
     QuadPos qn = q;
     advance(qn, g);
     Words wn = load_words(qn);
-    Tabs tabs;
-    if (NORMALS) stage_tables<PRECISE>(blob, smem, NTH, tabs);
+    if (NORMALS && !LUT4) {
+        // L2 prefetch of the AoLP LUT: the workgroups of an XCD (blockIdx.x % 8, round-robin dispatch) share its L2; workgroup
+        // k of the XCD pulls slice k of the 1 MB table through direct-to-LDS loads into a junk slot behind the table image
+        // (1 KiB per wave; nothing reads it)
+        const unsigned lut_kib = (static_cast<unsigned>(kLutCount) * 4u + 1023u) >> 10;
+        const unsigned nslices = (gridDim.x + 7u) >> 3, slice = blockIdx.x >> 3;
+        const unsigned per = (lut_kib + nslices - 1u) / nslices;
+        const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = NTH >> 6;
+        char* junk = smem + (PRECISE ? h->img_precise_bytes : h->img_fast_bytes) + (wave << 10);
+        const char* lsrc = reinterpret_cast<const char*>(lut);
+        for (unsigned p = slice * per + wave; p < min((slice + 1u) * per, lut_kib - 1u); p += nwaves)   // (last partial KiB skipped)
+            __builtin_amdgcn_global_load_lds((global_void_t*)(lsrc + (static_cast<size_t>(p) << 10) + lane * 16),
+                                             (lds_void_t*)junk, 16, 0, 0);
+    }
+    // planes four iterations ahead: at the bench size (B = 16: five iterations per thread) every read of the kernel is
+    // requested before its first store -- a read burst, then a pure write stream (tools/membench3.hip: interleaving the
+    // reads with the stores costs 3-7 us of 50 when the inputs come from HBM, as they do inside the training step)
+    QuadPos qa = qn;
+    advance(qa, g);
+    Words wa = load_words(qa);
+    QuadPos qb = qa;
+    advance(qb, g);
+    Words wb = load_words(qb);
+    if (NORMALS) __syncthreads();
+    PD_TRACE(1);                                 // table image landed in LDS (barrier)
     Gather Gc = gather(wc);
+#ifdef PD_POLAR_TRACE
+    { float sink = Gc.phi[0] + Gc.phi[3]; asm volatile("" :: "v"(sink)); }
+    PD_TRACE(2);                                 // first planes + first LUT gathers landed
+    int it_ = 0;
+#endif
 
     while (q.b < g.B) {
         const unsigned po = q.row * out_row + 4u * q.cq;     // first output pixel of the quad inside its plane
@@ -662,7 +713,7 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
 
         const Gather Gn = gather(wn);
         __builtin_amdgcn_sched_barrier(0);
-        QuadPos qnn = qn;
+        QuadPos qnn = qb;
         advance(qnn, g);
         const Words wnn = load_words(qnn);
         __builtin_amdgcn_sched_barrier(0);
@@ -687,6 +738,7 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
             if (PRECISE && (j & 1) == 0) __builtin_amdgcn_sched_barrier(0);   // fp64 chains in pairs: register pressure
             const bool on = MODE != PD_POLAR_STOKES || ((wm >> (8 * j)) & 0xffu) != 0;
             float rho, phi = Gc.phi[j], cp = Gc.cp[j], sp = Gc.sp[j];
+            if (FAST && !LUT4) sincos_f32(phi, sp, cp);          // ~1 ulp; the 1 MB LUT supplies phi only
             if (MODE == PD_POLAR_STOKES && !on) {   // images are masked first (:117-121); outputs are zero outside
                 rho = 0.f; phi = 0.f; cp = 1.f; sp = 0.f;
                 o_i[0][j] = 0; o_i[1][j] = 0;
@@ -741,8 +793,13 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
             for (unsigned c = 0; c < 5; ++c)
                 if (c < nch) store4i<NT>(o + c * g.Pout, o_i[c][0], o_i[c][1], o_i[c][2], o_i[c][3]);
         }
-        q = qn; wc = wn; Gc = Gn; qn = qnn; wn = wnn;
+        q = qn; wc = wn; Gc = Gn; qn = qa; wn = wa; qa = qb; wa = wb; qb = qnn; wb = wnn;
+#ifdef PD_POLAR_TRACE
+        if (it_ < 3) PD_TRACE(3 + it_);          // end of iterations 0, 1, 2 (stores issued, next operands landed)
+        ++it_;
+#endif
     }
+    PD_TRACE(6);
 }
 
 // get_normals() on an existing fp32 XOLP tensor (pre_encoders.py:99-113): [B,2,H,W] -> [B,9,H,W]
@@ -840,6 +897,11 @@ bool plain_stores() {
 
 }  // namespace
 
+#ifdef PD_POLAR_TRACE
+static unsigned long long* pd_polar_trace_buffer = nullptr;
+extern "C" void pd_polar_set_trace(void* buf) { pd_polar_trace_buffer = static_cast<unsigned long long*>(buf); }
+#endif
+
 extern "C" int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tables, size_t tables_bytes,
                                           int B, int H, int W, int flags, void* stream) {
     PD_REQUIRE(B >= 0 && H > 0 && W > 0, "pd_polar_normals_from_xolp: bad shape");
@@ -910,10 +972,12 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
     const bool pitched = Wout != W;
     const bool need_normals = normals != nullptr || ints != nullptr;
     const bool precise = (flags & PD_POLAR_PRECISE_NORMALS) != 0;
-    // LDS image: 64 KB of bucket records + the keys + 16 (fast) or 32 (precise) bytes per bin
-    const size_t lds = need_normals ? img_bytes_for(nk, precise) : 0;
     const bool nt = !plain_stores();
+    static const bool lut4 = [] { const char* e = getenv("PD_POLAR_LUT4"); return e && e[0] == '1'; }();   // A/B knob: the 4 MB LUT
     const int nth = need_normals ? (precise ? kThreadsP : (nt ? fast_threads() : 512)) : kThreads;
+    // LDS image: 64 KB of bucket records + the keys + 16 (fast) or 32 (precise) bytes per bin, + 1 KiB per wave for the
+    // LUT prefetch sink
+    const size_t lds = need_normals ? img_bytes_for(nk, precise) + (size_t)(nth / 64) * 1024 : 0;
     // 32-bit addressing inside the kernel: at most 2^30 elements per output tensor and 2^31 quads per launch
     PD_REQUIRE(9 * Pout < (1L << 30), "pd_polar_fwd: image too large (%ld output pixels)", Pout);
     const long max_b = (1L << 30) / (9 * Pout);
@@ -925,6 +989,9 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
         g.B = nb; g.Hrows = pitched ? H : 1;
         g.wq_in = pitched ? W / 4 : (int)(P / 4); g.wq_out = pitched ? Wout / 4 : (int)(P / 4);
         g.P = (unsigned)P; g.Pout = (unsigned)Pout; g.flags = flags;
+#ifdef PD_POLAR_TRACE
+        g.trace = pd_polar_trace_buffer;
+#endif
         const long total = (long)nb * (Pout / 4);
         long blocks = (total + nth - 1) / nth;
         // with normals: persistent, one workgroup per CU (the table image is staged once per CU);
@@ -951,7 +1018,8 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
             else if (!nt) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, false>);
             else if (nth == 256) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 256, true>);
             else if (nth == 512) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, true>);
-            else if (xolp && normals && !xolp_std && !ints) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true>);
+            else if (xolp && normals && !xolp_std && !ints)
+                rc = lut4 ? go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, true>) : go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true>);
             else rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true>);
         } else {
             if (!need_normals) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_XOLP, kThreads, true>);

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Where do K1's microseconds go?  A -DPD_POLAR_TRACE build of csrc/polar.hip stamps, per workgroup (wave 0), the 100 MHz
+wall clock at: 0 kernel entry, 1 table image in LDS, 2 first planes + first LUT gathers landed, 3/4/5 end of loop
+iterations 0/1/2, 6 loop exit.  Reported for the bench configuration (B=16, 612 -> 640, xolp + normals) back to back
+(warm caches) and after a cache-replacing predecessor (what the training step leaves behind).
+
+    python tools/k1_trace.py            (on the GPU box; compiles the trace variant with hipcc if missing)
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "supervised-depth-estimation-from-polarized-images_amd")
+sys.path.insert(0, PKG)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+SO = os.path.join(ROOT, "tools", "bin", "libpolartrace.so")
+
+
+def build():
+    src = os.path.join(PKG, "csrc")
+    if os.path.exists(SO) and os.path.getmtime(SO) >= os.path.getmtime(os.path.join(src, "polar.hip")):
+        return
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                    "-DPD_POLAR_TRACE", "-shared", "-o", SO, os.path.join(src, "polar.hip"), os.path.join(src, "pd_common.hip")],
+                   check=True)
+
+
+def main():
+    build()
+    from polardepth import polar as pdpolar
+    from bench_polar import make_planes
+    lib = ctypes.CDLL(SO)
+    vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    lib.pd_polar_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, i, i, i, vp]
+    lib.pd_polar_set_trace.argtypes = [vp]
+    B, H, W, WO = int(os.environ.get("B", 16)), 512, 612, 640
+    pols = [make_planes(B, H, W, True, seed=s) for s in range(3)]
+    tables = pdpolar._device_tables(1.5, 0)
+    xolp = [torch.empty(B, 2, H, WO, device="cuda") for _ in range(3)]
+    nrm = [torch.empty(B, 9, H, WO, device="cuda") for _ in range(3)]
+    trace = torch.zeros(256 * 8, dtype=torch.int64, device="cuda")
+    lib.pd_polar_set_trace(vp(trace.data_ptr()))
+    big = torch.zeros(1 << 28, device="cuda")          # 1 GiB
+
+    def launch(k):
+        st = vp(torch.cuda.current_stream().cuda_stream)
+        rc = lib.pd_polar_fwd(vp(pols[k].data_ptr()), None, vp(xolp[k].data_ptr()), None, vp(nrm[k].data_ptr()), None,
+                              vp(tables.data_ptr()), tables.numel(), B, H, W, WO, 0, 0, st)
+        assert rc == 0
+
+    def run(name, pre):
+        rows = []
+        for rep in range(8):
+            pre()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); launch(rep % 3); e1.record()
+            torch.cuda.synchronize()
+            t = trace.cpu().numpy().reshape(256, 8).astype(np.float64) * 0.01       # microseconds
+            t0 = t[:, 0].min()
+            rows.append(np.concatenate([[e0.elapsed_time(e1) * 1e3], (t[:, 0] - t0).mean(keepdims=True),
+                                        [np.median(t[:, k] - t[:, 0]) for k in range(1, 7)],
+                                        [(t[:, 6] - t0).max()]]))
+        r = np.median(np.array(rows[2:]), axis=0)
+        print(f"{name:38s} event {r[0]:6.1f} us | wg start skew {r[1]:4.1f} | tables {r[2]:5.1f}  first operands {r[3]:5.1f}  "
+              f"it0 {r[4]:5.1f}  it1 {r[5]:5.1f}  it2 {r[6]:5.1f}  exit {r[7]:5.1f} | last wg exit {r[8]:5.1f}", flush=True)
+
+    # the training step's own predecessor: the fused Adam kernel over the 85 MB parameter / gradient / moment buffers
+    from polardepth._lib import lib as pdlib, check, ptr
+    n = 21_330_000
+    pbuf, gbuf, mbuf, vbuf = (torch.zeros(n, device="cuda") for _ in range(4))
+
+    def adam():
+        check(pdlib.pd_adam_step(ptr(pbuf), ptr(gbuf), ptr(mbuf), ptr(vbuf), n, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, 1,
+                                 vp(torch.cuda.current_stream().cuda_stream)), "adam")
+
+    def adam_then_idle():
+        import time
+        adam(); torch.cuda.synchronize(); time.sleep(0.002)
+
+    run("back to back", lambda: None)
+    run("after pd_adam_step (85 MB x 4)", adam)
+    run("after pd_adam_step + 2 ms idle", adam_then_idle)
+    run("after add_ on 1 GiB (plain stores)", lambda: big.add_(1.0))
+    run("after fp32 matmul 4096^3", lambda: torch.mm(big[:1 << 24].view(4096, 4096), big[1 << 24:1 << 25].view(4096, 4096)))
+    run("after zero_ of 85 MB", lambda: big[:85 * 250000].zero_())
+
+
+if __name__ == "__main__":
+    main()
