@@ -663,14 +663,21 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
         q.row -= static_cast<unsigned>(q.b) * static_cast<unsigned>(g.Hrows);
     }
     PD_TRACE(0);
-    // Prologue order = order of the memory queue: the table image first (nothing can be computed without it), then the
-    // planes of the first two quads, the LUT prefetch, and the planes of quads three and four.
-    Tabs tabs;
-    if (NORMALS) stage_tables_issue<PRECISE>(blob, smem, NTH, tabs);
+    // Prologue: every read the first iterations need is requested before anything waits -- the planes of quads 0..3 (at
+    // the bench size, B = 16, a thread has five quads: a read burst, then a pure write stream; tools/membench3.hip:
+    // interleaving reads with the stores costs 3-7 us of 50 when the inputs come from HBM, as inside the training step),
+    // the LUT prefetch, the table image.  (Requesting the table image first changed nothing: the barrier waits for all.)
     Words wc = load_words(q);
     QuadPos qn = q;
     advance(qn, g);
     Words wn = load_words(qn);
+    QuadPos qa = qn;
+    advance(qa, g);
+    Words wa = load_words(qa);
+    QuadPos qb = qa;
+    advance(qb, g);
+    Words wb = load_words(qb);
+    Tabs tabs;
     if (NORMALS && !LUT4) {
         // L2 prefetch of the AoLP LUT: the workgroups of an XCD (blockIdx.x % 8, round-robin dispatch) share its L2; workgroup
         // k of the XCD pulls slice k of the 1 MB table through direct-to-LDS loads into a junk slot behind the table image
@@ -685,16 +692,7 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
             __builtin_amdgcn_global_load_lds((global_void_t*)(lsrc + (static_cast<size_t>(p) << 10) + lane * 16),
                                              (lds_void_t*)junk, 16, 0, 0);
     }
-    // planes four iterations ahead: at the bench size (B = 16: five iterations per thread) every read of the kernel is
-    // requested before its first store -- a read burst, then a pure write stream (tools/membench3.hip: interleaving the
-    // reads with the stores costs 3-7 us of 50 when the inputs come from HBM, as they do inside the training step)
-    QuadPos qa = qn;
-    advance(qa, g);
-    Words wa = load_words(qa);
-    QuadPos qb = qa;
-    advance(qb, g);
-    Words wb = load_words(qb);
-    if (NORMALS) __syncthreads();
+    if (NORMALS) stage_tables<PRECISE>(blob, smem, NTH, tabs);
     PD_TRACE(1);                                 // table image landed in LDS (barrier)
     Gather Gc = gather(wc);
 #ifdef PD_POLAR_TRACE
