@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_graph", action="store_true",
+                    help="time the eager step only (default on one GPU: the step is also captured into a hipGraph and "
+                         "`value` is the faster of the two; both are reported)")
     ap.add_argument("--attention", action="store_true",
                     help="BASELINE configs[4] variant (single-head attention at the joint-encoder merge, fp32); "
                          "not the headline workload")
@@ -204,26 +207,68 @@ def main():
     batch[("pol", 0, 0)] = batch[("pol", 0, 0)][..., :FRAME_W].contiguous()      # true 512x612 planes for K1
     batch.pop("depth_gt"); batch.pop(("mask", 0, 0))
 
-    t_host = None
-    for i in range(args.warmup):
-        if i == args.warmup - 1:                  # host cost of enqueueing one step into an empty queue (informational)
+    def timed_loop(step_fn):
+        """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; also the host time
+        of enqueueing one step into an empty queue."""
+        t_host = None
+        for i in range(args.warmup):
+            if i == args.warmup - 1:
+                torch.cuda.synchronize()
+                t_h0 = time.perf_counter()
+            step_fn()
+            if i == args.warmup - 1:
+                t_host = time.perf_counter() - t_h0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step_fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, t_host, loss
+
+    dt, t_host, loss = timed_loop(lambda: train_step(tr, batch))
+    eager = {"images_per_s": round(args.batch * args.steps / dt, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
+             "host_enqueue_ms_per_step": None if t_host is None else round(t_host * 1e3, 2), "final_loss": round(float(loss.detach()), 6)}
+    graph_info = None
+    if world == 1 and not dist.is_initialized() and not args.no_graph:
+        # the same step replayed from a hipGraph (polardepth/graph.py).  A second trainer with the same seed, so that both
+        # loops run the same number of steps from the same initial weights: final_loss must agree bit for bit.
+        try:
+            from polardepth.graph import GraphedTrainStep
+            PF.DropoutState.manual_seed(1234 + rank)
+            tr_g = build_trainer(args.batch, H, W, log_dir)
+            tr_g.set_train()
+            t_c0 = time.perf_counter()
+            gstep = GraphedTrainStep(tr_g, batch, warmup=3)
             torch.cuda.synchronize()
+            t_capture = time.perf_counter() - t_c0
+            # the eager loop ran warmup + steps steps before its final loss; the graphed trainer has run its 3 eager warm-up
+            # steps (the capture itself executes nothing)
+            extra = args.warmup - 3
+            for _ in range(max(extra, 0)):
+                gstep.step()
+            saved_warmup, args.warmup = args.warmup, 0
+            dt_g, _, loss_g = timed_loop(lambda: gstep.step())
+            args.warmup = saved_warmup
+            torch.cuda.synchronize()
+            loss_g_val = float(loss_g.detach())      # (the loss tensor is a static buffer of the graph: read it before the next replay)
             t_h0 = time.perf_counter()
-        train_step(tr, batch)
-        if i == args.warmup - 1:
-            t_host = time.perf_counter() - t_h0
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(tr, batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+            gstep.step()
+            t_host_g = time.perf_counter() - t_h0
+            torch.cuda.synchronize()
+            graph_info = {"images_per_s": round(args.batch * args.steps / dt_g, 3), "ms_per_step": round(dt_g / args.steps * 1e3, 3),
+                          "host_enqueue_ms_per_step": round(t_host_g * 1e3, 3), "final_loss": round(loss_g_val, 6),
+                          "capture_s": round(t_capture, 2),
+                          "final_loss_equals_eager": bool(extra >= 0 and loss_g_val == float(loss.detach()))}
+            if dt_g < dt:
+                dt, t_host = dt_g, t_host_g
+        except Exception as exc:           # the bench line must not depend on the capture
+            graph_info = {"error": f"{type(exc).__name__}: {exc}"[:400]}
     dp_info = None
     if dist.is_initialized():
         # per-rank view for diagnosing a scaling run: every rank's own loop time (before the MAX) and the part of the last
@@ -375,6 +420,8 @@ def main():
                    "global_batch": args.batch * world, "height": H, "width": W, "frame_width": FRAME_W,
                    "parallelism": f"dp{world}"},
         "final_loss": round(loss_val, 6), "host_enqueue_ms_per_step": None if t_host is None else round(t_host * 1e3, 2),
+        "step_launch": "hipGraph replay" if (graph_info and "error" not in graph_info and graph_info["ms_per_step"] <= eager["ms_per_step"]) else "eager",
+        "eager": eager, "graph": graph_info,
         "roofline": roofline, "xolp_kernel": xolp_kernel,
     }
     if dp_info is not None:

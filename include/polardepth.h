@@ -234,15 +234,16 @@ int pd_bn_bwd_finalize(const void* partial, long R, int C, double count, void* a
 long pd_chain_bwd_rows(int N, int H, int W, int C);
 int pd_chain_fwd(const void* x, const void* scale, const void* shift, const void* res, void* out,
                  int N, int H, int W, int C, long ld_res, long ld_out, int relu_pre, int pool,
-                 float drop_p, uint64_t seed, uint64_t offset, int relu_post, void* stream);
+                 float drop_p, uint64_t seed, uint64_t offset, const void* step_state, int relu_post, void* stream);
 int pd_chain_bwd_reduce(const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
                         const void* scale, const void* shift, const void* mean, const void* invstd,
                         void* partial, int N, int H, int W, int C, int relu_pre, int pool, float drop_p,
-                        uint64_t seed, uint64_t offset, int relu_post, void* stream);
+                        uint64_t seed, uint64_t offset, const void* step_state, int relu_post, void* stream);
 int pd_chain_bwd_apply(const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
                        const void* scale, const void* shift, const void* mean, const void* invstd,
                        const void* coef, void* dx, void* dres, int N, int H, int W, int C, int relu_pre,
-                       int pool, float drop_p, uint64_t seed, uint64_t offset, int relu_post, void* stream);
+                       int pool, float drop_p, uint64_t seed, uint64_t offset, const void* step_state, int relu_post,
+                       void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) of the ResNet stem (resnet_encoder.py:814) and its gradient. */
 /* idx (optional in fwd): uint8 [N,Ho,Wo,C] window position (dh*3+dw) of the first maximum, consumed by bwd. */
@@ -272,9 +273,16 @@ int pd_reflect_dgrad_border(const void* dz, long ldd, const void* w, void* dx, i
                             void* stream);
 /* torch.optim.Adam step (trainer.py:238,442) over one flat fp32 buffer; grads are pre-multiplied
  * by grad_scale (1/world_size after the RCCL sum).  zero_grad != 0 also clears g in the same pass
- * (trainer.py:436 zero_grad of the NEXT iteration, without a separate 85 MB memset). */
+ * (trainer.py:436 zero_grad of the NEXT iteration, without a separate 85 MB memset).
+ * step_state (optional): the step counters below; Adam's t is then read from step_state[1] on the device instead of
+ * `step`, so that a hipGraph of the training step can be replayed with frozen arguments.  Bias corrections use beta^t
+ * by repeated squaring in double on either side (identical bits). */
 int pd_adam_step(void* p, void* g, void* m, void* v, long n, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, long step, float grad_scale, int zero_grad, void* stream);
+                 float weight_decay, long step, const void* step_state, float grad_scale, int zero_grad, void* stream);
+/* Step counters in device memory, int64[4]: [0] training steps begun -- the dropout sites of pd_chain_* add
+ * step_state[0] << 12 to their Philox offset (step_state NULL: the offset argument alone) --, [1] optimizer steps.
+ * pd_step_tick increments the selected counters (one thread); the only per-step state of a captured training step. */
+int pd_step_tick(void* step_state, int bump_dropout, int bump_adam, void* stream);
 
 /* ------------------------------------------------------------------------- K5
  * Multi-scale supervised loss (trainer.py:1126-1150,1241-1265,1298-1309; layers.py:62-71,452-465).

@@ -38,6 +38,12 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 
 // keep-mask scaled by 1/(1-p) for the 4 channels of output element quad `q`
+// Philox offset of a dropout site: the call's own index (kernel argument) + 4096 x the training-step counter kept in
+// device memory, so that a captured hipGraph of the step draws fresh masks on every replay with frozen arguments
+__device__ __forceinline__ uint64_t site_offset(uint64_t offset, const long long* step_state) {
+    return step_state ? offset + ((uint64_t)step_state[0] << 12) : offset;
+}
+
 __device__ __forceinline__ float4 dropout_scale(long q, uint64_t seed, uint64_t offset, float p) {
     const uint4 r = philox4x32_10(make_uint4((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)offset,
                                              (uint32_t)(offset >> 32)),
@@ -228,6 +234,7 @@ struct ChainArgs {
     int relu_pre, pool, relu_post;
     float drop_p;
     uint64_t seed, offset;
+    const long long* step_state;   // device step counters (pd_step_tick) or null: offset += step_state[0] << 12
     // backward only
     const float* dy;       // grad of out, row stride ld_dy
     long ld_dy;
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(EW_T) void chain_fwd_kernel(const ChainArgs a) {
             v = affine4(ld4(a.x + (size_t)pix * a.C + c4), s, b);
             if (a.relu_pre) v = relu4(v);
         }
-        if (a.drop_p > 0.f) v = mul4(v, dropout_scale(i, a.seed, a.offset, a.drop_p));
+        if (a.drop_p > 0.f) v = mul4(v, dropout_scale(i, a.seed, site_offset(a.offset, a.step_state), a.drop_p));
         if (a.res) v = add4(v, ld4(a.res + (size_t)pix * a.ld_res + c4));
         if (a.relu_post) v = relu4(v);
         st4_nt(a.out + (size_t)pix * a.ld_out + c4, v);
@@ -300,7 +307,7 @@ __device__ __forceinline__ float4 chain_grad(const ChainArgs& a, unsigned n, uns
         g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
     }
     if (g_post) *g_post = g;            // gradient behind the post-add ReLU = gradient of the residual input
-    if (a.drop_p > 0.f) g = mul4(g, dropout_scale(opix * (a.C >> 2) + (c4 >> 2), a.seed, a.offset, a.drop_p));
+    if (a.drop_p > 0.f) g = mul4(g, dropout_scale(opix * (a.C >> 2) + (c4 >> 2), a.seed, site_offset(a.offset, a.step_state), a.drop_p));
     float4 z = affine4(xv, s, b);
     if (a.pool) {
         // route to the first maximum of the 2x2 window (scan order), like torch max_pool2d
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(EW_T) void chain_bwd_kernel(const ChainArgs a) {
                 const float4 o = ld4(a.out + (size_t)opix * a.ld_out + c4);
                 g = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
             }
-            if (a.drop_p > 0.f) g = mul4(g, dropout_scale(i, a.seed, a.offset, a.drop_p));
+            if (a.drop_p > 0.f) g = mul4(g, dropout_scale(i, a.seed, site_offset(a.offset, a.step_state), a.drop_p));
             // first maximum of the window in scan order, like torch max_pool2d
             int ax = 0, ay = 0, az = 0, aw = 0;
             float mx = v[0].x, my = v[0].y, mz = v[0].z, mw = v[0].w;
@@ -755,11 +762,31 @@ __global__ __launch_bounds__(EW_T) void reflect_dgrad_border_flat_kernel(const f
 // before the next step's kernels have streamed gigabytes -- left dirty in the caches, the kernel that follows
 // (K1 of the next step) pays for their write-back (measured: 50 -> 87 us, tools/k1_instep_probe.py).
 
+// beta^t by repeated squaring in double: the same IEEE operations on the host (step passed by value) and on the device
+// (step read from the step-state words), so that a captured step and an eager step update bit-identically
+__host__ __device__ inline double ipow(double b, long t) {
+    double r = 1.0;
+    while (t > 0) { if (t & 1) r *= b; b *= b; t >>= 1; }
+    return r;
+}
+
+// step_state = int64[4] in device memory: [0] training steps begun (dropout epoch), [1] optimizer steps (Adam's t)
+__global__ void step_tick_kernel(long long* __restrict__ st, int bump_dropout, int bump_adam) {
+    if (bump_dropout) st[0] += 1;
+    if (bump_adam) st[1] += 1;
+}
+
 template <bool ZERO_G>
 __global__ __launch_bounds__(EW_T) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt, float grad_scale) {
+                                                    float bc2_sqrt, float grad_scale,
+                                                    const long long* __restrict__ step_state) {
+    if (step_state) {       // step count in device memory (captured step): the bias corrections of pd_adam_step's host branch
+        const long t = (long)step_state[1];
+        bc1 = (float)(1.0 - ipow((double)beta1, t));
+        bc2_sqrt = sqrtf((float)(1.0 - ipow((double)beta2, t)));
+    }
     for (long i = (blockIdx.x * (long)EW_T + threadIdx.x) * 4; i < n; i += (long)gridDim.x * EW_T * 4) {
         if (i + 3 < n) {
             float4 pp = ld4(p + i), gg = ld4(g + i), mm = ld4(m + i), vv = ld4(v + i);
@@ -865,7 +892,8 @@ extern "C" long pd_chain_bwd_rows(int N, int H, int W, int C) {
 
 extern "C" int pd_chain_fwd(const void* x, const void* scale, const void* shift, const void* res, void* out,
                             int N, int H, int W, int C, long ld_res, long ld_out, int relu_pre, int pool,
-                            float drop_p, uint64_t seed, uint64_t offset, int relu_post, void* stream) {
+                            float drop_p, uint64_t seed, uint64_t offset, const void* step_state, int relu_post,
+                            void* stream) {
     int rc = chain_check(N, H, W, C, pool);
     if (rc) return rc;
     PD_REQUIRE(x && out && (!scale || shift), "pd_chain_fwd: null tensor");
@@ -876,6 +904,7 @@ extern "C" int pd_chain_fwd(const void* x, const void* scale, const void* shift,
     a.x = (const float*)x; a.scale = (const float*)scale; a.shift = (const float*)shift; a.res = (const float*)res;
     a.out = (float*)out; a.ld_res = ld_res; a.ld_out = ld_out; a.N = N; a.H = H; a.W = W; a.C = C;
     a.relu_pre = relu_pre; a.pool = pool; a.relu_post = relu_post; a.drop_p = drop_p; a.seed = seed; a.offset = offset;
+    a.step_state = (const long long*)step_state;
     const long items = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / 4);
     hipLaunchKernelGGL(chain_fwd_kernel, dim3(ew_grid(items)), dim3(EW_T), 0, (hipStream_t)stream, a);
     return pd::check_launch("pd_chain_fwd");
@@ -884,7 +913,7 @@ extern "C" int pd_chain_fwd(const void* x, const void* scale, const void* shift,
 static int chain_bwd_common(ChainArgs& a, const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
                             const void* scale, const void* shift, const void* mean, const void* invstd, int N, int H,
                             int W, int C, int relu_pre, int pool, float drop_p, uint64_t seed, uint64_t offset,
-                            int relu_post) {
+                            const void* step_state, int relu_post) {
     int rc = chain_check(N, H, W, C, pool);
     if (rc) return rc;
     PD_REQUIRE(dy && x && (!relu_post || out) && (!scale || shift) && (!mean || invstd), "pd_chain_bwd: null tensor");
@@ -892,17 +921,17 @@ static int chain_bwd_common(ChainArgs& a, const void* dy, long ld_dy, const void
     a.dy = (const float*)dy; a.ld_dy = ld_dy; a.x = (const float*)x; a.out = (float*)out; a.ld_out = ld_out;
     a.scale = (const float*)scale; a.shift = (const float*)shift; a.mean = (const float*)mean; a.invstd = (const float*)invstd;
     a.N = N; a.H = H; a.W = W; a.C = C; a.relu_pre = relu_pre; a.pool = pool; a.relu_post = relu_post;
-    a.drop_p = drop_p; a.seed = seed; a.offset = offset;
+    a.drop_p = drop_p; a.seed = seed; a.offset = offset; a.step_state = (const long long*)step_state;
     return PD_OK;
 }
 
 extern "C" int pd_chain_bwd_reduce(const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
                                    const void* scale, const void* shift, const void* mean, const void* invstd,
                                    void* partial, int N, int H, int W, int C, int relu_pre, int pool, float drop_p,
-                                   uint64_t seed, uint64_t offset, int relu_post, void* stream) {
+                                   uint64_t seed, uint64_t offset, const void* step_state, int relu_post, void* stream) {
     ChainArgs a{};
     int rc = chain_bwd_common(a, dy, ld_dy, x, out, ld_out, scale, shift, mean, invstd, N, H, W, C, relu_pre, pool,
-                              drop_p, seed, offset, relu_post);
+                              drop_p, seed, offset, step_state, relu_post);
     if (rc) return rc;
     PD_REQUIRE(partial && mean, "pd_chain_bwd_reduce: partial and mean/invstd are required");
     PD_REQUIRE(EW_T % (C / 4) == 0, "pd_chain_bwd_reduce: C/4 must divide 256");
@@ -916,10 +945,11 @@ extern "C" int pd_chain_bwd_reduce(const void* dy, long ld_dy, const void* x, co
 extern "C" int pd_chain_bwd_apply(const void* dy, long ld_dy, const void* x, const void* out, long ld_out,
                                   const void* scale, const void* shift, const void* mean, const void* invstd,
                                   const void* coef, void* dx, void* dres, int N, int H, int W, int C, int relu_pre,
-                                  int pool, float drop_p, uint64_t seed, uint64_t offset, int relu_post, void* stream) {
+                                  int pool, float drop_p, uint64_t seed, uint64_t offset, const void* step_state,
+                                  int relu_post, void* stream) {
     ChainArgs a{};
     int rc = chain_bwd_common(a, dy, ld_dy, x, out, ld_out, scale, shift, mean, invstd, N, H, W, C, relu_pre, pool,
-                              drop_p, seed, offset, relu_post);
+                              drop_p, seed, offset, step_state, relu_post);
     if (rc) return rc;
     PD_REQUIRE(dx && (!mean || coef), "pd_chain_bwd_apply: dx (and coef with batch statistics) required");
     PD_REQUIRE(!dres || relu_post, "pd_chain_bwd_apply: dres is only produced for post-add ReLU blocks");
@@ -1015,19 +1045,30 @@ extern "C" int pd_reflect_dgrad_border(const void* dz, long ldd, const void* w, 
     return pd::check_launch("pd_reflect_dgrad_border");
 }
 
+extern "C" int pd_step_tick(void* step_state, int bump_dropout, int bump_adam, void* stream) {
+    PD_REQUIRE(step_state, "pd_step_tick: null state");
+    hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)step_state, bump_dropout, bump_adam);
+    return pd::check_launch("pd_step_tick");
+}
+
 extern "C" int pd_adam_step(void* p, void* g, void* m, void* v, long n, float lr, float beta1, float beta2,
-                            float eps, float weight_decay, long step, float grad_scale, int zero_grad, void* stream) {
-    PD_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "pd_adam_step: bad arguments");
+                            float eps, float weight_decay, long step, const void* step_state, float grad_scale,
+                            int zero_grad, void* stream) {
+    PD_REQUIRE(p && g && m && v && n >= 0 && (step >= 1 || step_state), "pd_adam_step: bad arguments");
     PD_REQUIRE(pd::aligned16(p) && pd::aligned16(g) && pd::aligned16(m) && pd::aligned16(v), "pd_adam_step: unaligned");
     if (n == 0) return PD_OK;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
+    float bc1 = 0.f, bc2s = 0.f;
+    if (!step_state) {
+        bc1 = (float)(1.0 - ipow((double)beta1, step));
+        bc2s = sqrtf((float)(1.0 - ipow((double)beta2, step)));
+    }
+    const long long* ss = (const long long*)step_state;
     if (zero_grad)
         hipLaunchKernelGGL(adam_kernel<true>, dim3(ew_grid((n + 3) / 4)), dim3(EW_T), 0, (hipStream_t)stream, (float*)p,
-                           (float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+                           (float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, ss);
     else
         hipLaunchKernelGGL(adam_kernel<false>, dim3(ew_grid((n + 3) / 4)), dim3(EW_T), 0, (hipStream_t)stream, (float*)p,
-                           (float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+                           (float*)g, (float*)m, (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, ss);
     return pd::check_launch("pd_adam_step");
 }
 

@@ -34,6 +34,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -870,11 +872,19 @@ inline int nk_from_blob_bytes(size_t tables_bytes) {
     return 0;
 }
 
+// (once per kernel and size: the attribute call is not allowed while a stream is being captured into a hipGraph)
 template <typename K>
 int set_lds_limit(K kernel, size_t lds) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (lds <= 64 * 1024) return PD_OK;
+    static std::mutex mu;
+    static std::map<const void*, size_t> done;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= lds) return PD_OK;
+    if (hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return pd::fail(PD_ELAUNCH, "pd_polar: cannot reserve %zu bytes of LDS", lds);
+    done[key] = lds;
     return PD_OK;
 }
 

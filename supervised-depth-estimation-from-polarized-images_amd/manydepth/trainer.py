@@ -496,7 +496,8 @@ class Trainer:
             # checkpoint is marked incomplete and resumes inside the same epoch.
             _save({"epoch": self.epoch, "step": self.step, "epoch_complete": bool(epoch_complete),
                    "batch_idx": int(batch_idx), "lr_scheduler": self.model_lr_scheduler.state_dict(),
-                   "dropout_seed": PF.DropoutState.seed, "dropout_offset": PF.DropoutState.offset}, "trainer_state.pth")
+                   "dropout_seed": PF.DropoutState.seed,
+                   "dropout_step": PF.DropoutState.get_step(getattr(self, "device", None))}, "trainer_state.pth")
         if self.distributed:
             torch.distributed.barrier()
 
@@ -536,4 +537,5 @@ class Trainer:
                 self.resume_epoch, self.resume_step = int(st["epoch"]), int(st["step"]) + 1
                 self.resume_batch = int(st.get("batch_idx", -1)) + 1
             self.model_lr_scheduler.load_state_dict(st["lr_scheduler"])
-            PF.DropoutState.seed, PF.DropoutState.offset = int(st["dropout_seed"]), int(st["dropout_offset"])
+            PF.DropoutState.seed = int(st["dropout_seed"])
+            PF.DropoutState.set_step(getattr(self, "device", None), int(st.get("dropout_step", 0)))

@@ -53,11 +53,11 @@ SIGNATURES = {
     "pd_bn_fwd_finalize": (_i, [_vp, _l, _i, _dbl, _vp, _vp, _vp, _vp, _f, _f, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp]),
     "pd_bn_bwd_finalize": (_i, [_vp, _l, _i, _dbl, _vp, _l, _vp, _vp, _vp, _i, _vp]),
     "pd_chain_bwd_rows": (_l, [_i, _i, _i, _i]),
-    "pd_chain_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _i, _i, _f, _u64, _u64, _i, _vp]),
+    "pd_chain_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _i, _i, _f, _u64, _u64, _vp, _i, _vp]),
     "pd_chain_bwd_reduce": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u64,
-                                 _u64, _i, _vp]),
+                                 _u64, _vp, _i, _vp]),
     "pd_chain_bwd_apply": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f,
-                                _u64, _u64, _i, _vp]),
+                                _u64, _u64, _vp, _i, _vp]),
     "pd_maxpool3s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_maxpool3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_upcat_fwd": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -67,7 +67,8 @@ SIGNATURES = {
     "pd_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_reflect_fold_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pd_reflect_dgrad_border": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "pd_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _i, _vp]),
+    "pd_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _vp, _f, _i, _vp]),
+    "pd_step_tick": (_i, [_vp, _i, _i, _vp]),
     "pd_loss_rows": (_i, [_l]),
     "pd_disp_to_depth": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "pd_up_gather_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -141,11 +141,22 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(store.flat)
         self.step_count = 0
         self.grad_scale = 1.0
+        self.device_step = False     # graph mode: Adam's t lives in device memory (functional.DropoutState.state()[1])
+
+    def use_device_step(self, on=True):
+        """Keep Adam's step count in device memory (incremented by pd_step_tick in front of the update) so that step() has
+        no per-step kernel argument and can be replayed from a hipGraph.  Same bits as the host-side count."""
+        from . import functional as PF
+        self.device_step = bool(on)
+        if on:
+            PF.DropoutState.state(self.store.flat.device)[1] = self.step_count
 
     def zero_grad(self, set_to_none=False):
         from . import functional as PF
         PF.sync_wgrad_stream()
         self.store.zero_grad()
+        if self.store.flat.is_cuda:
+            PF.DropoutState.begin_step(self.store.flat.device)       # a training step begins: fresh dropout masks
         if self.reducer is not None:
             self.reducer.reset()
 
@@ -159,9 +170,13 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count += 1
         n = self.store.n_used
         b1, b2 = g["betas"]
+        state = None
+        if self.device_step:
+            state = PF.DropoutState.state(self.store.flat.device)
+            check(lib.pd_step_tick(ptr(state), 0, 1, stream_ptr()), "pd_step_tick")
         check(lib.pd_adam_step(ptr(self.store.flat), ptr(self.store.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n,
                                float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
-                               self.step_count, float(self.grad_scale), int(self.zero_grad_in_step), stream_ptr()),
+                               self.step_count, ptr(state), float(self.grad_scale), int(self.zero_grad_in_step), stream_ptr()),
               "pd_adam_step")
         self.store.weights_changed()           # (raw-pointer write: the transposed copies are stale)
         if self.zero_grad_in_step:

@@ -19,18 +19,55 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 # ------------------------------------------------------------------ dropout RNG stream (Philox)
 class DropoutState:
-    """(seed, offset) pairs for the Philox4x32-10 dropout masks; one offset per call site and step."""
+    """Philox4x32-10 stream of the dropout masks: (seed, offset) with offset = site + 4096 * step, where ``site`` numbers
+    the dropout call sites since the step began (host side, a kernel argument) and ``step`` counts the training steps in
+    DEVICE memory (``state(device)[0]``, incremented by pd_step_tick when the optimizer's zero_grad opens a step).  Nothing
+    per-step is a kernel argument, so a captured hipGraph of the step draws fresh masks on every replay; the eager path
+    uses the same scheme and therefore the same masks.  state(device)[1] is Adam's step count (FusedAdam, graph mode)."""
     seed = 0x5EEDC0DE
-    offset = 0
+    site = 0
+    _state = {}
+
+    @classmethod
+    def state(cls, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = cls._state.get(idx)
+        if st is None:
+            st = cls._state[idx] = torch.zeros(4, dtype=torch.int64, device=torch.device("cuda", idx))
+        return st
 
     @classmethod
     def manual_seed(cls, seed):
-        cls.seed, cls.offset = int(seed) & (2 ** 63 - 1), 0
+        cls.seed, cls.site = int(seed) & (2 ** 63 - 1), 0
+        for st in cls._state.values():
+            st[0] = 0
+
+    @classmethod
+    def get_step(cls, device=None):
+        """Training steps begun so far (host copy of the device counter: synchronises; checkpoints only)."""
+        if device is None or not torch.cuda.is_available():
+            return 0
+        return int(cls.state(device)[0].item())
+
+    @classmethod
+    def set_step(cls, device, step):
+        if device is not None and torch.cuda.is_available():
+            cls.state(device)[0] = int(step)
+
+    @classmethod
+    def begin_step(cls, device):
+        """A training step begins (FusedAdam.zero_grad): site numbering restarts, the device step counter advances."""
+        cls.site = 0
+        with torch.cuda.device(device):
+            check(lib.pd_step_tick(ptr(cls.state(device)), 1, 0, stream_ptr()), "pd_step_tick")
 
     @classmethod
     def next(cls):
-        cls.offset += 1
-        return cls.seed, cls.offset
+        cls.site += 1
+        if cls.site >= 4096:
+            raise RuntimeError("more than 4095 dropout sites since the last optimizer.zero_grad(): the Philox offsets of "
+                               "consecutive steps would overlap")
+        return cls.seed, cls.site
 
 
 # ------------------------------------------------------------------ side stream for weight gradients
@@ -299,7 +336,8 @@ class ConvBNChainFn(torch.autograd.Function):
         if drop > 0:
             cfg.seed, cfg.offset = DropoutState.next()
         check(lib.pd_chain_fwd(ptr(z), ptr(scale), ptr(shift), ptr(res), ptr(out), N, Hz, Wz, Co, ld_res, Co,
-                               int(cfg.relu_pre), int(cfg.pool), drop, cfg.seed, cfg.offset, int(cfg.relu_post),
+                               int(cfg.relu_pre), int(cfg.pool), drop, cfg.seed, cfg.offset,
+                               ptr(DropoutState.state(dev)) if drop > 0 else None, int(cfg.relu_post),
                                stream_ptr()), "pd_chain_fwd")
         ctx.cfg, ctx.drop, ctx.training, ctx.has_res = cfg, drop, training, res is not None
         ctx.params = (weight, bias, gamma, beta)
@@ -330,7 +368,7 @@ class ConvBNChainFn(torch.autograd.Function):
         if res is not None:
             res, ld_res = nhwc_view(res)
         check(lib.pd_chain_fwd(ptr(y), None, None, ptr(res), ptr(out), N, Hz, Wz, Co, ld_res, Co, 0, int(cfg.pool), 0.0,
-                               0, 0, int(cfg.relu_post), stream_ptr()), "pd_chain_fwd")
+                               0, 0, None, int(cfg.relu_post), stream_ptr()), "pd_chain_fwd")
         return out
 
     @staticmethod
@@ -343,12 +381,14 @@ class ConvBNChainFn(torch.autograd.Function):
         dy, ld_dy = nhwc_view(dy)
         st = stream_ptr()
         mean_p, invstd_p, coef = (mean, invstd, _f32(dev, 2 * Co)) if ctx.training else (None, None, None)
+        step_state = ptr(DropoutState.state(dev)) if ctx.drop > 0 else None
         if ctx.training:
             rows = lib.pd_chain_bwd_rows(N, Hz, Wz, Co)
             part = _f32(dev, rows, Co, 2)
             check(lib.pd_chain_bwd_reduce(ptr(dy), ld_dy, ptr(z), ptr(out), Co, ptr(scale), ptr(shift), ptr(mean),
                                           ptr(invstd), ptr(part), N, Hz, Wz, Co, int(cfg.relu_pre), int(cfg.pool),
-                                          ctx.drop, cfg.seed, cfg.offset, int(cfg.relu_post), st), "pd_chain_bwd_reduce")
+                                          ctx.drop, cfg.seed, cfg.offset, step_state, int(cfg.relu_post), st),
+                  "pd_chain_bwd_reduce")
             acc = _bn_acc(dev, Co)
             dgamma = grad_buf(gamma) if gamma is not None and gamma.requires_grad else None
             dbeta = grad_buf(beta) if beta is not None and beta.requires_grad else None
@@ -359,7 +399,7 @@ class ConvBNChainFn(torch.autograd.Function):
         dres = ops.empty_nhwc(*out.shape, dev) if want_dres else None
         check(lib.pd_chain_bwd_apply(ptr(dy), ld_dy, ptr(z), ptr(out), Co, ptr(scale), ptr(shift), ptr(mean_p),
                                      ptr(invstd_p), ptr(coef), ptr(dz), ptr(dres), N, Hz, Wz, Co, int(cfg.relu_pre),
-                                     int(cfg.pool), ctx.drop, cfg.seed, cfg.offset, int(cfg.relu_post), st),
+                                     int(cfg.pool), ctx.drop, cfg.seed, cfg.offset, step_state, int(cfg.relu_post), st),
               "pd_chain_bwd_apply")
         if ctx.has_res and not cfg.relu_post and ctx.needs_input_grad[5]:
             dres = dy                     # out = f(x) + res: the residual gradient is dy itself

@@ -1,0 +1,85 @@
+"""The training step as a hipGraph (polardepth/graph.py) against the eager step: same weights, same batches, same dropout
+seed -> bit-identical parameters, Adam moments and losses after several steps (dropout 0.1 active: the masks come from the
+device-side step counter in both modes), and a host cost per step that no longer scales with the ~550 launches."""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(tmp_path, tag):
+    from test_step_gpu import _opts
+    from manydepth.trainer import Trainer
+    torch.manual_seed(0)
+    return Trainer(_opts(tmp_path / tag, ["--dropout_rate", "0.1"]))
+
+
+def test_graphed_step_is_bit_identical_to_the_eager_step(tmp_path):
+    from polardepth import functional as PF
+    from polardepth import synthetic
+    from polardepth.graph import GraphedTrainStep
+    batches = [synthetic.make_batch(2, 64, 96, frame_w=92, device="cuda", seed=s) for s in range(7)]
+
+    PF.DropoutState.manual_seed(99)
+    tr_e = _trainer(tmp_path, "eager")
+    tr_e.set_train()
+    losses_e = []
+    for b in batches:
+        tr_e.model_optimizer.zero_grad()
+        _, L, _ = tr_e.process_batch(dict(b), is_train=True)
+        L["loss"].backward()
+        tr_e.model_optimizer.step()
+        losses_e.append(L["loss"].detach().clone())
+    torch.cuda.synchronize()
+
+    PF.DropoutState.manual_seed(99)
+    tr_g = _trainer(tmp_path, "graph")
+    assert torch.equal(tr_g.store.flat, _trainer(tmp_path, "init").store.flat)
+    # three eager steps, then capture and replay the rest
+    losses_g = []
+    gs = None
+    for i, b in enumerate(batches):
+        if i < 3:
+            tr_g.set_train()
+            tr_g.model_optimizer.zero_grad()
+            _, L, _ = tr_g.process_batch(dict(b), is_train=True)
+            L["loss"].backward()
+            tr_g.model_optimizer.step()
+            losses_g.append(L["loss"].detach().clone())
+        else:
+            if gs is None:
+                # capture with warmup=1 on a scratch copy of the state: the warm-up step must not advance the real state
+                flat, m, v = tr_g.store.flat.clone(), tr_g.model_optimizer.exp_avg.clone(), tr_g.model_optimizer.exp_avg_sq.clone()
+                bn = [t.clone() for mod in tr_g.models.values() for t in mod.buffers()]
+                st = PF.DropoutState.state(tr_g.device).clone()
+                count = tr_g.model_optimizer.step_count
+                gs = GraphedTrainStep(tr_g, b, warmup=1)
+                tr_g.store.flat.copy_(flat); tr_g.model_optimizer.exp_avg.copy_(m); tr_g.model_optimizer.exp_avg_sq.copy_(v)
+                for t, s in zip([t for mod in tr_g.models.values() for t in mod.buffers()], bn):
+                    t.copy_(s)
+                tr_g.model_optimizer.step_count = count
+                PF.DropoutState.state(tr_g.device).copy_(st)
+                PF.DropoutState.state(tr_g.device)[1] = count
+                tr_g.store.grad.zero_()
+            losses_g.append(gs.step(b).detach().clone())
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(losses_e, losses_g)):
+        assert torch.equal(a, b), f"loss of step {i}: eager {a.item()!r} graph {b.item()!r}"
+    assert torch.equal(tr_e.store.flat, tr_g.store.flat)
+    assert torch.equal(tr_e.model_optimizer.exp_avg, tr_g.model_optimizer.exp_avg)
+    assert torch.equal(tr_e.model_optimizer.exp_avg_sq, tr_g.model_optimizer.exp_avg_sq)
+    assert tr_e.model_optimizer.step_count == tr_g.model_optimizer.step_count == len(batches)
+    for (n1, b1), (n2, b2) in zip(tr_e.models["joint_encoder"].named_buffers(), tr_g.models["joint_encoder"].named_buffers()):
+        assert torch.equal(b1, b2), n1
+    # dropout masks do change from replay to replay (the step counter in device memory advances)
+    assert len({round(x.item(), 7) for x in losses_g[3:]}) > 1
+
+    # host cost of one replay: a few hundred microseconds, not the ~10 ms of 550 Python launches
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gs.step()
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    assert host < 2e-3, f"replay took {host * 1e3:.2f} ms of host time"

@@ -36,15 +36,15 @@ def run(N, H, W, C, pool, drop=0.1, sets=3, iters=12):
         return sorted(a.elapsed_time(b) for a, b in ev)[iters // 2]
     nin, nout = N * H * W * C * 4, N * Ho * Wo * C * 4
     t = timeit(lambda i: check(lib.pd_chain_fwd(ptr(xs[i]), ptr(scale), ptr(shift), None, ptr(outs[i]), N, H, W, C, 0, C, 1,
-                                                int(pool), drop, 1, 2, 0, st), "fwd"))
+                                                int(pool), drop, 1, 2, None, 0, st), "fwd"))
     res["fwd"] = (t, (nin + nout) / t / 1e6)
     t = timeit(lambda i: check(lib.pd_chain_bwd_reduce(ptr(dys[i]), C, ptr(xs[i]), ptr(outs[i]), C, ptr(scale), ptr(shift),
                                                        ptr(mean), ptr(invstd), ptr(part), N, H, W, C, 1, int(pool), drop, 1, 2,
-                                                       0, st), "reduce"))
+                                                       None, 0, st), "reduce"))
     res["bwd_reduce"] = (t, (nin + nout) / t / 1e6)
     t = timeit(lambda i: check(lib.pd_chain_bwd_apply(ptr(dys[i]), C, ptr(xs[i]), ptr(outs[i]), C, ptr(scale), ptr(shift),
                                                       ptr(mean), ptr(invstd), ptr(coef), ptr(dxs[i]), None, N, H, W, C, 1,
-                                                      int(pool), drop, 1, 2, 0, st), "apply"))
+                                                      int(pool), drop, 1, 2, None, 0, st), "apply"))
     res["bwd_apply"] = (t, (2 * nin + nout) / t / 1e6)
     print(json.dumps({"shape": [N, H, W, C], "pool": pool,
                       **{k: {"ms": round(v[0], 4), "GBps": round(v[1])} for k, v in res.items()}}), flush=True)

@@ -76,7 +76,7 @@ def main():
     pbuf, gbuf, mbuf, vbuf = (torch.zeros(n, device="cuda") for _ in range(4))
 
     def adam():
-        check(pdlib.pd_adam_step(ptr(pbuf), ptr(gbuf), ptr(mbuf), ptr(vbuf), n, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, 1,
+        check(pdlib.pd_adam_step(ptr(pbuf), ptr(gbuf), ptr(mbuf), ptr(vbuf), n, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1, None, 1.0, 1,
                                  vp(torch.cuda.current_stream().cuda_stream)), "adam")
 
     def adam_then_idle():
