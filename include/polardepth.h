@@ -309,6 +309,23 @@ int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, const void*
  * floats; the ratio is formed on the device from an ordered fp64 sum of the partials. */
 int pd_normals_loss_masked(const void* pred, const void* gt, const void* K, const void* mask, void* partial_ws, void* out,
                            int N, int H, int W, void* stream);
+/* The loop over scales of trainer.py:1134-1265 in one call: the per-scale kernels above dispatched by blockIdx.y = scale
+ * with each scale's own grid (identical partial sums, hence identical bits), the supervised forward pass reading the
+ * ground truth once for all scales: 4 launches forward, 4 + a memset backward, whatever S <= 8.
+ * Arrays of S device pointers (host arrays): disps [N,1,hs,ws], colors [N,3,hs,ws], depths [N,1,H,W] (out), means [N] (out),
+ * edge_ws [N,hs,ws,2] (out, entries may be NULL); sup_part [S][part_stride][3], sm_part [S][part_stride][2] floats with
+ * part_stride >= pd_loss_rows(N*H*W); then pd_loss_finalize as before.
+ * Backward: wts [S][3] (pd_loss_weights), sums [S][5]; workspaces gup_ws S*N*H*W floats, g_ws sum_s N*hs*ws floats,
+ * gd_acc S*N doubles; gdisps [N,1,hs,ws] (out) = d loss / d disp_s. */
+int pd_multiscale_loss_fwd(const void* const* disps, const void* const* colors, const int* hs, const int* ws, int S,
+                           const void* gt, const void* K, const void* gt_normals, void* const* depths, void* const* means,
+                           void* const* edge_ws, void* sup_part, void* sm_part, int part_stride, int N, int H, int W,
+                           float min_depth, float max_depth, int with_normals, void* stream);
+int pd_multiscale_loss_bwd(const void* const* disps, const void* const* colors, const void* const* depths,
+                           const void* const* means, const void* const* edge_ws, const int* hs, const int* ws, int S,
+                           const void* gt, const void* K, const void* gt_normals, const void* wts, const void* sums,
+                           void* gup_ws, void* g_ws, void* gd_acc, void* const* gdisps, int N, int H, int W,
+                           float min_depth, float max_depth, void* stream);
 /* pd_sup_loss_bwd: ab_ws ([N,H,W,6] floats) is only read by the two-pass form (PD_SUP_BWD_TWO_PASS=1, kept for A/B runs);
  * by default one kernel evaluates the per-pixel normal gradients for the halo of an 8 x 64 tile into LDS and gathers
  * from there, so ab_ws may be NULL. */

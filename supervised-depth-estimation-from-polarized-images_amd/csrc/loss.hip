@@ -12,6 +12,7 @@
 // All sums are reduced per wavefront (shuffles), then per workgroup, written as fp32 partials and
 // finished in fp64 by a one-block kernel -- no float atomics, run-to-run deterministic.
 #include "pd_common.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -65,12 +66,12 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
 }
 
 // ------------------------------------------------------------------ disp -> full-res depth
-__global__ __launch_bounds__(LT) void disp_to_depth_kernel(const float* __restrict__ disp, float* __restrict__ depth,
-                                                           float* __restrict__ updisp, int N, int hs, int ws, int H,
-                                                           int W, float min_disp, float max_disp) {
+__device__ __forceinline__ void disp_to_depth_body(const float* __restrict__ disp, float* __restrict__ depth,
+                                                   float* __restrict__ updisp, int N, int hs, int ws, int H,
+                                                   int W, float min_disp, float max_disp, unsigned bid, unsigned nb) {
     const long total = (long)N * H * W;
     const float sh = (float)hs / H, sw = (float)ws / W;
-    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+    for (long i = bid * (long)LT + threadIdx.x; i < total; i += (long)nb * LT) {
         int x, y;
         const long t = divmod(i, W, x);
         const long n = divmod(t, H, y);
@@ -85,6 +86,11 @@ __global__ __launch_bounds__(LT) void disp_to_depth_kernel(const float* __restri
         depth[i] = 1.f / scaled;
         if (updisp) updisp[i] = up;
     }
+}
+__global__ __launch_bounds__(LT) void disp_to_depth_kernel(const float* __restrict__ disp, float* __restrict__ depth,
+                                                           float* __restrict__ updisp, int N, int hs, int ws, int H,
+                                                           int W, float min_disp, float max_disp) {
+    disp_to_depth_body(disp, depth, updisp, N, hs, ws, H, W, min_disp, max_disp, blockIdx.x, gridDim.x);
 }
 
 // d(disp_s) = bilinear^T( g_up ), gather form: every low-res pixel sums its footprint
@@ -121,11 +127,12 @@ __global__ __launch_bounds__(LT) void up_gather_bwd_kernel(const float* __restri
 // evaluated once (same expressions, hence the same bits) and the 3F x 3F footprint is unrolled; the generic kernel
 // re-derived both source indices for every element of the footprint (~25 instructions per element).
 template <int F>
-__global__ __launch_bounds__(LT) void up_gather_bwd_f_kernel(const float* __restrict__ gup, float* __restrict__ gdisp,
-                                                             int N, int hs, int ws, int H, int W, int accumulate) {
+__device__ __forceinline__ void up_gather_bwd_f_body(const float* __restrict__ gup, float* __restrict__ gdisp,
+                                                     int N, int hs, int ws, int H, int W, int accumulate, unsigned bid,
+                                                     unsigned nb) {
     const long total = (long)N * hs * ws;
     const float sh = (float)hs / H, sw = (float)ws / W;
-    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+    for (long i = bid * (long)LT + threadIdx.x; i < total; i += (long)nb * LT) {
         int xs, ys;
         const long t = divmod(i, ws, xs);
         const long n = divmod(t, hs, ys);
@@ -154,6 +161,11 @@ __global__ __launch_bounds__(LT) void up_gather_bwd_f_kernel(const float* __rest
         }
         gdisp[i] = accumulate ? gdisp[i] + acc : acc;
     }
+}
+template <int F>
+__global__ __launch_bounds__(LT) void up_gather_bwd_f_kernel(const float* __restrict__ gup, float* __restrict__ gdisp,
+                                                             int N, int hs, int ws, int H, int W, int accumulate) {
+    up_gather_bwd_f_body<F>(gup, gdisp, N, hs, ws, H, W, accumulate, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------ supervised depth + normals terms
@@ -400,16 +412,16 @@ __global__ __launch_bounds__(LT) void sup_bwd_b_kernel(const float* __restrict__
 // (1.29x the evaluations) and gathers from there -- the [N,H,W,6] intermediate (126 MB written and re-read per scale)
 // never reaches memory.  Same per-pixel arithmetic and summation order as the two-pass form.
 constexpr int SB_TR = 8, SB_TW = 64, SB_HR = SB_TR + 2, SB_HC = SB_TW + 2, SB_HP = SB_HR * SB_HC;
-__global__ __launch_bounds__(LT) void sup_bwd_fused_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                           const float* __restrict__ K, const float4* __restrict__ gtn,
-                                                           const float* __restrict__ wts, const double* __restrict__ sums,
-                                                           float* __restrict__ gout, int N, int H, int W, float min_d,
-                                                           float max_d, float disp_range, int to_disp, int tiles_h,
-                                                           int tiles_w, int ntiles) {
-    __shared__ float abl[6][SB_HP];
+__device__ __forceinline__ void sup_bwd_fused_body(float (&abl)[6][SB_HP], const float* __restrict__ pred,
+                                                   const float* __restrict__ gt,
+                                                   const float* __restrict__ K, const float4* __restrict__ gtn,
+                                                   const float* __restrict__ wts, const double* __restrict__ sums,
+                                                   float* __restrict__ gout, int N, int H, int W, float min_d,
+                                                   float max_d, float disp_range, int to_disp, int tiles_h,
+                                                   int tiles_w, int ntiles, unsigned bid, unsigned nb) {
     const float wln = (float)((double)wts[1] / sums[2]);
     const float wl1 = (float)((double)wts[0] / sums[2]);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = (int)bid; tile < ntiles; tile += (int)nb) {
         const int tw = tile % tiles_w, th = (tile / tiles_w) % tiles_h;
         const long n = tile / (tiles_w * tiles_h);
         const int h0 = th * SB_TR, w0 = tw * SB_TW;
@@ -454,11 +466,21 @@ __global__ __launch_bounds__(LT) void sup_bwd_fused_kernel(const float* __restri
         }
     }
 }
+__global__ __launch_bounds__(LT) void sup_bwd_fused_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                           const float* __restrict__ K, const float4* __restrict__ gtn,
+                                                           const float* __restrict__ wts, const double* __restrict__ sums,
+                                                           float* __restrict__ gout, int N, int H, int W, float min_d,
+                                                           float max_d, float disp_range, int to_disp, int tiles_h,
+                                                           int tiles_w, int ntiles) {
+    __shared__ float abl[6][SB_HP];
+    sup_bwd_fused_body(abl, pred, gt, K, gtn, wts, sums, gout, N, H, W, min_d, max_d, disp_range, to_disp, tiles_h, tiles_w,
+                       ntiles, blockIdx.x, gridDim.x);
+}
 
 // ------------------------------------------------------------------ edge-aware smoothness
-__global__ __launch_bounds__(1024) void image_mean_kernel(const float* __restrict__ disp, float* __restrict__ mean, int P) {
-    __shared__ double sm[16];
-    const float* d = disp + (long)blockIdx.x * P;
+__device__ __forceinline__ void image_mean_body(double (&sm)[16], const float* __restrict__ disp, float* __restrict__ mean,
+                                                int P, unsigned img) {
+    const float* d = disp + (long)img * P;
     // four independent fp64 chains over 16-byte loads (one chain of scalar loads was latency-bound: 32 us per launch)
     const int P4 = ((P & 3) == 0 && (((size_t)d) & 15) == 0) ? P >> 2 : 0;
     const float4* d4 = reinterpret_cast<const float4*>(d);
@@ -476,8 +498,12 @@ __global__ __launch_bounds__(1024) void image_mean_kernel(const float* __restric
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < 16; ++i) t += sm[i];
-        mean[blockIdx.x] = (float)(t / P);
+        mean[img] = (float)(t / P);
     }
+}
+__global__ __launch_bounds__(1024) void image_mean_kernel(const float* __restrict__ disp, float* __restrict__ mean, int P) {
+    __shared__ double sm[16];
+    image_mean_body(sm, disp, mean, P, blockIdx.x);
 }
 
 __device__ __forceinline__ float color_grad(const float* __restrict__ img, long base, long plane, long a, long b) {
@@ -489,13 +515,12 @@ __device__ __forceinline__ float color_grad(const float* __restrict__ img, long 
 // partial[block][2] = (sum_x |dx norm| e^{-|dx I|}, sum_y ...)
 // edge_w (optional) [N,h,w,2] receives e^{-|dx I|}, e^{-|dy I|} of every pixel (0 on the last column / row): they depend
 // on the image only and the backward pass needs each of them twice
-__global__ __launch_bounds__(LT) void smooth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ img,
-                                                        const float* __restrict__ mean, float* __restrict__ partial,
-                                                        float2* __restrict__ edge_w, int N, int h, int w) {
-    __shared__ float sm[4 * 2];
+__device__ __forceinline__ void smooth_fwd_body(float* sm, const float* __restrict__ disp, const float* __restrict__ img,
+                                                const float* __restrict__ mean, float* __restrict__ partial,
+                                                float2* __restrict__ edge_w, int N, int h, int w, unsigned bid, unsigned nb) {
     const long P = (long)h * w, total = N * P;
     float acc[2] = {0.f, 0.f};
-    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+    for (long i = bid * (long)LT + threadIdx.x; i < total; i += (long)nb * LT) {
         int x, y;
         const long t = divmod(i, w, x);
         const long n = divmod(t, h, y);
@@ -508,23 +533,29 @@ __global__ __launch_bounds__(LT) void smooth_fwd_kernel(const float* __restrict_
         if (edge_w) edge_w[i] = make_float2(ex, ey);
     }
     block_sum<2>(acc, sm);
-    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = acc[0]; partial[blockIdx.x * 2 + 1] = acc[1]; }
+    if (threadIdx.x == 0) { partial[bid * 2] = acc[0]; partial[bid * 2 + 1] = acc[1]; }
+}
+__global__ __launch_bounds__(LT) void smooth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ img,
+                                                        const float* __restrict__ mean, float* __restrict__ partial,
+                                                        float2* __restrict__ edge_w, int N, int h, int w) {
+    __shared__ float sm[4 * 2];
+    smooth_fwd_body(sm, disp, img, mean, partial, edge_w, N, h, w, blockIdx.x, gridDim.x);
 }
 
 // G = d smooth / d norm (already times the scale weight); gd_acc[n] += sum_i G_i * disp_i
-__global__ __launch_bounds__(LT) void smooth_bwd_g_kernel(const float* __restrict__ disp, const float* __restrict__ img,
-                                                          const float* __restrict__ mean, const float* __restrict__ wts,
-                                                          const float2* __restrict__ edge_w,
-                                                          float* __restrict__ G, double* __restrict__ gd_acc, int N,
-                                                          int h, int w) {
+__device__ __forceinline__ void smooth_bwd_g_body(double (&smd)[4], const float* __restrict__ disp,
+                                                  const float* __restrict__ img,
+                                                  const float* __restrict__ mean, const float* __restrict__ wts,
+                                                  const float2* __restrict__ edge_w,
+                                                  float* __restrict__ G, double* __restrict__ gd_acc, int N,
+                                                  int h, int w, unsigned bid, unsigned nb) {
     const long P = (long)h * w, total = N * P;
     const float wx = wts[2] / (float)((double)N * h * (w - 1)), wy = wts[2] / (float)((double)N * (h - 1) * w);
-    __shared__ double smd[4];
     // A workgroup walks a CONTIGUOUS range of pixels and keeps the running sum of the image it is in: one fp64 atomic per
     // workgroup and image.  (One atomic per 256 pixels -- 20 000 on 16 addresses at scale 0 -- serialised in the L2:
     // 0.2 ms of a kernel whose loads take 0.03.)
-    const long chunk = ((total + gridDim.x - 1) / gridDim.x + LT - 1) / LT * LT;
-    const long beg = blockIdx.x * chunk, end = min(beg + chunk, total);
+    const long chunk = ((total + nb - 1) / nb + LT - 1) / LT * LT;
+    const long beg = bid * chunk, end = min(beg + chunk, total);
     double run = 0.0;
     long run_n = -1;
     auto flush = [&]() {                       // block-uniform
@@ -575,17 +606,151 @@ __global__ __launch_bounds__(LT) void smooth_bwd_g_kernel(const float* __restric
     }
     flush();
 }
+__global__ __launch_bounds__(LT) void smooth_bwd_g_kernel(const float* __restrict__ disp, const float* __restrict__ img,
+                                                          const float* __restrict__ mean, const float* __restrict__ wts,
+                                                          const float2* __restrict__ edge_w,
+                                                          float* __restrict__ G, double* __restrict__ gd_acc, int N,
+                                                          int h, int w) {
+    __shared__ double smd[4];
+    smooth_bwd_g_body(smd, disp, img, mean, wts, edge_w, G, gd_acc, N, h, w, blockIdx.x, gridDim.x);
+}
 
-__global__ __launch_bounds__(LT) void smooth_bwd_final_kernel(const float* __restrict__ G, const float* __restrict__ mean,
-                                                              const double* __restrict__ gd_acc, float* __restrict__ gdisp,
-                                                              int N, long P, int accumulate) {
+__device__ __forceinline__ void smooth_bwd_final_body(const float* __restrict__ G, const float* __restrict__ mean,
+                                                      const double* __restrict__ gd_acc, float* __restrict__ gdisp,
+                                                      int N, long P, int accumulate, unsigned bid, unsigned nb) {
     const long total = N * P;
-    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+    for (long i = bid * (long)LT + threadIdx.x; i < total; i += (long)nb * LT) {
         const long n = i / P;
         const float me = mean[n] + 1e-7f;
         const float v = G[i] / me - (float)(gd_acc[n] / ((double)me * me * (double)P));
         gdisp[i] = accumulate ? gdisp[i] + v : v;
     }
+}
+__global__ __launch_bounds__(LT) void smooth_bwd_final_kernel(const float* __restrict__ G, const float* __restrict__ mean,
+                                                              const double* __restrict__ gd_acc, float* __restrict__ gdisp,
+                                                              int N, long P, int accumulate) {
+    smooth_bwd_final_body(G, mean, gd_acc, gdisp, N, P, accumulate, blockIdx.x, gridDim.x);
+}
+
+// ------------------------------------------------------------------ all scales in one launch
+// The per-scale kernels above, dispatched by blockIdx.y = scale with the SAME per-scale grid (blocks beyond a scale's own
+// grid leave at once), so every partial sum, atomic and rounding is the one the single-scale launches produce: the
+// multi-scale loss is 6 launches forward (gt normals, depths, supervised terms, image means, smoothness, finalise) and
+// 6 backward instead of 18 + 21.  The supervised forward kernel additionally reads gt / gt normals once for all scales.
+struct MsArgs {
+    int S, N, H, W;
+    const float* disp[8]; const float* color[8];
+    float* depth[8]; float* mean[8]; float2* edge[8];
+    float* gdisp[8]; float* gws[8]; float* gup[8];
+    int hs[8], ws[8];
+    unsigned nb_full, nb_s[8];          // blocks of a full-resolution / a scale-resolution launch
+};
+
+__global__ __launch_bounds__(LT) void ms_disp_to_depth_kernel(const MsArgs a, float min_disp, float max_disp) {
+    const int s = blockIdx.y;
+    disp_to_depth_body(a.disp[s], a.depth[s], nullptr, a.N, a.hs[s], a.ws[s], a.H, a.W, min_disp, max_disp, blockIdx.x, gridDim.x);
+}
+
+// partial[s][block][3]: the sums of sup_fwd_kernel for every scale, one pass over the pixels
+__global__ __launch_bounds__(LT) void ms_sup_fwd_kernel(const MsArgs a, const float* __restrict__ gt, const float* __restrict__ K,
+                                                        const float4* __restrict__ gtn, float* __restrict__ partial,
+                                                        int part_stride, float min_d, float max_d, int with_normals) {
+    __shared__ float sm[4 * 3];
+    const int N = a.N, H = a.H, W = a.W;
+    const long total = (long)N * H * W;
+    float acc[8][3];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { acc[s][0] = 0.f; acc[s][1] = 0.f; acc[s][2] = 0.f; }
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        int x, y;
+        const long t = divmod(i, W, x);
+        const long n = divmod(t, H, y);
+        const float g = gt[i];
+        if (!(g >= min_d && g <= max_d)) continue;
+        V3 ng{0, 0, 0};
+        float n1 = 1.f;
+        Cam c{};
+        if (with_normals) {
+            c = load_cam(K, n);
+            if (gtn) { const float4 q = gtn[i]; ng = V3{q.x, q.y, q.z}; }
+            else { V3 A, B; float nv; sobel_xyz(gt + n * H * W, H, W, x, y, c, A, B); ng = normalize12(cross(A, B), nv); }
+            n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s >= a.S) break;
+            const float* pred = a.depth[s];
+            acc[s][0] += fabsf(g - pred[i]);
+            acc[s][2] += 1.f;
+            if (with_normals) {
+                V3 A, B; float nv;
+                sobel_xyz(pred + n * H * W, H, W, x, y, c, A, B);
+                const V3 np_ = normalize12(cross(A, B), nv);
+                const float n2 = fmaxf(sqrtf(dot(np_, np_)), 1e-8f);
+                const float cs = (ng.x / n1) * (np_.x / n2) + (ng.y / n1) * (np_.y / n2) + (ng.z / n1) * (np_.z / n2);
+                acc[s][1] += 2.f - cs;
+            }
+        }
+    }
+    for (int s = 0; s < a.S; ++s) {
+        float v[3] = {acc[s][0], acc[s][1], acc[s][2]};
+        __syncthreads();
+        block_sum<3>(v, sm);
+        if (threadIdx.x == 0) {
+            float* p = partial + ((long)s * part_stride + blockIdx.x) * 3;
+            p[0] = v[0]; p[1] = v[1]; p[2] = v[2];
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void ms_image_mean_kernel(const MsArgs a) {
+    __shared__ double sm[16];
+    const int s = blockIdx.y;
+    image_mean_body(sm, a.disp[s], a.mean[s], a.hs[s] * a.ws[s], blockIdx.x);
+}
+
+__global__ __launch_bounds__(LT) void ms_smooth_fwd_kernel(const MsArgs a, float* __restrict__ partial, int part_stride) {
+    __shared__ float sm[4 * 2];
+    const int s = blockIdx.y;
+    if (blockIdx.x >= a.nb_s[s]) return;
+    smooth_fwd_body(sm, a.disp[s], a.color[s], a.mean[s], partial + (long)s * part_stride * 2, a.edge[s], a.N, a.hs[s], a.ws[s],
+                    blockIdx.x, a.nb_s[s]);
+}
+
+__global__ __launch_bounds__(LT) void ms_sup_bwd_kernel(const MsArgs a, const float* __restrict__ gt, const float* __restrict__ K,
+                                                        const float4* __restrict__ gtn, const float* __restrict__ wts,
+                                                        const double* __restrict__ sums, float min_d, float max_d,
+                                                        float disp_range, int tiles_h, int tiles_w, int ntiles) {
+    __shared__ float abl[6][SB_HP];
+    const int s = blockIdx.y;
+    sup_bwd_fused_body(abl, a.depth[s], gt, K, gtn, wts + 3 * s, sums + 5 * s, a.gup[s], a.N, a.H, a.W, min_d, max_d, disp_range, 1,
+                       tiles_h, tiles_w, ntiles, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(LT) void ms_up_gather_bwd_kernel(const MsArgs a) {
+    const int s = blockIdx.y;
+    if (blockIdx.x >= a.nb_s[s]) return;
+    const int f = a.H / a.hs[s];
+    if (f == 1) up_gather_bwd_f_body<1>(a.gup[s], a.gdisp[s], a.N, a.hs[s], a.ws[s], a.H, a.W, 0, blockIdx.x, a.nb_s[s]);
+    else if (f == 2) up_gather_bwd_f_body<2>(a.gup[s], a.gdisp[s], a.N, a.hs[s], a.ws[s], a.H, a.W, 0, blockIdx.x, a.nb_s[s]);
+    else if (f == 4) up_gather_bwd_f_body<4>(a.gup[s], a.gdisp[s], a.N, a.hs[s], a.ws[s], a.H, a.W, 0, blockIdx.x, a.nb_s[s]);
+    else up_gather_bwd_f_body<8>(a.gup[s], a.gdisp[s], a.N, a.hs[s], a.ws[s], a.H, a.W, 0, blockIdx.x, a.nb_s[s]);
+}
+
+__global__ __launch_bounds__(LT) void ms_smooth_bwd_g_kernel(const MsArgs a, const float* __restrict__ wts,
+                                                             double* __restrict__ gd_acc) {
+    __shared__ double smd[4];
+    const int s = blockIdx.y;
+    if (blockIdx.x >= a.nb_s[s]) return;
+    smooth_bwd_g_body(smd, a.disp[s], a.color[s], a.mean[s], wts + 3 * s, a.edge[s], a.gws[s], gd_acc + (long)s * a.N, a.N,
+                      a.hs[s], a.ws[s], blockIdx.x, a.nb_s[s]);
+}
+
+__global__ __launch_bounds__(LT) void ms_smooth_bwd_final_kernel(const MsArgs a, const double* __restrict__ gd_acc) {
+    const int s = blockIdx.y;
+    if (blockIdx.x >= a.nb_s[s]) return;
+    smooth_bwd_final_body(a.gws[s], a.mean[s], gd_acc + (long)s * a.N, a.gdisp[s], a.N, (long)a.hs[s] * a.ws[s], 1, blockIdx.x,
+                          a.nb_s[s]);
 }
 
 // ------------------------------------------------------------------ scalar bookkeeping
@@ -790,6 +955,81 @@ extern "C" int pd_smooth_bwd(const void* disp, const void* img, const void* mean
     hipLaunchKernelGGL(smooth_bwd_final_kernel, dim3(grid), dim3(LT), 0, st, (const float*)g_ws, (const float*)mean,
                        (const double*)gd_acc, (float*)gdisp, N, (long)h * w, accumulate);
     return pd::check_launch("pd_smooth_bwd");
+}
+
+// ---- all scales per launch (trainer.py:1134-1265 loop over scales)
+static int ms_fill(MsArgs& a, const void* const* disps, const void* const* colors, void* const* depths, void* const* means,
+                   void* const* edge_ws, const int* hs, const int* ws, int S, int N, int H, int W) {
+    PD_REQUIRE(S > 0 && S <= 8 && N > 0 && H > 0 && W > 0 && disps && depths && hs && ws, "pd_multiscale_loss: bad arguments");
+    a = MsArgs{};
+    a.S = S; a.N = N; a.H = H; a.W = W;
+    a.nb_full = lgrid((long)N * H * W);
+    for (int s = 0; s < S; ++s) {
+        PD_REQUIRE(disps[s] && depths[s] && hs[s] > 1 && ws[s] > 1 && H % hs[s] == 0 && W % ws[s] == 0 && H / hs[s] == W / ws[s] &&
+                       (H / hs[s] == 1 || H / hs[s] == 2 || H / hs[s] == 4 || H / hs[s] == 8),
+                   "pd_multiscale_loss: scale %d: the full size must be 1, 2, 4 or 8 times the scale size", s);
+        a.disp[s] = (const float*)disps[s]; a.color[s] = colors ? (const float*)colors[s] : nullptr;
+        a.depth[s] = (float*)depths[s]; a.mean[s] = means ? (float*)means[s] : nullptr;
+        a.edge[s] = edge_ws ? (float2*)edge_ws[s] : nullptr;
+        a.hs[s] = hs[s]; a.ws[s] = ws[s];
+        a.nb_s[s] = lgrid((long)N * hs[s] * ws[s]);
+    }
+    return PD_OK;
+}
+
+extern "C" int pd_multiscale_loss_fwd(const void* const* disps, const void* const* colors, const int* hs, const int* ws, int S,
+                                      const void* gt, const void* K, const void* gt_normals, void* const* depths,
+                                      void* const* means, void* const* edge_ws, void* sup_part, void* sm_part, int part_stride,
+                                      int N, int H, int W, float min_depth, float max_depth, int with_normals, void* stream) {
+    MsArgs a;
+    int rc = ms_fill(a, disps, colors, depths, means, edge_ws, hs, ws, S, N, H, W);
+    if (rc) return rc;
+    PD_REQUIRE(colors && means && gt && (K || !with_normals) && sup_part && sm_part, "pd_multiscale_loss_fwd: null pointer");
+    PD_REQUIRE(min_depth > 0 && max_depth > min_depth, "pd_multiscale_loss_fwd: bad depth range");
+    unsigned nb_max = 0;
+    for (int s = 0; s < S; ++s) { PD_REQUIRE(colors[s] && means[s], "pd_multiscale_loss_fwd: null scale tensor"); nb_max = std::max(nb_max, a.nb_s[s]); }
+    PD_REQUIRE((int)a.nb_full <= part_stride && (int)nb_max <= part_stride, "pd_multiscale_loss_fwd: part_stride too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ms_disp_to_depth_kernel, dim3(a.nb_full, S), dim3(LT), 0, st, a, 1.f / max_depth, 1.f / min_depth);
+    hipLaunchKernelGGL(ms_sup_fwd_kernel, dim3(a.nb_full), dim3(LT), 0, st, a, (const float*)gt, (const float*)K,
+                       (const float4*)gt_normals, (float*)sup_part, part_stride, min_depth, max_depth, with_normals);
+    hipLaunchKernelGGL(ms_image_mean_kernel, dim3(N, S), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(ms_smooth_fwd_kernel, dim3(nb_max, S), dim3(LT), 0, st, a, (float*)sm_part, part_stride);
+    return pd::check_launch("pd_multiscale_loss_fwd");
+}
+
+extern "C" int pd_multiscale_loss_bwd(const void* const* disps, const void* const* colors, const void* const* depths,
+                                      const void* const* means, const void* const* edge_ws, const int* hs, const int* ws, int S,
+                                      const void* gt, const void* K, const void* gt_normals, const void* wts, const void* sums,
+                                      void* gup_ws, void* g_ws, void* gd_acc, void* const* gdisps, int N, int H, int W,
+                                      float min_depth, float max_depth, void* stream) {
+    MsArgs a;
+    int rc = ms_fill(a, disps, colors, const_cast<void* const*>(depths), const_cast<void* const*>(means),
+                     const_cast<void* const*>(edge_ws), hs, ws, S, N, H, W);
+    if (rc) return rc;
+    PD_REQUIRE(colors && means && gt && K && wts && sums && gup_ws && g_ws && gd_acc && gdisps, "pd_multiscale_loss_bwd: null pointer");
+    unsigned nb_max = 0;
+    long goff = 0;
+    for (int s = 0; s < S; ++s) {
+        PD_REQUIRE(colors[s] && means[s] && gdisps[s], "pd_multiscale_loss_bwd: null scale tensor");
+        a.gdisp[s] = (float*)gdisps[s];
+        a.gup[s] = (float*)gup_ws + (long)s * N * H * W;
+        a.gws[s] = (float*)g_ws + goff;
+        goff += (long)N * hs[s] * ws[s];
+        nb_max = std::max(nb_max, a.nb_s[s]);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_h = (H + SB_TR - 1) / SB_TR, tiles_w = (W + SB_TW - 1) / SB_TW;
+    const long ntiles = (long)N * tiles_h * tiles_w;
+    PD_REQUIRE(ntiles < (1L << 31), "pd_multiscale_loss_bwd: too many tiles");
+    hipLaunchKernelGGL(ms_sup_bwd_kernel, dim3((unsigned)(ntiles > 4096 ? 4096 : ntiles), S), dim3(LT), 0, st, a, (const float*)gt,
+                       (const float*)K, (const float4*)gt_normals, (const float*)wts, (const double*)sums, min_depth, max_depth,
+                       1.f / min_depth - 1.f / max_depth, tiles_h, tiles_w, (int)ntiles);
+    hipLaunchKernelGGL(ms_up_gather_bwd_kernel, dim3(nb_max, S), dim3(LT), 0, st, a);
+    if (hipMemsetAsync(gd_acc, 0, sizeof(double) * N * S, st) != hipSuccess) return pd::fail(PD_ELAUNCH, "pd_multiscale_loss_bwd: memset");
+    hipLaunchKernelGGL(ms_smooth_bwd_g_kernel, dim3(nb_max, S), dim3(LT), 0, st, a, (const float*)wts, (double*)gd_acc);
+    hipLaunchKernelGGL(ms_smooth_bwd_final_kernel, dim3(nb_max, S), dim3(LT), 0, st, a, (const double*)gd_acc);
+    return pd::check_launch("pd_multiscale_loss_bwd");
 }
 
 extern "C" int pd_loss_finalize(const void* sup_part, const int* sup_rows, const void* sm_part, const int* sm_rows,

@@ -20,6 +20,7 @@ _dp = _c.POINTER(_c.c_double)
 _l, _f = _c.c_long, _c.c_float
 _u64 = _c.c_uint64
 _ip = _c.POINTER(_c.c_int)
+_vpp = _c.POINTER(_c.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/polardepth.h one to one
 SIGNATURES = {
@@ -75,6 +76,10 @@ SIGNATURES = {
     "pd_gt_normals": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "pd_sup_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "pd_normals_loss_masked": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pd_multiscale_loss_fwd": (_i, [_vpp, _vpp, _ip, _ip, _i, _vp, _vp, _vp, _vpp, _vpp, _vpp, _vp, _vp, _i, _i, _i, _i, _f, _f,
+                                    _i, _vp]),
+    "pd_multiscale_loss_bwd": (_i, [_vpp, _vpp, _vpp, _vpp, _vpp, _ip, _ip, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vpp,
+                                    _i, _i, _i, _f, _f, _vp]),
     "pd_sup_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
     "pd_smooth_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pd_smooth_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

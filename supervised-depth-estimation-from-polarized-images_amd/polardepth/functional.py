@@ -868,6 +868,14 @@ def _iarr(vals):
     return (ctypes.c_int * len(vals))(*vals)
 
 
+def _parr(tensors):
+    """Host array of device pointers (NULL for None) for the multi-scale entry points."""
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+USE_MULTISCALE_LAUNCH = os.environ.get("PD_MULTISCALE_LAUNCH", "1") != "0"   # all scales of the loss per launch
+
+
 class MultiScaleLossFn(torch.autograd.Function):
     """trainer.py:531-545 + 1126-1150,1241-1265,1298-1309 as one node.
 
@@ -896,21 +904,31 @@ class MultiScaleLossFn(torch.autograd.Function):
         if USE_GT_NORMAL_CACHE and S > 1:
             gtn = _f32(dev, N, H, W, 4)
             check(lib.pd_gt_normals(ptr(gt), ptr(K), ptr(gtn), N, H, W, cfg.min_depth, cfg.max_depth, st), "pd_gt_normals")
+        multi = USE_MULTISCALE_LAUNCH and S <= 8 and all(H % d.shape[2] == 0 and H // d.shape[2] in (1, 2, 4, 8) and
+                                                          W // d.shape[3] == H // d.shape[2] and W % d.shape[3] == 0 for d in disps)
         for i, s in enumerate(cfg.scales):
             d = disps[i]
             hs, ws = d.shape[2], d.shape[3]
-            depth = _f32(dev, N, 1, H, W)
-            check(lib.pd_disp_to_depth(ptr(d), ptr(depth), None, N, hs, ws, H, W, cfg.min_depth, cfg.max_depth, st),
-                  "pd_disp_to_depth")
-            check(lib.pd_sup_loss_fwd(ptr(depth), ptr(gt), ptr(K), ptr(gtn), ptr(sup_part[i]), N, H, W, cfg.min_depth,
-                                      cfg.max_depth, with_n, st), "pd_sup_loss_fwd")
-            mean = _f32(dev, N)
-            ew = _f32(dev, N, hs, ws, 2) if (USE_EDGE_WEIGHT_CACHE and ctx.needs_input_grad[3 + i]) else None
-            check(lib.pd_smooth_fwd(ptr(d), ptr(colors[i]), ptr(mean), ptr(sm_part[i]), ptr(ew), N, hs, ws, st), "pd_smooth_fwd")
-            edge_ws.append(ew)
+            depths.append(_f32(dev, N, 1, H, W)); means.append(_f32(dev, N))
+            edge_ws.append(_f32(dev, N, hs, ws, 2) if (USE_EDGE_WEIGHT_CACHE and ctx.needs_input_grad[3 + i]) else None)
             sup_rows.append(lib.pd_loss_rows(N * H * W)); sm_rows.append(lib.pd_loss_rows(N * hs * ws))
             dims += [N, hs, ws]
-            depths.append(depth); means.append(mean)
+        if multi:
+            check(lib.pd_multiscale_loss_fwd(_parr(disps), _parr(colors), _iarr([d.shape[2] for d in disps]),
+                                             _iarr([d.shape[3] for d in disps]), S, ptr(gt), ptr(K), ptr(gtn), _parr(depths),
+                                             _parr(means), _parr(edge_ws), ptr(sup_part), ptr(sm_part), stride, N, H, W,
+                                             cfg.min_depth, cfg.max_depth, with_n, st), "pd_multiscale_loss_fwd")
+        else:
+            for i in range(S):
+                d = disps[i]
+                hs, ws = d.shape[2], d.shape[3]
+                check(lib.pd_disp_to_depth(ptr(d), ptr(depths[i]), None, N, hs, ws, H, W, cfg.min_depth, cfg.max_depth, st),
+                      "pd_disp_to_depth")
+                check(lib.pd_sup_loss_fwd(ptr(depths[i]), ptr(gt), ptr(K), ptr(gtn), ptr(sup_part[i]), N, H, W, cfg.min_depth,
+                                          cfg.max_depth, with_n, st), "pd_sup_loss_fwd")
+                check(lib.pd_smooth_fwd(ptr(d), ptr(colors[i]), ptr(means[i]), ptr(sm_part[i]), ptr(edge_ws[i]), N, hs, ws, st),
+                      "pd_smooth_fwd")
+        ctx.multi = multi
         sums = torch.empty(S * 5, dtype=torch.float64, device=dev)
         vals = _f32(dev, 1 + 3 * S)
         check(lib.pd_loss_finalize(ptr(sup_part), _iarr(sup_rows), ptr(sm_part), _iarr(sm_rows), _iarr(dims),
@@ -941,6 +959,16 @@ class MultiScaleLossFn(torch.autograd.Function):
         wts = _f32(dev, 3 * S)
         check(lib.pd_loss_weights(ptr(gvals), _iarr(cfg.scales), S, cfg.w_normals, cfg.w_smooth, ptr(wts), st),
               "pd_loss_weights")
+        if ctx.multi and os.environ.get("PD_SUP_BWD_TWO_PASS") != "1":
+            grads = [torch.empty_like(d) for d in disps]
+            gup = _f32(dev, S, N, H, W)
+            gws = _f32(dev, sum(d.numel() for d in disps))
+            gacc = torch.empty(S * N, dtype=torch.float64, device=dev)
+            check(lib.pd_multiscale_loss_bwd(_parr(disps), _parr(colors), _parr(depths), _parr(means), _parr(ctx.edge_ws),
+                                             _iarr([d.shape[2] for d in disps]), _iarr([d.shape[3] for d in disps]), S, ptr(gt),
+                                             ptr(K), ptr(ctx.gtn), ptr(wts), ptr(sums), ptr(gup), ptr(gws), ptr(gacc),
+                                             _parr(grads), N, H, W, cfg.min_depth, cfg.max_depth, st), "pd_multiscale_loss_bwd")
+            return (None, None, None, *grads, *([None] * S))
         # (the [N,H,W,6] intermediate of the two-pass form; the fused kernel keeps it in LDS)
         ab = _f32(dev, N, H, W, 6) if os.environ.get("PD_SUP_BWD_TWO_PASS") == "1" else None
         gup = _f32(dev, N, H, W)

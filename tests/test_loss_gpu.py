@@ -57,6 +57,32 @@ def test_input_only_caches_are_bit_exact(switch, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("scales,size", [([0, 1, 2, 3], (2, 64, 96)), ([0, 2], (3, 32, 80)), ([1, 3], (1, 128, 64)), ([0], (2, 16, 48))])
+def test_all_scales_per_launch_equals_the_per_scale_launches(scales, size, monkeypatch):
+    """pd_multiscale_loss_fwd / _bwd (every scale of the loss in one launch per kernel, ground truth read once for all
+    scales in the supervised forward pass) against the per-scale launches they replace: identical loss values, depth maps
+    and disparity gradients, for all four scales, a subset, and a single scale."""
+    N, H, W = size
+    g = torch.Generator().manual_seed(sum(size) + len(scales))
+    gt = (0.05 + 2.2 * torch.rand(N, 1, H, W, generator=g)).cuda()          # some pixels out of the depth range
+    K = torch.eye(4)[None].repeat(N, 1, 1)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = 0.65 * W, 0.65 * W, 0.5 * W, 0.5 * H
+    K = K.cuda()
+    cfg = PF.LossCfg(scales, 0.1, 2.0, 0.35, 1e-3, H, W)
+    colors = [torch.rand(N, 3, H >> s, W >> s, generator=g).cuda() for s in scales]
+    out = []
+    for multi in (True, False):
+        monkeypatch.setattr(PF, "USE_MULTISCALE_LAUNCH", multi)
+        disps = [torch.rand(N, 1, H >> s, W >> s, generator=torch.Generator().manual_seed(7 + s)).cuda().requires_grad_(True)
+                 for s in scales]
+        vals, depths = PF.multiscale_loss(cfg, gt, K, disps, colors)
+        (vals[0] * 1.7 + vals[1:].sum()).backward()
+        out.append([vals.detach().clone()] + [d.clone() for d in depths] + [d.grad.clone() for d in disps])
+    assert len(out[0]) == 1 + 2 * len(scales)
+    for i, (a, b) in enumerate(zip(*out)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), f"output {i} differs"
+
+
 @pytest.mark.parametrize("geom", [(2, 64, 96), (1, 21, 70), (3, 8, 130)])
 def test_fused_supervised_backward_equals_the_two_pass_form(geom, monkeypatch):
     """pd_sup_loss_bwd: passes A and B through an LDS halo tile == pass A to memory + pass B (same bits), on grids that
