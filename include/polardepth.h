@@ -249,6 +249,10 @@ int pd_chain_bwd_apply(const void* dy, long ld_dy, const void* x, const void* ou
 /* idx (optional in fwd): uint8 [N,Ho,Wo,C] window position (dh*3+dw) of the first maximum, consumed by bwd. */
 int pd_maxpool3s2_fwd(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream);
 int pd_maxpool3s2_bwd(const void* idx, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+/* ... + addend (optional, NHWC [N,H,W,C] with row stride ld_add): the gradient a second consumer of the pooled tensor
+ * delivers (the decoder's skip connection, depth_decoder.py:65-66), summed in the same pass. */
+int pd_maxpool3s2_bwd_add(const void* idx, const void* dy, const void* addend, long ld_add, void* dx, int N, int H, int W,
+                          int C, void* stream);
 
 /* Decoder glue: out[N,2H,2W,Ca+Cs] = cat(bilinear_x2(a), skip)  (layers.py:446-449 upsample,
  * depth_decoder.py:64-67 cat) and the gradient of the upsampled part (gather form). */

@@ -520,7 +520,10 @@ __global__ __launch_bounds__(EW_T) void maxpool3_fwd_kernel(const float* __restr
 // dx from the saved window positions: an input pixel lies in 1, 2 or 4 windows (ho in {h/2, (h+1)/2}); it receives
 // dy of those whose first maximum it is.  One read of idx (4 B) and dy (16 B) per covering window instead of the nine
 // taps of x: 0.66 ms -> ~0.1 ms on the ResNet stem.
+// add (optional, row stride ld_add): a second gradient of the pooled tensor (the decoder's skip connection reads the same
+// feature map), summed here instead of by a separate pass over three 335 MB tensors
 __global__ __launch_bounds__(EW_T) void maxpool3_bwd_kernel(const uint32_t* __restrict__ idx, const float* __restrict__ dy,
+                                                            const float* __restrict__ add, long ld_add,
                                                             float* __restrict__ dx, int N, int H, int W, int C, int Ho,
                                                             int Wo) {
     const int cq = C >> 2;
@@ -545,6 +548,8 @@ __global__ __launch_bounds__(EW_T) void maxpool3_bwd_kernel(const uint32_t* __re
             mes[k] = (uint32_t)(h - (2 * ho - 1)) * 3u + (uint32_t)(w - (2 * wo - 1));
         }
         float4 acc = f4(0.f);
+        float4 extra = f4(0.f);
+        if (add) extra = ld4(add + ((n * H + h) * (long)W + w) * ld_add + cqi * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!use[k]) continue;
@@ -554,6 +559,7 @@ __global__ __launch_bounds__(EW_T) void maxpool3_bwd_kernel(const uint32_t* __re
             acc.z += ((id >> 16) & 0xffu) == me ? gs[k].z : 0.f;
             acc.w += (id >> 24) == me ? gs[k].w : 0.f;
         }
+        if (add) { acc.x += extra.x; acc.y += extra.y; acc.z += extra.z; acc.w += extra.w; }
         st4(dx + i * 4, acc);
     }
 }
@@ -977,13 +983,20 @@ extern "C" int pd_maxpool3s2_fwd(const void* x, void* y, void* idx, int N, int H
     return pd::check_launch("pd_maxpool3s2_fwd");
 }
 
-extern "C" int pd_maxpool3s2_bwd(const void* idx, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+extern "C" int pd_maxpool3s2_bwd_add(const void* idx, const void* dy, const void* addend, long ld_add, void* dx, int N, int H,
+                                    int W, int C, void* stream) {
     PD_REQUIRE(idx && dy && dx && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_maxpool3s2_bwd: bad arguments");
+    PD_REQUIRE(!addend || (ld_add >= C && ld_add % 4 == 0 && pd::aligned16(addend)), "pd_maxpool3s2_bwd: bad addend");
     if (N == 0) return PD_OK;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(EW_T), 0,
-                       (hipStream_t)stream, (const uint32_t*)idx, (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo);
+                       (hipStream_t)stream, (const uint32_t*)idx, (const float*)dy, (const float*)addend, ld_add, (float*)dx, N,
+                       H, W, C, Ho, Wo);
     return pd::check_launch("pd_maxpool3s2_bwd");
+}
+
+extern "C" int pd_maxpool3s2_bwd(const void* idx, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+    return pd_maxpool3s2_bwd_add(idx, dy, nullptr, 0, dx, N, H, W, C, stream);
 }
 
 extern "C" int pd_upcat_fwd(const void* a, const void* skip, long ld_skip, void* out, int N, int H, int W, int Ca,

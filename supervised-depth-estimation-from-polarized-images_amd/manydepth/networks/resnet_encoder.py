@@ -96,7 +96,12 @@ class ShallowResnetEncoder(nn.Module):
         cfg = PF.ChainCfg(stride=2, pad=3, relu_pre=True, affine=(0.45, 0.225))
         f0 = PF.conv_bn_chain(input_image.float(), e.conv1, e.bn1, cfg, training=tr)
         self.features.append(f0)
-        x = PF.maxpool3s2(f0)
+        # f0 feeds the max-pool and, as a skip connection, the decoder: the decoder deposits its gradient in this mailbox and
+        # the max-pool's backward kernel adds it (functional.SkipGrad), instead of autograd's pass over three 335 MB tensors
+        mail = PF.SkipGrad() if (PF.USE_SKIP_FUSION and torch.is_grad_enabled() and f0.requires_grad) else None
+        if mail is not None:
+            f0._pd_skip_mail = mail
+        x = PF.maxpool3s2(f0, mail)
         for blk in e.layer1:
             x = blk(x)
         self.features.append(x)

@@ -61,6 +61,7 @@ SIGNATURES = {
                                 _u64, _u64, _vp, _i, _vp]),
     "pd_maxpool3s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_maxpool3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_maxpool3s2_bwd_add": (_i, [_vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "pd_upcat_fwd": (_i, [_vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),
     "pd_up_bwd": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "pd_up_bwd_elu": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -183,14 +183,16 @@ class BNParams:
 
 
 class SkipGrad:
-    """Mailbox of a residual block: the backward pass of the block's LAST convolution deposits the gradient of the skip
+    """(also used between the decoder's skip connection and the max-pool of the ResNet stem, see attach_skip_mail)
+    Mailbox of a residual block: the backward pass of the block's LAST convolution deposits the gradient of the skip
     connection here instead of returning it; the backward pass of the block's FIRST convolution (which autograd runs
     later: its output feeds the last one) adds it in the epilogue of its data-gradient kernel.  Both convolutions read
     the same block input, so the sum is exactly what autograd would have formed with a separate add kernel."""
-    __slots__ = ("grad",)
+    __slots__ = ("grad", "closed")
 
     def __init__(self):
         self.grad = None
+        self.closed = False
 
 
 class ActGrad:
@@ -652,7 +654,7 @@ class UpCatFn(torch.autograd.Function):
     """cat([bilinear_x2(a), skip], 1)  (layers.upsample + depth_decoder.py:64-67)."""
 
     @staticmethod
-    def forward(ctx, a, skip, act_mail=None):
+    def forward(ctx, a, skip, act_mail=None, skip_mail=None):
         a = ops.as_nhwc(a)
         N, Ca, H, W = a.shape
         Cs, ld_s = 0, 0
@@ -662,6 +664,7 @@ class UpCatFn(torch.autograd.Function):
         out = ops.empty_nhwc(N, Ca + Cs, 2 * H, 2 * W, a.device)
         check(lib.pd_upcat_fwd(ptr(a), ptr(skip), ld_s, ptr(out), N, H, W, Ca, Cs, stream_ptr()), "pd_upcat_fwd")
         ctx.dims = (N, Ca, Cs, H, W)
+        ctx.skip_mail = skip_mail
         ctx.mail = act_mail                     # ActGrad of a (ELU output whose only consumer this node is)
         if act_mail is not None:
             ctx.save_for_backward(a)            # the same tensor the producing convolution keeps: no extra memory
@@ -678,18 +681,31 @@ class UpCatFn(torch.autograd.Function):
             ctx.mail.activated = True
         check(lib.pd_up_bwd_elu(ptr(dout), ld, ptr(elu_y), ptr(da), N, H, W, Ca, stream_ptr()), "pd_up_bwd")
         dskip = dout[:, Ca:] if Cs and ctx.needs_input_grad[1] else None
-        return da, dskip, None
+        smail = ctx.skip_mail
+        if dskip is not None and smail is not None and USE_SKIP_FUSION and not smail.closed and smail.grad is None:
+            # the skip tensor's other consumer (the ResNet max-pool) adds this gradient in its own backward kernel
+            global _deposit_check_queued
+            smail.grad, dskip = dskip, None
+            _DEPOSITS.append(smail)
+            if not _deposit_check_queued:
+                torch.autograd.Variable._execution_engine.queue_callback(_check_deposits_after_backward)
+                _deposit_check_queued = True
+        return da, dskip, None, None
 
 
 def upcat(a, skip=None, act_mail=None):
-    return UpCatFn.apply(a, skip, act_mail)
+    # a skip tensor that carries a mailbox (set by the encoder: its other consumer can add the skip gradient in its own
+    # backward kernel) receives the gradient by deposit instead of through autograd's accumulation pass
+    skip_mail = getattr(skip, "_pd_skip_mail", None) if skip is not None and torch.is_grad_enabled() else None
+    return UpCatFn.apply(a, skip, act_mail, skip_mail)
 
 
 class MaxPool3s2Fn(torch.autograd.Function):
     """nn.MaxPool2d(3, 2, 1) (resnet_encoder.py:814)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, mail=None):
+        ctx.mail = mail                         # SkipGrad of x: the gradient of x's other consumer (decoder skip)
         x = ops.as_nhwc(x)
         N, C, H, W = x.shape
         y = ops.empty_nhwc(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x.device)
@@ -708,12 +724,21 @@ class MaxPool3s2Fn(torch.autograd.Function):
         if not dy.is_contiguous(memory_format=CL):
             dy = dy.contiguous(memory_format=CL)
         dx = ops.empty_nhwc(N, C, H, W, dy.device)
-        check(lib.pd_maxpool3s2_bwd(ptr(idx), ptr(dy), ptr(dx), N, H, W, C, stream_ptr()), "pd_maxpool3s2_bwd")
-        return dx
+        add, ld_add = None, 0
+        if ctx.mail is not None and ctx.mail.grad is not None:
+            add, ctx.mail.grad = ctx.mail.grad, None
+            if tuple(add.shape) != (N, C, H, W) or add.stride(1) != 1 or add.stride(3) % 4:
+                raise RuntimeError("SkipGrad: the deposited skip gradient does not match the pooled tensor")
+            ld_add = add.stride(3)
+        if ctx.mail is not None:
+            ctx.mail.closed = True              # a deposit arriving after this node ran goes back to autograd
+        check(lib.pd_maxpool3s2_bwd_add(ptr(idx), ptr(dy), ptr(add), ld_add, ptr(dx), N, H, W, C, stream_ptr()),
+              "pd_maxpool3s2_bwd")
+        return dx, None
 
 
-def maxpool3s2(x):
-    return MaxPool3s2Fn.apply(x)
+def maxpool3s2(x, mail=None):
+    return MaxPool3s2Fn.apply(x, mail)
 
 
 # ------------------------------------------------------------------ plain convolution with bias (no BatchNorm)
