@@ -391,11 +391,16 @@ int pd_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
 
 /* The same attention on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16; BASELINE configs[4] "bf16, MFMA attention
  * path"): identical tensors and semantics (fp32 [N][T][128] in and out), operands rounded to bf16 when staged,
- * softmax statistics / exp2 / accumulators in fp32.  Selected by PD_ATTENTION_BF16=1 / bench.py --attention --bf16. */
-int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, void* lse, int N, int T, int C, float scale,
-                     void* stream);
+ * softmax statistics / exp2 / accumulators in fp32.  Selected by PD_ATTENTION_BF16=1 / bench.py --attention --bf16.
+ * workspace (caller-owned, pd_attn_bf16_workspace bytes, 16-byte aligned): the operands every workgroup re-reads are packed
+ * once per call into bf16 images of the kernels' LDS tiles (forward: K rows + V^T; backward: K rows, K^T, V rows, Q rows,
+ * Q^T, dO rows, dO^T), so that staging a block is a verbatim 16-byte copy. */
+size_t pd_attn_bf16_workspace(int N, int T, int C, int backward);
+int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, void* lse, void* workspace, size_t ws_bytes,
+                     int N, int T, int C, float scale, void* stream);
 int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const void* lse,
-                     void* delta, void* dq, void* dk, void* dv, int N, int T, int C, float scale, void* stream);
+                     void* delta, void* dq, void* dk, void* dv, void* workspace, size_t ws_bytes, int N, int T, int C,
+                     float scale, void* stream);
 
 /* ---- disparity heads: sigmoid(Conv3x3(x)) with one output channel
  * (manydepth/networks/depth_decoder.py:52-53,69-71; layers.py:364-380 Conv3x3 = ReflectionPad2d(1) + Conv2d(C,1,3)).

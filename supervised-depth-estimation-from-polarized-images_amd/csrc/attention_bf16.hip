@@ -26,6 +26,16 @@ constexpr int ATT_T = 256;         // 4 waves -> 128 tokens per workgroup
 constexpr int TILE = KB * HD * 2;  // bytes of one bf16 tile (either layout): 8 KB
 constexpr float kLog2e = 1.4426950408889634f;
 
+// v_exp_f32 as it is (1 ulp).  exp2f() wraps it in a denormal-range fix-up (compare, select, add, exp, ldexp: five
+// instructions per score, ~70 of the ~250 vector instructions a wave issues per 32-key block beside its 16 MFMAs); the
+// arguments here are score - max <= 0 or score - lse, and a result that underflows to zero instead of a denormal is beyond
+// what the bf16 probabilities resolve.  Forward 0.46 -> 0.43 ms; with the operands pre-packed into bf16 tile images (below:
+// no conversion / address arithmetic in the loop) 0.37 ms.  Measured without effect or worse on top of that (round 3): a
+// prefetch distance of two blocks, two query groups per wave (half the LDS reads per MFMA, but one wave per SIMD:
+// 0.79 ms), packed fp32 softmax arithmetic with compile-time LDS buffers (0.39 ms) -- the loop is bound by the dependent
+// chain LDS read -> 8 chained MFMAs -> max / exp / sum across the half-waves -> 8 MFMAs of one wave, which three waves
+// per SIMD do not cover.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ bf16x4 cvt4(float a, float b, float c, float d) {
     bf16x4 r; r[0] = (__bf16)a; r[1] = (__bf16)b; r[2] = (__bf16)c; r[3] = (__bf16)d; return r;
@@ -97,9 +107,36 @@ __device__ __forceinline__ void zero(f32x16& a) {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
+// ---- operands packed once per call: bf16 tile IMAGES in global memory
+// Every workgroup of the attention kernels stages every block of the other operand; converting fp32 -> bf16 and scattering
+// into the swizzled layouts there repeated that work 40 times per image, on the VALU, beside the MFMAs.  attn_pack_kernel
+// writes, per 32-token block, the row-major and / or the transposed LDS tile verbatim (8 KB each); the attention kernels
+// then copy a tile with two 16-byte loads + two ds_write_b128 per thread: no conversion, no address arithmetic.
+__global__ __launch_bounds__(ATT_T) void attn_pack_kernel(const float* __restrict__ x, char* __restrict__ rows,
+                                                          char* __restrict__ trans, long nblocks) {
+    for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const Stage s = load_stage(x + b * (long)KB * HD, 0, threadIdx.x);
+        if (rows) store_rows(rows + b * TILE, s, threadIdx.x);
+        if (trans) store_transposed(trans + b * TILE, s, threadIdx.x);
+    }
+}
+
+struct TileRegs { uint4 a, b; };
+__device__ __forceinline__ TileRegs load_tile(const char* __restrict__ g, int tid) {
+    TileRegs t;
+    t.a = *reinterpret_cast<const uint4*>(g + 16 * tid);
+    t.b = *reinterpret_cast<const uint4*>(g + TILE / 2 + 16 * tid);
+    return t;
+}
+__device__ __forceinline__ void store_tile(char* lds, const TileRegs& t, int tid) {
+    *reinterpret_cast<uint4*>(lds + 16 * tid) = t.a;
+    *reinterpret_cast<uint4*>(lds + TILE / 2 + 16 * tid) = t.b;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(ATT_T, 2) void attn_fwd_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                 const float* __restrict__ v, float* __restrict__ o,
+// Three workgroups per CU: 16 x 5120 queries are 640 workgroups of 128 -- 1.25 rounds of the chip at two per CU, one at three.
+__global__ __launch_bounds__(ATT_T, 3) void attn_fwd_bf16_kernel(const float* __restrict__ q, const char* __restrict__ kr,
+                                                                 const char* __restrict__ vt, float* __restrict__ o,
                                                                  float* __restrict__ lse, int T, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char Ks[2][TILE];
     __shared__ __attribute__((aligned(16))) char Vt[2][TILE];
@@ -107,8 +144,9 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_fwd_bf16_kernel(const float* __
     const int n = blockIdx.y;
     const int q0 = blockIdx.x * (4 * QW) + wave * QW;
     const int ql = lane & 31, h = lane >> 5;
-    const float* kn = k + (long)n * T * HD;
-    const float* vn = v + (long)n * T * HD;
+    const int nkb = T / KB;
+    const char* kn = kr + (long)n * nkb * TILE;
+    const char* vn = vt + (long)n * nkb * TILE;
     bf16x8 qb[HD / 16];
     own_frags(q + ((long)n * T + (q0 + ql < T ? q0 + ql : T - 1)) * HD, h, scale_log2e, qb);
     f32x16 oacc[HD / 32];
@@ -116,14 +154,13 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_fwd_bf16_kernel(const float* __
     for (int c = 0; c < HD / 32; ++c) zero(oacc[c]);
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int nkb = T / KB;
-    Stage sk = load_stage(kn, 0, tid), sv = load_stage(vn, 0, tid);
-    store_rows(Ks[0], sk, tid);
-    store_transposed(Vt[0], sv, tid);
+    TileRegs k1 = load_tile(kn, tid), v1 = load_tile(vn, tid);
+    store_tile(Ks[0], k1, tid);
+    store_tile(Vt[0], v1, tid);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         const int buf = kb & 1;
-        if (kb + 1 < nkb) { sk = load_stage(kn, (kb + 1) * KB, tid); sv = load_stage(vn, (kb + 1) * KB, tid); }
+        if (kb + 1 < nkb) { k1 = load_tile(kn + (long)(kb + 1) * TILE, tid); v1 = load_tile(vn + (long)(kb + 1) * TILE, tid); }
         // ---- S^T = K_blk . Q^T  (keys on rows, this wave's queries on lanes)
         f32x16 s;
         zero(s);
@@ -136,10 +173,10 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_fwd_bf16_kernel(const float* __
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = fast_exp2(m_run - m_new);
         float lsum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - m_new); lsum += s[r]; }
+        for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r] - m_new); lsum += s[r]; }
         lsum += __shfl_xor(lsum, 32);
         l_run = l_run * alpha + lsum;
         // the rescale of O^T is skipped (exactly: alpha == 1) while no query of the wave has met a new maximum
@@ -157,7 +194,7 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_fwd_bf16_kernel(const float* __
             oacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt[buf], 32 * c + ql, 0, h), p0, oacc[c], 0, 0, 0);
             oacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt[buf], 32 * c + ql, 1, h), p1, oacc[c], 0, 0, 0);
         }
-        if (kb + 1 < nkb) { store_rows(Ks[buf ^ 1], sk, tid); store_transposed(Vt[buf ^ 1], sv, tid); }
+        if (kb + 1 < nkb) { store_tile(Ks[buf ^ 1], k1, tid); store_tile(Vt[buf ^ 1], v1, tid); }
         __syncthreads();
     }
     // ---- epilogue: O[query][c] = O^T[c][query] / l ; lse = (m + log2 l) * ln 2
@@ -178,8 +215,9 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_fwd_bf16_kernel(const float* __
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // queries on lanes.  Per key block:  S^T = K.Q^T,  dP^T = V.dO^T,  dS = exp2(S - lse) (dP - delta),
 //   dQ^T (chan x queries) += K_blk^T (chan x keys) . dS (keys x queries)
-__global__ __launch_bounds__(ATT_T, 2) void attn_bwd_dq_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                    const float* __restrict__ v, const float* __restrict__ d_o,
+__global__ __launch_bounds__(ATT_T, 2) void attn_bwd_dq_bf16_kernel(const float* __restrict__ q, const char* __restrict__ kr,
+                                                                    const char* __restrict__ kt, const char* __restrict__ vr,
+                                                                    const float* __restrict__ d_o,
                                                                     const float* __restrict__ lse, const float* __restrict__ delta,
                                                                     float* __restrict__ dq, int T, float scale) {
     __shared__ __attribute__((aligned(16))) char Ks[2][TILE];
@@ -190,8 +228,10 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_bwd_dq_bf16_kernel(const float*
     const int q0 = blockIdx.x * (4 * QW) + wave * QW;
     const int ql = lane & 31, h = lane >> 5;
     const long base = (long)n * T * HD;
-    const float* kn = k + base;
-    const float* vn = v + base;
+    const int nkb = T / KB;
+    const char* krn = kr + (long)n * nkb * TILE;
+    const char* ktn = kt + (long)n * nkb * TILE;
+    const char* vrn = vr + (long)n * nkb * TILE;
     const int qi = q0 + ql < T ? q0 + ql : T - 1;
     bf16x8 qb[HD / 16], dob[HD / 16];
     own_frags(q + base + (long)qi * HD, h, scale * kLog2e, qb);
@@ -202,13 +242,15 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_bwd_dq_bf16_kernel(const float*
 #pragma unroll
     for (int c = 0; c < HD / 32; ++c) zero(acc[c]);
 
-    const int nkb = T / KB;
-    Stage sk = load_stage(kn, 0, tid), sv = load_stage(vn, 0, tid);
-    store_rows(Ks[0], sk, tid); store_transposed(Kt[0], sk, tid); store_rows(Vs[0], sv, tid);
+    TileRegs a1 = load_tile(krn, tid), b1 = load_tile(ktn, tid), c1 = load_tile(vrn, tid);
+    store_tile(Ks[0], a1, tid); store_tile(Kt[0], b1, tid); store_tile(Vs[0], c1, tid);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         const int buf = kb & 1;
-        if (kb + 1 < nkb) { sk = load_stage(kn, (kb + 1) * KB, tid); sv = load_stage(vn, (kb + 1) * KB, tid); }
+        if (kb + 1 < nkb) {
+            const long off = (long)(kb + 1) * TILE;
+            a1 = load_tile(krn + off, tid); b1 = load_tile(ktn + off, tid); c1 = load_tile(vrn + off, tid);
+        }
         f32x16 s, dp;
         zero(s); zero(dp);
 #pragma unroll
@@ -217,16 +259,14 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_bwd_dq_bf16_kernel(const float*
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs[buf], ql, g, h), dob[g], dp, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = exp2f(s[r] - lse2) * (dp[r] - dl);      // dS (keys x queries), fp32
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] - lse2) * (dp[r] - dl);      // dS (keys x queries), fp32
         const bf16x8 d0 = acc_frag(s, 0), d1 = acc_frag(s, 1);
 #pragma unroll
         for (int c = 0; c < HD / 32; ++c) {
             acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt[buf], 32 * c + ql, 0, h), d0, acc[c], 0, 0, 0);
             acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt[buf], 32 * c + ql, 1, h), d1, acc[c], 0, 0, 0);
         }
-        if (kb + 1 < nkb) {
-            store_rows(Ks[buf ^ 1], sk, tid); store_transposed(Kt[buf ^ 1], sk, tid); store_rows(Vs[buf ^ 1], sv, tid);
-        }
+        if (kb + 1 < nkb) { store_tile(Ks[buf ^ 1], a1, tid); store_tile(Kt[buf ^ 1], b1, tid); store_tile(Vs[buf ^ 1], c1, tid); }
         __syncthreads();
     }
     if (q0 + ql < T) {
@@ -244,8 +284,9 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_bwd_dq_bf16_kernel(const float*
 // keys on lanes.  Per query block:  S = Q_blk.K^T,  dP = dO_blk.V^T  (rows = queries),
 //   P = exp2(S - lse[row]),  dS = P (dP - delta[row]),
 //   dV^T (chan x keys) += dO_blk^T . P,   dK^T (chan x keys) += Q_blk^T . dS
-__global__ __launch_bounds__(ATT_T, 1) void attn_bwd_dkv_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                     const float* __restrict__ v, const float* __restrict__ d_o,
+__global__ __launch_bounds__(ATT_T, 1) void attn_bwd_dkv_bf16_kernel(const char* __restrict__ qr, const char* __restrict__ qt,
+                                                                     const float* __restrict__ k, const float* __restrict__ v,
+                                                                     const char* __restrict__ dr, const char* __restrict__ dt,
                                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                                      float* __restrict__ dk, float* __restrict__ dv, int T,
                                                                      float scale) {
@@ -262,8 +303,11 @@ __global__ __launch_bounds__(ATT_T, 1) void attn_bwd_dkv_bf16_kernel(const float
     const int k0 = blockIdx.x * (4 * QW) + wave * QW;
     const int kl = lane & 31, h = lane >> 5;
     const long base = (long)n * T * HD;
-    const float* qn = q + base;
-    const float* dn = d_o + base;
+    const int nqb = T / KB;
+    const char* qrn = qr + (long)n * nqb * TILE;
+    const char* qtn = qt + (long)n * nqb * TILE;
+    const char* drn = dr + (long)n * nqb * TILE;
+    const char* dtn = dt + (long)n * nqb * TILE;
     const int ki = k0 + kl < T ? k0 + kl : T - 1;
     bf16x8 kfr[HD / 16], vfr[HD / 16];
     own_frags(k + base + (long)ki * HD, h, scale * kLog2e, kfr);
@@ -272,23 +316,27 @@ __global__ __launch_bounds__(ATT_T, 1) void attn_bwd_dkv_bf16_kernel(const float
 #pragma unroll
     for (int c = 0; c < HD / 32; ++c) { zero(akk[c]); zero(avv[c]); }
 
-    float pl = 0.f, pdl = 0.f;
-    auto load_stats = [&](int qb) {
-        if (tid < KB) { pl = lse[(long)n * T + qb * KB + tid] * kLog2e; pdl = delta[(long)n * T + qb * KB + tid]; }
+    struct St { TileRegs qr, qt, dr, dt; float pl, pdl; };
+    auto load_all = [&](int qb) {
+        St t;
+        const long off = (long)qb * TILE;
+        t.qr = load_tile(qrn + off, tid); t.qt = load_tile(qtn + off, tid);
+        t.dr = load_tile(drn + off, tid); t.dt = load_tile(dtn + off, tid);
+        t.pl = 0.f; t.pdl = 0.f;
+        if (tid < KB) { t.pl = lse[(long)n * T + qb * KB + tid] * kLog2e; t.pdl = delta[(long)n * T + qb * KB + tid]; }
+        return t;
     };
-    auto store_all = [&](int buf, const Stage& sq, const Stage& sd) {
-        store_rows(Qs[buf], sq, tid); store_transposed(Qt[buf], sq, tid);
-        store_rows(Ds[buf], sd, tid); store_transposed(Dt[buf], sd, tid);
-        if (tid < KB) { Ls[buf][tid] = pl; Dl[buf][tid] = pdl; }
+    auto store_all = [&](int buf, const St& t) {
+        store_tile(Qs[buf], t.qr, tid); store_tile(Qt[buf], t.qt, tid);
+        store_tile(Ds[buf], t.dr, tid); store_tile(Dt[buf], t.dt, tid);
+        if (tid < KB) { Ls[buf][tid] = t.pl; Dl[buf][tid] = t.pdl; }
     };
-    const int nqb = T / KB;
-    Stage sq = load_stage(qn, 0, tid), sd = load_stage(dn, 0, tid);
-    load_stats(0);
-    store_all(0, sq, sd);
+    St s1 = load_all(0);
+    store_all(0, s1);
     __syncthreads();
     for (int qb = 0; qb < nqb; ++qb) {
         const int buf = qb & 1;
-        if (qb + 1 < nqb) { sq = load_stage(qn, (qb + 1) * KB, tid); sd = load_stage(dn, (qb + 1) * KB, tid); load_stats(qb + 1); }
+        if (qb + 1 < nqb) s1 = load_all(qb + 1);
         f32x16 s, dp;
         zero(s); zero(dp);
 #pragma unroll
@@ -304,7 +352,7 @@ __global__ __launch_bounds__(ATT_T, 1) void attn_bwd_dkv_bf16_kernel(const float
             const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float p = exp2f(s[4 * j + i] - lv[i]);
+                const float p = fast_exp2(s[4 * j + i] - lv[i]);
                 s[4 * j + i] = p;                                  // P  (queries x keys)
                 dp[4 * j + i] = p * (dp[4 * j + i] - dvv[i]);      // dS (queries x keys)
             }
@@ -317,7 +365,7 @@ __global__ __launch_bounds__(ATT_T, 1) void attn_bwd_dkv_bf16_kernel(const float
             akk[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt[buf], 32 * c + kl, 0, h), d0, akk[c], 0, 0, 0);
             akk[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt[buf], 32 * c + kl, 1, h), d1, akk[c], 0, 0, 0);
         }
-        if (qb + 1 < nqb) store_all(buf ^ 1, sq, sd);
+        if (qb + 1 < nqb) store_all(buf ^ 1, s1);
         __syncthreads();
     }
     if (k0 + kl < T) {
@@ -350,42 +398,71 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, void* lse, int N, int T, int C,
-                                float scale, void* stream) {
+extern "C" size_t pd_attn_bf16_workspace(int N, int T, int C, int backward) {
+    if (N <= 0 || T <= 0 || C != HD || T % KB) return 0;
+    return (size_t)N * T * HD * 2 * (backward ? 7 : 2);       // bf16 tile images: forward K rows + V^T; backward Kr Kt Vr Qr Qt dOr dOt
+}
+
+static void pack(const void* x, char* rows, char* trans, long nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)(nblocks > 8192 ? 8192 : nblocks)), dim3(ATT_T), 0, st, (const float*)x,
+                       rows, trans, nblocks);
+}
+
+extern "C" int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, void* lse, void* workspace,
+                                size_t ws_bytes, int N, int T, int C, float scale, void* stream) {
     PD_REQUIRE(N >= 0 && T > 0, "pd_attn_bf16_fwd: bad shape N=%d T=%d", N, T);
     PD_REQUIRE(C == HD, "pd_attn_bf16_fwd: head dimension must be %d (got %d)", HD, C);
     PD_REQUIRE(T % KB == 0, "pd_attn_bf16_fwd: the token count must be a multiple of %d (got %d)", KB, T);
     if (N == 0) return PD_OK;
-    PD_REQUIRE(q && k && v && o && lse, "pd_attn_bf16_fwd: null tensor");
-    PD_REQUIRE(pd::aligned16(q) && pd::aligned16(k) && pd::aligned16(v) && pd::aligned16(o), "pd_attn_bf16_fwd: tensors must be 16-byte aligned");
+    PD_REQUIRE(q && k && v && o && lse && workspace, "pd_attn_bf16_fwd: null tensor");
+    PD_REQUIRE(ws_bytes >= pd_attn_bf16_workspace(N, T, C, 0), "pd_attn_bf16_fwd: workspace too small");
+    PD_REQUIRE(pd::aligned16(q) && pd::aligned16(k) && pd::aligned16(v) && pd::aligned16(o) && pd::aligned16(workspace),
+               "pd_attn_bf16_fwd: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t one = (size_t)N * T * HD * 2;
+    char* kr = (char*)workspace; char* vt = kr + one;
+    const long nblocks = (long)N * T / KB;
+    pack(k, kr, nullptr, nblocks, st);
+    pack(v, nullptr, vt, nblocks, st);
     const dim3 grid((unsigned)((T + 4 * QW - 1) / (4 * QW)), (unsigned)N);
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(ATT_T), 0, (hipStream_t)stream, (const float*)q, (const float*)k,
-                       (const float*)v, (float*)o, (float*)lse, T, scale * kLog2e);
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr,
+                       (const char*)vt, (float*)o, (float*)lse, T, scale * kLog2e);
     return pd::check_launch("pd_attn_bf16_fwd");
 }
 
 extern "C" int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const void* lse,
-                                void* delta, void* dq, void* dk, void* dv, int N, int T, int C, float scale, void* stream) {
+                                void* delta, void* dq, void* dk, void* dv, void* workspace, size_t ws_bytes, int N, int T, int C,
+                                float scale, void* stream) {
     PD_REQUIRE(N >= 0 && T > 0, "pd_attn_bf16_bwd: bad shape N=%d T=%d", N, T);
     PD_REQUIRE(C == HD, "pd_attn_bf16_bwd: head dimension must be %d (got %d)", HD, C);
     PD_REQUIRE(T % KB == 0, "pd_attn_bf16_bwd: the token count must be a multiple of %d (got %d)", KB, T);
     if (N == 0) return PD_OK;
-    PD_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "pd_attn_bf16_bwd: null tensor");
+    PD_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv && workspace, "pd_attn_bf16_bwd: null tensor");
+    PD_REQUIRE(ws_bytes >= pd_attn_bf16_workspace(N, T, C, 1), "pd_attn_bf16_bwd: workspace too small");
     PD_REQUIRE(pd::aligned16(q) && pd::aligned16(k) && pd::aligned16(v) && pd::aligned16(o) && pd::aligned16(d_o) &&
-                   pd::aligned16(dq) && pd::aligned16(dk) && pd::aligned16(dv),
+                   pd::aligned16(dq) && pd::aligned16(dk) && pd::aligned16(dv) && pd::aligned16(workspace),
                "pd_attn_bf16_bwd: tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long ntok = (long)N * T;
     hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3((unsigned)((ntok + 7) / 8)), dim3(256), 0, st, (const float*)o,
                        (const float*)d_o, (float*)delta, ntok);
+    const size_t one = (size_t)N * T * HD * 2;
+    char* w = (char*)workspace;
+    char *kr = w, *kt = w + one, *vr = w + 2 * one, *qr = w + 3 * one, *qt = w + 4 * one, *dr = w + 5 * one, *dt = w + 6 * one;
+    const long nblocks = ntok / KB;
+    pack(k, kr, kt, nblocks, st);
+    pack(v, vr, nullptr, nblocks, st);
+    pack(q, qr, qt, nblocks, st);
+    pack(d_o, dr, dt, nblocks, st);
     const dim3 grid((unsigned)((T + 4 * QW - 1) / (4 * QW)), (unsigned)N);
     constexpr int kDkvLds = 8 * TILE + 4 * KB * 4;
     static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, kDkvLds);
     PD_REQUIRE(lds_ok == hipSuccess, "pd_attn_bf16_bwd: cannot reserve %d bytes of LDS", kDkvLds);
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(ATT_T), kDkvLds, st, (const float*)q, (const float*)k, (const float*)v,
-                       (const float*)d_o, (const float*)lse, (const float*)delta, (float*)dk, (float*)dv, T, scale);
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const float*)k, (const float*)v,
-                       (const float*)d_o, (const float*)lse, (const float*)delta, (float*)dq, T, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(ATT_T), kDkvLds, st, (const char*)qr, (const char*)qt, (const float*)k,
+                       (const float*)v, (const char*)dr, (const char*)dt, (const float*)lse, (const float*)delta, (float*)dk,
+                       (float*)dv, T, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr, (const char*)kt,
+                       (const char*)vr, (const float*)d_o, (const float*)lse, (const float*)delta, (float*)dq, T, scale);
     return pd::check_launch("pd_attn_bf16_bwd");
 }

@@ -831,8 +831,12 @@ class FlashAttentionFn(torch.autograd.Function):
         o = ops.empty_nhwc(N, C, H, W, q.device)
         lse = torch.empty((N, T), dtype=torch.float32, device=q.device)
         ctx.bf16 = USE_BF16_ATTENTION
-        fwd = lib.pd_attn_bf16_fwd if ctx.bf16 else lib.pd_attn_fwd
-        check(fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), N, T, C, scale, stream_ptr()), "pd_attn_fwd")
+        if ctx.bf16:
+            ws = ops._workspace(lib.pd_attn_bf16_workspace(N, T, C, 0), q.device)
+            check(lib.pd_attn_bf16_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(ws), ws.numel(), N, T, C, scale,
+                                       stream_ptr()), "pd_attn_bf16_fwd")
+        else:
+            check(lib.pd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), N, T, C, scale, stream_ptr()), "pd_attn_fwd")
         ctx.scale = scale
         ctx.save_for_backward(q, k, v, o, lse)
         return o
@@ -845,9 +849,13 @@ class FlashAttentionFn(torch.autograd.Function):
         do = ops.as_nhwc(do)
         dq, dk, dv = (ops.empty_nhwc(N, C, H, W, do.device) for _ in range(3))
         delta = torch.empty_like(lse)
-        bwd = lib.pd_attn_bf16_bwd if ctx.bf16 else lib.pd_attn_bwd
-        check(bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                  N, T, C, ctx.scale, stream_ptr()), "pd_attn_bwd")
+        if ctx.bf16:
+            ws = ops._workspace(lib.pd_attn_bf16_workspace(N, T, C, 1), q.device)
+            check(lib.pd_attn_bf16_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                       ptr(ws), ws.numel(), N, T, C, ctx.scale, stream_ptr()), "pd_attn_bf16_bwd")
+        else:
+            check(lib.pd_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                  N, T, C, ctx.scale, stream_ptr()), "pd_attn_bwd")
         return dq, dk, dv
 
 

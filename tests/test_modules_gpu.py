@@ -304,8 +304,9 @@ def test_bf16_attention_matches_fp32_attention_within_bf16_tolerance(shape):
     T_ = Hh * Ww
     o2 = torch.empty_like(qc.detach())
     lse = torch.empty((N, T_), device="cuda")
-    check(lib.pd_attn_bf16_fwd(ptr(qc.detach()), ptr(kc.detach()), ptr(vc.detach()), ptr(o2), ptr(lse), N, T_, 128,
-                               1.0 / 128 ** 0.5, stream_ptr()), "pd_attn_bf16_fwd")
+    ws = torch.empty(lib.pd_attn_bf16_workspace(N, T_, 128, 0), dtype=torch.uint8, device="cuda")
+    check(lib.pd_attn_bf16_fwd(ptr(qc.detach()), ptr(kc.detach()), ptr(vc.detach()), ptr(o2), ptr(lse), ptr(ws), ws.numel(),
+                               N, T_, 128, 1.0 / 128 ** 0.5, stream_ptr()), "pd_attn_bf16_fwd")
     assert (lse.cpu().double() - torch.logsumexp(scores.detach(), -1)).abs().max().item() < 2e-2
     assert torch.equal(o2, o.detach())
 
