@@ -18,7 +18,9 @@ class GraphedTrainStep:
     batch will have.  ``step(batch)`` copies the batch into the static input buffers, replays the graph and returns the
     (static) loss tensor; ``outputs`` / ``losses`` are the static dictionaries of the captured step."""
 
-    def __init__(self, tr, example_batch, warmup=3):
+    def __init__(self, tr, example_batch, warmup=3, restore_state=False):
+        """restore_state: run the warm-up steps on a snapshot (parameters, Adam moments, BatchNorm buffers, step counters are
+        put back afterwards), so that building the graph in the middle of a run does not consume training steps."""
         if getattr(tr, "distributed", False):
             raise NotImplementedError("GraphedTrainStep: the RCCL gradient exchange is not captured; use the eager step "
                                       "for multi-process runs")
@@ -28,6 +30,12 @@ class GraphedTrainStep:
         self.static = {k: v.to(dev).clone() for k, v in example_batch.items()}
         self.opt.use_device_step(True)
         tr.set_train()
+        snap = None
+        if restore_state:
+            from . import functional as PF
+            bufs = [t for m in tr.models.values() for t in m.buffers()]
+            snap = (tr.store.flat.clone(), self.opt.exp_avg.clone(), self.opt.exp_avg_sq.clone(), [t.clone() for t in bufs],
+                    PF.DropoutState.state(dev).clone(), self.opt.step_count)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                       # warm-up on a side stream, as stream capture requires
@@ -39,6 +47,17 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.outputs, self.losses = self._eager_step()
         self.opt.step_count -= 1           # the capture recorded a step without executing it
+        if snap is not None:
+            from . import functional as PF
+            flat, m, v, bvals, st, count = snap
+            tr.store.flat.copy_(flat); self.opt.exp_avg.copy_(m); self.opt.exp_avg_sq.copy_(v)
+            for t, b in zip([t for mod in tr.models.values() for t in mod.buffers()], bvals):
+                t.copy_(b)
+            PF.DropoutState.state(dev).copy_(st)
+            PF.DropoutState.state(dev)[1] = count
+            self.opt.step_count = count
+            tr.store.grad.zero_(); tr.store.mark_zeroed()
+            tr.store.weights_changed()
         self.loss = self.losses["loss"]
         self.replays = 0
 

@@ -49,20 +49,8 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(tmp_path):
             tr_g.model_optimizer.step()
             losses_g.append(L["loss"].detach().clone())
         else:
-            if gs is None:
-                # capture with warmup=1 on a scratch copy of the state: the warm-up step must not advance the real state
-                flat, m, v = tr_g.store.flat.clone(), tr_g.model_optimizer.exp_avg.clone(), tr_g.model_optimizer.exp_avg_sq.clone()
-                bn = [t.clone() for mod in tr_g.models.values() for t in mod.buffers()]
-                st = PF.DropoutState.state(tr_g.device).clone()
-                count = tr_g.model_optimizer.step_count
-                gs = GraphedTrainStep(tr_g, b, warmup=1)
-                tr_g.store.flat.copy_(flat); tr_g.model_optimizer.exp_avg.copy_(m); tr_g.model_optimizer.exp_avg_sq.copy_(v)
-                for t, s in zip([t for mod in tr_g.models.values() for t in mod.buffers()], bn):
-                    t.copy_(s)
-                tr_g.model_optimizer.step_count = count
-                PF.DropoutState.state(tr_g.device).copy_(st)
-                PF.DropoutState.state(tr_g.device)[1] = count
-                tr_g.store.grad.zero_()
+            if gs is None:       # built in the middle of the run: the warm-up step runs on a snapshot that is restored
+                gs = GraphedTrainStep(tr_g, b, warmup=1, restore_state=True)
             losses_g.append(gs.step(b).detach().clone())
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(zip(losses_e, losses_g)):
@@ -83,3 +71,23 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(tmp_path):
     host = time.perf_counter() - t0
     torch.cuda.synchronize()
     assert host < 2e-3, f"replay took {host * 1e3:.2f} ms of host time"
+
+
+def test_run_epoch_with_the_graphed_step_matches_the_eager_epoch(tmp_path, monkeypatch):
+    """Trainer.run_epoch (trainer.py:430-442) with PD_STEP_GRAPH=1: the graph is captured on the first batch of the loader
+    (warm-up on a snapshot), every batch is copied into the static inputs and replayed -- same parameters after the epoch
+    as the eager loop, step / epoch bookkeeping unchanged."""
+    from polardepth import functional as PF
+    out = []
+    for graph in ("0", "1"):
+        monkeypatch.setenv("PD_STEP_GRAPH", graph)
+        PF.DropoutState.manual_seed(5)
+        tr = _trainer(tmp_path, "epoch" + graph)
+        tr.opt.log_frequency = 10 ** 9          # no logging / validation inside the epoch
+        tr.step = 1
+        tr.run_epoch()
+        torch.cuda.synchronize()
+        assert tr.step == 1 + len(tr.train_loader)
+        out.append((tr.store.flat.clone(), tr.model_optimizer.step_count, tr.model_optimizer.exp_avg.clone()))
+    assert out[0][1] == out[1][1] > 0
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][2], out[1][2])
