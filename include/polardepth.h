@@ -358,6 +358,11 @@ int pd_loss_weights(const void* gvals, const int* scale_ids, int S, float w_norm
  * NCHW fp32.  Inactive under --depth_supervision_only; forward only. */
 int pd_ssim_fwd(const void* x, const void* y, void* out, int N, int C, int H, int W, int mode, int no_ssim,
                 void* stream);
+/* Gradient of pd_ssim_fwd w.r.t. both images: gout [N,C,H,W] (mode 0) or [N,1,H,W] (mode 1), gx / gy [N,C,H,W] (gy may be
+ * NULL), coef_ws 5*N*C*H*W floats.  Two launches: per-pixel coefficients of the five window means (with the clamp mask), then
+ * the gather over the (reflected) 3x3 windows that contain each pixel. */
+int pd_ssim_bwd(const void* x, const void* y, const void* gout, void* coef_ws, void* gx, void* gy, int N, int C, int H, int W,
+                int mode, int no_ssim, void* stream);
 /* compute_depth_errors (layers.py:539-557) per image on the device: metrics [N][8] = abs_rel, sq_rel, rmse,
  * rmse_log, a1, a2, a3, pixel count over min < gt < max (and mask == mask_value when mask != NULL, the
  * per-material selection of trainer.py:1385-1411); pred is clamped to [min, max] (trainer.py:1422-1423).

@@ -1123,6 +1123,93 @@ __global__ __launch_bounds__(LT) void ssim_kernel(const float* __restrict__ x, c
     }
 }
 
+// ---- SSIM backward (layers.py:468-499 differentiated; trainer.py:1069-1081 for the photometric mix)
+// Per pixel q and channel: f = clamp((1 - n/d) / 2, 0, 1), n = (2 mx my + C1)(2 sxy + C2), d = (mx^2 + my^2 + C1)(sx + sy + C2),
+// with the window means Sx, Sy, Sxx, Syy, Sxy (mx = Sx, sx = Sxx - Sx^2, sxy = Sxy - Sx Sy).  Pass A writes the five
+// coefficients G_S(q) = g_q [0 < f < 1] df/dS of every pixel; pass B gathers, for a source pixel p,
+//   dL/dx_p = 1/9 sum over windows q and taps t of q that land on p (reflection!) of G_Sx(q) + 2 x_p G_Sxx(q) + y_p G_Sxy(q)
+// and the same with x <-> y.  mode 1: g_q = 0.85 / C * gout[n, 0, q] for every channel, plus the L1 term 0.15 / C sign(x - y).
+__global__ __launch_bounds__(LT) void ssim_bwd_a_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ gout, float* __restrict__ coef, int N, int C,
+                                                        int H, int W, int mode) {
+    const long P = (long)H * W, total = (long)N * C * P;
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        int px, py;
+        long t = divmod(i, W, px);
+        t = divmod(t, H, py);
+        const long n = t / C;
+        const float* xp = x + t * P;
+        const float* yp = y + t * P;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = reflect1(py + dy, H);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = reflect1(px + dx, W);
+                const float a = xp[(long)yy * W + xx], b = yp[(long)yy * W + xx];
+                sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+            }
+        }
+        const float k = 1.f / 9.f;
+        const float mx = sx * k, my = sy * k;
+        const float vx = sxx * k - mx * mx, vy = syy * k - my * my, vxy = sxy * k - mx * my;
+        const float a = 2.f * mx * my + 1e-4f, b = 2.f * vxy + 9e-4f, c = mx * mx + my * my + 1e-4f, e = vx + vy + 9e-4f;
+        const float nn = a * b, dd = c * e;
+        const float f = (1.f - nn / dd) * 0.5f;
+        float g = mode == 0 ? gout[i] : gout[n * P + (long)py * W + px] * (0.85f / C);
+        if (!(f > 0.f && f < 1.f)) g = 0.f;                       // clamp
+        // df/dS = -(dn d - n dd') / (2 d^2)
+        const float s = -0.5f * g / (dd * dd);
+        const float dn_sx = 2.f * my * (b - a), dd_sx = 2.f * mx * (e - c);
+        const float dn_sy = 2.f * mx * (b - a), dd_sy = 2.f * my * (e - c);
+        float* o = coef + i;
+        o[0] = s * (dn_sx * dd - nn * dd_sx);                     // G_Sx
+        o[total] = s * (dn_sy * dd - nn * dd_sy);                 // G_Sy
+        o[2 * total] = s * (-nn * c);                             // G_Sxx  (dd/dSxx = c, dn/dSxx = 0)
+        o[3 * total] = s * (-nn * c);                             // G_Syy
+        o[4 * total] = s * (2.f * a * dd);                        // G_Sxy  (dn/dSxy = 2a, dd/dSxy = 0)
+    }
+}
+
+__global__ __launch_bounds__(LT) void ssim_bwd_b_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ gout, const float* __restrict__ coef,
+                                                        float* __restrict__ gx, float* __restrict__ gy, int N, int C, int H,
+                                                        int W, int mode, int no_ssim) {
+    const long P = (long)H * W, total = (long)N * C * P;
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        int px, py;
+        long t = divmod(i, W, px);
+        t = divmod(t, H, py);
+        const long n = t / C;
+        const float xv = x[i], yv = y[i];
+        float ax = 0.f, ay = 0.f;
+        if (!no_ssim) {
+            const float* cf = coef + t * P;
+            for (int qy = max(py - 2, 0); qy <= min(py + 2, H - 1); ++qy)
+                for (int qx = max(px - 2, 0); qx <= min(px + 2, W - 1); ++qx) {
+                    int mult = 0;                             // taps of window q that land on p after reflection
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx)
+                            mult += (reflect1(qy + dy, H) == py && reflect1(qx + dx, W) == px) ? 1 : 0;
+                    if (!mult) continue;
+                    const long q = (long)qy * W + qx;
+                    const float m = (float)mult;
+                    ax += m * (cf[q] + 2.f * xv * cf[2 * total + q] + yv * cf[4 * total + q]);
+                    ay += m * (cf[total + q] + 2.f * yv * cf[3 * total + q] + xv * cf[4 * total + q]);
+                }
+            ax *= 1.f / 9.f; ay *= 1.f / 9.f;
+        }
+        if (mode == 1) {
+            const float g = gout[n * P + (long)py * W + px] * ((no_ssim ? 1.f : 0.15f) / C);
+            const float sg = xv > yv ? 1.f : (xv < yv ? -1.f : 0.f);   // d|y - x| / dx = sign(x - y)
+            ax += g * sg; ay -= g * sg;
+        }
+        gx[i] = ax;
+        if (gy) gy[i] = ay;
+    }
+}
+
 // compute_depth_errors (layers.py:539-557) over the pixels selected by lo < gt < hi [and mask == mask_value],
 // per image: partial[block][9] = (count, sum|d|/gt, sum d^2/gt, sum d^2, sum dlog^2, a1, a2, a3, 0); the
 // prediction is clamped to [lo, hi] first like trainer.py:1422-1423.  One image per blockIdx.y.
@@ -1172,6 +1259,19 @@ extern "C" int pd_ssim_fwd(const void* x, const void* y, void* out, int N, int C
     hipLaunchKernelGGL(ssim_kernel, dim3(lgrid((long)N * H * W)), dim3(LT), 0, (hipStream_t)stream, (const float*)x,
                        (const float*)y, (float*)out, N, C, H, W, mode, no_ssim);
     return pd::check_launch("pd_ssim_fwd");
+}
+
+extern "C" int pd_ssim_bwd(const void* x, const void* y, const void* gout, void* coef_ws, void* gx, void* gy, int N, int C, int H,
+                           int W, int mode, int no_ssim, void* stream) {
+    PD_REQUIRE(x && y && gout && coef_ws && gx && N > 0 && C > 0 && H > 1 && W > 1, "pd_ssim_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = lgrid((long)N * C * H * W);
+    if (!no_ssim)
+        hipLaunchKernelGGL(ssim_bwd_a_kernel, dim3(grid), dim3(LT), 0, st, (const float*)x, (const float*)y, (const float*)gout,
+                           (float*)coef_ws, N, C, H, W, mode);
+    hipLaunchKernelGGL(ssim_bwd_b_kernel, dim3(grid), dim3(LT), 0, st, (const float*)x, (const float*)y, (const float*)gout,
+                       (const float*)coef_ws, (float*)gx, (float*)gy, N, C, H, W, mode, no_ssim);
+    return pd::check_launch("pd_ssim_bwd");
 }
 
 extern "C" int pd_depth_metrics(const void* gt, const void* pred, const void* mask, int mask_value, void* partial_ws,

@@ -88,8 +88,8 @@ class SSIM(nn.Module):
         self.C1, self.C2 = 0.01 ** 2, 0.03 ** 2
 
     def forward(self, x, y):
-        if x.is_cuda and not (x.requires_grad or y.requires_grad):
-            return ops.ssim(x, y)             # fused HIP kernel (forward only)
+        if x.is_cuda:
+            return ops.ssim(x, y)             # fused HIP kernels, forward and backward (pd_ssim_fwd / pd_ssim_bwd)
         x, y = self.refl(x), self.refl(y)
         mu_x, mu_y = self.pool(x), self.pool(y)
         sigma_x = self.pool(x ** 2) - mu_x ** 2

@@ -100,6 +100,7 @@ SIGNATURES = {
     "pd_disphead_workspace": (_sz, [_i]),
     "pd_disphead_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     "pd_disphead_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
+    "pd_ssim_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pd_ssim_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pd_depth_metrics": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _l, _f, _f, _vp]),
 }

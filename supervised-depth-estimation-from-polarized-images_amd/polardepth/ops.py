@@ -257,24 +257,44 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
     return (dw, dbias) if (want_bias or dbias is not None) else dw
 
 
+class _SSIMFn(torch.autograd.Function):
+    """layers.SSIM (mode 0: the [N,C,H,W] loss map) and compute_reprojection_loss (mode 1: [N,1,H,W]) with their gradients
+    w.r.t. both images (pd_ssim_fwd / pd_ssim_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, y, mode, no_ssim):
+        x, y = x.float().contiguous(), y.float().contiguous()
+        N, C, H, W = x.shape
+        out = torch.empty((N, C if mode == 0 else 1, H, W), dtype=torch.float32, device=x.device)
+        check(lib.pd_ssim_fwd(ptr(x), ptr(y), ptr(out), N, C, H, W, mode, int(no_ssim), stream_ptr()), "pd_ssim_fwd")
+        ctx.args = (mode, int(no_ssim))
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y = ctx.saved_tensors
+        mode, no_ssim = ctx.args
+        N, C, H, W = x.shape
+        gout = gout.float().contiguous()
+        ws = torch.empty(5 * x.numel(), dtype=torch.float32, device=x.device)
+        gx = torch.empty_like(x)
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        check(lib.pd_ssim_bwd(ptr(x), ptr(y), ptr(gout), ptr(ws), ptr(gx), ptr(gy), N, C, H, W, mode, no_ssim, stream_ptr()),
+              "pd_ssim_bwd")
+        return gx, gy, None, None
+
+
 def ssim(x, y):
-    """layers.SSIM forward on the GPU: planar NCHW fp32 -> SSIM loss map of the same shape."""
+    """layers.SSIM on the GPU: planar NCHW fp32 -> SSIM loss map of the same shape (differentiable in both images)."""
     _require_cuda(x, y)
-    x, y = x.float().contiguous(), y.float().contiguous()
-    N, C, H, W = x.shape
-    out = torch.empty_like(x)
-    check(lib.pd_ssim_fwd(ptr(x), ptr(y), ptr(out), N, C, H, W, 0, 0, stream_ptr()), "pd_ssim_fwd")
-    return out
+    return _SSIMFn.apply(x, y, 0, False)
 
 
 def reprojection_loss(pred, target, no_ssim=False):
-    """trainer.py:1069-1081: [N,1,H,W] = 0.85 * mean_c SSIM(pred, target) + 0.15 * mean_c |target - pred|."""
+    """trainer.py:1069-1081: [N,1,H,W] = 0.85 * mean_c SSIM(pred, target) + 0.15 * mean_c |target - pred| (differentiable)."""
     _require_cuda(pred, target)
-    pred, target = pred.float().contiguous(), target.float().contiguous()
-    N, C, H, W = pred.shape
-    out = torch.empty((N, 1, H, W), dtype=torch.float32, device=pred.device)
-    check(lib.pd_ssim_fwd(ptr(pred), ptr(target), ptr(out), N, C, H, W, 1, int(no_ssim), stream_ptr()), "pd_ssim_fwd")
-    return out
+    return _SSIMFn.apply(pred, target, 1, bool(no_ssim))
 
 
 def depth_metrics(gt, pred, min_depth, max_depth, mask=None, mask_value=0):

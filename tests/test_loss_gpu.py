@@ -193,6 +193,43 @@ def test_ssim_and_reprojection_loss_match_reference_fixture():
     _close(SSIM()(x, y), T(G5["ssim.out"]), 2e-5, "layers.SSIM")
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 3, 3, 4), (2, 1, 2, 9), (1, 3, 37, 21)])
+def test_ssim_backward_matches_autograd_of_the_reference_formula(shape):
+    """pd_ssim_bwd (both images, SSIM map and the 0.85 SSIM + 0.15 L1 photometric mix of trainer.py:1069-1081) against
+    torch autograd through the reference's formula (oracle.losses.ssim, layers.py:468-499) in fp64; images small enough that
+    both reflected borders of a window can fold onto the same pixel."""
+    from polardepth import ops
+    from oracle import losses as ol
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(N, C, H, W, generator=g)
+    y = (x + 0.15 * torch.randn(N, C, H, W, generator=g)).clamp(0, 1)        # correlated: the clamp is mostly inactive
+    w0 = torch.randn(N, C, H, W, generator=g)
+    w1 = torch.randn(N, 1, H, W, generator=g)
+    xr, yr = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    (ol.ssim(xr, yr) * w0.double()).sum().backward()
+    xc, yc = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    out = ops.ssim(xc, yc)
+    (out * w0.cuda()).sum().backward()
+    inner = ((out > 0) & (out < 1)).float().mean().item()
+    assert inner > 0.5
+    _close(xc.grad, xr.grad.float(), 2e-4, "d ssim / dx")
+    _close(yc.grad, yr.grad.float(), 2e-4, "d ssim / dy")
+    # photometric mix; |target - pred| has a kink where they are equal: none in random data
+    xr2, yr2 = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    rep = 0.85 * ol.ssim(xr2, yr2).mean(1, True) + 0.15 * (yr2 - xr2).abs().mean(1, True)
+    (rep * w1.double()).sum().backward()
+    xc2, yc2 = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    (ops.reprojection_loss(xc2, yc2) * w1.cuda()).sum().backward()
+    _close(xc2.grad, xr2.grad.float(), 2e-4, "d reprojection / d pred")
+    _close(yc2.grad, yr2.grad.float(), 2e-4, "d reprojection / d target")
+    xc3 = x.cuda().requires_grad_(True)
+    (ops.reprojection_loss(xc3, y.cuda(), no_ssim=True) * w1.cuda()).sum().backward()
+    xr3 = x.double().requires_grad_(True)
+    ((y.double() - xr3).abs().mean(1, True) * w1.double()).sum().backward()
+    _close(xc3.grad, xr3.grad.float(), 1e-6, "d L1 / d pred")
+
+
 def test_depth_metrics_match_reference_fixture():
     from polardepth import ops
     gt, pr = T(G5["err.gt"]), T(G5["err.pred"])          # 500 values in (0.2, 1.7): all inside (0.1, 2.0)
