@@ -121,22 +121,42 @@ def cpu_baseline():
     from oracle import polar as opolar
     host = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    step = _oracle_step_factory(2)
-    # thread sweep: one probe step per count after one warm-up step (oversubscribed intra-op threading makes "all cores"
-    # SLOWER than one thread on the 128-thread hosts of this pool), then warm-up 2 / median of 5 at the best count
+    t_begin = time.perf_counter()
+
+    def note(msg):               # progress on stderr: a silent multi-minute CPU phase reads as a hung run
+        print(f"[cpu_baseline +{time.perf_counter() - t_begin:5.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    # thread sweep at batch 1: one probe step per count after one warm-up step (oversubscribed intra-op threading makes
+    # "all cores" SLOWER than one thread on the 128-thread hosts of this pool); the sweep stops growing the thread count
+    # once a step gets slower or ~60 s are spent.  Then the best count: batch 2, warm-up 2, median of up to 5 steps within
+    # ~45 s.  One thread (the reference pins OMP/MKL_NUM_THREADS=1): batch 1, warm-up 1, median of 3.
+    probe = _oracle_step_factory(1)
     sweep = {}
-    for t in sorted({8, 16, 32, 64, host} & set(range(1, host + 1))):
+    for t in sorted({1, 8, 16, 32, 64, host} & set(range(1, host + 1))):
         torch.set_num_threads(t)
-        sweep[t] = _median_time(step, 1, 1)
+        sweep[t] = _median_time(probe, 1, 1)
+        note(f"{t} threads: {sweep[t]:.2f} s / step (batch 1)")
+        if time.perf_counter() - t_begin > 60 or (t > 1 and sweep[t] > 1.5 * min(sweep.values())):
+            break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    t_best = _median_time(step, 2, 5)
+    step = _oracle_step_factory(2)
+    ts = []
+    for i in range(7):
+        t0 = time.perf_counter()
+        step()
+        if i >= 2:
+            ts.append(time.perf_counter() - t0)
+        if i >= 4 and time.perf_counter() - t_begin > 60 + 45:
+            break
+    t_best = sorted(ts)[len(ts) // 2]
+    note(f"best: {best} threads, batch 2: {t_best:.2f} s / step (median of {len(ts)})")
     torch.set_num_threads(1)
     try:
-        step1 = _oracle_step_factory(1)
-        t_one = _median_time(step1, 1, 3)
+        t_one = _median_time(probe, 1, 3) if 1 not in sweep or sweep[1] < 8 else sweep[1]
     finally:
         torch.set_num_threads(default_threads)
+    note(f"1 thread, batch 1: {t_one:.2f} s / step")
     rng = np.random.default_rng(1)
     frame = rng.integers(0, 256, (H, FRAME_W, 4), dtype=np.uint8)
     P = H * FRAME_W
@@ -147,8 +167,8 @@ def cpu_baseline():
     return {"value": round(2 / t_best, 4), "unit": "images/s", "cores": best, "kind": "port",
             "sample": f"oracle/ (PyTorch-CPU + NumPy/SciPy restatement of the reference) train step of the same 3-encoder "
                       f"512x640 workload at batch 2 on the best thread count of a sweep ({best} of {host} host threads): "
-                      f"warm-up 2, median of 5 = {t_best:.2f} s/step",
-            "thread_sweep_s_per_step": {str(k): round(v, 2) for k, v in sweep.items()},
+                      f"warm-up 2, median of {len(ts)} = {t_best:.2f} s/step",
+            "thread_sweep_s_per_step_batch1": {str(k): round(v, 2) for k, v in sweep.items()},
             "host_threads": host,
             "one_thread": {"value": round(1 / t_one, 4), "unit": "images/s", "cores": 1,
                            "sample": f"same step at batch 1, torch.set_num_threads(1) (the reference pins OMP/MKL_NUM_THREADS=1, "
@@ -366,6 +386,24 @@ def main():
     time_k1(K1_SETS, 6)
     k1_ms = time_k1(K1_SETS)
     k1_ms_warm = time_k1(1)
+    # K1 on a batch large enough that launch / prologue / drain no longer weigh (SURVEY.md §7 hard part 7: "report GB/s vs B")
+    k1_big = None
+    try:
+        BIG = 128
+        big_pol = pol.repeat(BIG // args.batch + 1, 1, 1, 1)[:BIG].contiguous()
+        big_out = pdpolar.polar_forward(big_pol, want=("xolp", "normals"), out_width=W)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+        for e0, e1 in evs:
+            e0.record()
+            pdpolar.polar_forward(big_pol, want=("xolp", "normals"), out_width=W, out=big_out)
+            e1.record()
+        torch.cuda.synchronize()
+        big_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[len(evs) // 2]
+        k1_big = {"batch": BIG, "avg_launch_ms": round(big_ms, 4), "GBps": round(BIG * H * FRAME_W * 48 / big_ms / 1e6, 1),
+                  "frac": round(BIG * H * FRAME_W * 48 / big_ms / 1e6 / 8000.0, 4)}
+        del big_pol, big_out
+    except Exception as exc:
+        k1_big = {"error": str(exc)[:200]}
     k1_bytes = args.batch * H * FRAME_W * 48
     # `achieved` is the launch INSIDE the training step (what a rocprof trace of this command shows): the step streams
     # gigabytes between two K1 launches, so K1 starts with its LUT / table image evicted and the caches holding the
@@ -377,8 +415,12 @@ def main():
                    "back_to_back": {"buffer_sets": K1_SETS, "avg_launch_ms": round(k1_ms, 4),
                                     "GBps": round(k1_bytes / k1_ms / 1e6, 1), "frac": round(k1_bytes / k1_ms / 1e6 / 8000.0, 4),
                                     "cache_resident_GBps": round(k1_bytes / k1_ms_warm / 1e6, 1)},
-                   "streaming_ceiling_note": "same access shape, trivial compute, B=16: 4.9-5.0 TB/s back to back, "
-                                             "3.7 TB/s after a cache-replacing predecessor (tools/membench2.hip d)"}
+                   "batch_128": k1_big,
+                   "streaming_ceiling_note": "same access shape with trivial compute at this size (B=16, 240 MB, after a "
+                                             "cache-replacing predecessor, i.e. the state the step leaves behind): 43-50 us = "
+                                             "4.8-5.6 TB/s for the best read schedule (tools/membench3.hip, "
+                                             "profiles/r03_membench3_read_schedules.log); the kernel's own issue phase ends "
+                                             "after ~36 us, the rest is launch + HBM write drain (profiles/r03_k1_timeline.log)"}
     del pols, k1_outs
 
     attention = None
