@@ -602,7 +602,7 @@ __device__ __forceinline__ void advance(QuadPos& q, const PolarGeo& g) {
 // polynomials.  The small LUT fits every XCD's L2 and is pulled in by a prologue prefetch -- inside the training step K1
 // starts with cold caches, and the scattered first-touch misses of the big LUT (every XCD fetches every line it needs
 // from HBM, behind K1's own write stream) stretched every iteration of the loop, not just the first.
-template <int MODE, int OUT, int NTH, bool NT, bool HOT = false, bool LUT4 = false>
+template <int MODE, int OUT, int NTH, bool NT, bool HOT = false, bool LUT4 = false, bool NTL = false>
 __global__ __launch_bounds__(NTH) void polar_kernel(
     const uint8_t* __restrict__ pol, const uint8_t* __restrict__ mask, float* __restrict__ xolp,
     float* __restrict__ xolp_std, float* __restrict__ normals, int* __restrict__ ints,
@@ -631,11 +631,21 @@ __global__ __launch_bounds__(NTH) void polar_kernel(
         Words w = {0u, 0u, 0u, 0u};
         if (p.b < g.B && p.cq < g.wq_in) {
             const unsigned p4 = static_cast<unsigned>(p.b) * 4u * g.P + p.row * in_row + 4u * p.cq;
-            // read-once stream: nontemporal (no L2 / Infinity-Cache allocation that would push out the LUT and tables)
-            w.w0 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + p4));
-            w.w45 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + (p4 + g.P)));
-            w.w90 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P)));
-            w.w135 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P)));
+            // NTL: the nontemporal hint on this read-once stream (no L2 / Infinity-Cache allocation that would push out the LUT and
+            // tables).  Measured both ways (bench.py, tools/bench_polar.py): with the hint the kernel starts faster from the cache
+            // state the training step leaves behind (B = 16 inside the step: 57-64 us against 68-73) but runs a third slower in
+            // steady state (B = 128 back to back: 3.4-3.7 against 5.1-5.9 TB/s) -- the host picks it for short launches only.
+            if (NTL) {
+                w.w0 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + p4));
+                w.w45 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + (p4 + g.P)));
+                w.w90 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P)));
+                w.w135 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P)));
+            } else {
+                w.w0 = *reinterpret_cast<const uint32_t*>(pol + p4);
+                w.w45 = *reinterpret_cast<const uint32_t*>(pol + (p4 + g.P));
+                w.w90 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 2u * g.P));
+                w.w135 = *reinterpret_cast<const uint32_t*>(pol + (p4 + 3u * g.P));
+            }
         }
         return w;
     };
@@ -1026,8 +1036,15 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
             else if (!nt) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, false>);
             else if (nth == 256) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 256, true>);
             else if (nth == 512) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, true>);
-            else if (xolp && normals && !xolp_std && !ints)
-                rc = lut4 ? go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, true>) : go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true>);
+            else if (xolp && normals && !xolp_std && !ints) {
+                // the training step's output set; nontemporal plane loads for launches of up to 32 frames' worth of 512x640
+                // output (see load_words)
+                static const int ntl_env = [] { const char* e = getenv("PD_POLAR_NT_LOADS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+                const bool ntl = ntl_env >= 0 ? ntl_env != 0 : total * 4 <= 32L * 512 * 640;
+                rc = lut4 ? go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, true, true>)
+                          : ntl ? go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, false, true>)
+                                : go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, false, false>);
+            }
             else rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true>);
         } else {
             if (!need_normals) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_XOLP, kThreads, true>);

@@ -78,6 +78,68 @@ def test_all_difference_pairs_exhaustive():
     _check_against_oracle(np.stack(planes))
 
 
+def _check_training_output_set(pol_np, **kw):
+    """want = (xolp, normals) is the training step's output set and runs polar_hot_kernel (quadrant LUT for AoLP / cos / sin,
+    DoLP as one fp64 multiply of tabulated sqrt(s4) and 2 / S + rounding test, packed-fp32 theta polynomials): DoLP / AoLP
+    bit-exact vs the oracle, normals within the stated tolerance, and every output equal or within 1e-6 of the general
+    kernel's (PD_POLAR_GENERAL=1 is read once per process, so the general kernel is reached through a third output)."""
+    got = _run(pol_np, want=("xolp", "normals"), **kw)
+    gen = _run(pol_np, want=("xolp", "normals", "ints"), **kw)
+    assert torch.equal(got["xolp"].view(torch.int32), gen["xolp"].view(torch.int32))
+    np.testing.assert_allclose(got["normals"].numpy(), gen["normals"].numpy(), rtol=0, atol=1e-6)
+    if not kw:
+        xolp, _, normals, _ = opolar.polar_forward(pol_np)
+        assert torch.equal(got["xolp"], xolp), "DoLP/AoLP of the training-step kernel must be bit-exact"
+        np.testing.assert_allclose(got["normals"].numpy(), normals.numpy(), rtol=0, atol=NORMALS_ATOL)
+    return got
+
+
+def test_training_step_kernel_vs_oracle_and_general_kernel(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_xolp.npz"))
+    for name in ("rnd", "phys"):
+        _check_training_output_set(np.ascontiguousarray(np.moveaxis(g[name + "_img"], -1, 0)[None]))
+    # every (d1, d2) at the darkest and a bright offset (the whole AoLP domain, every quadrant-LUT entry and sign case)
+    d = np.arange(-255, 256)
+    d2, d1 = np.meshgrid(d, d, indexing="ij")
+    planes = []
+    for off_frac in (0.0, 1.0):
+        i0 = np.maximum(d1, 0); i90 = np.maximum(-d1, 0)
+        i45 = np.maximum(d2, 0); i135 = np.maximum(-d2, 0)
+        o1 = ((255 - np.maximum(i0, i90)) * off_frac).astype(int); o2 = ((255 - np.maximum(i45, i135)) * off_frac).astype(int)
+        p = np.stack([i0 + o1, i45 + o2, i90 + o1, i135 + o2]).astype(np.uint8)
+        planes.append(np.pad(p, ((0, 0), (0, 1), (0, 1)), mode="edge"))
+    _check_training_output_set(np.stack(planes))
+    rng = np.random.default_rng(11)
+    pol = rng.integers(0, 256, (3, 4, 64, 100), dtype=np.uint8)
+    pol[0, :, :4] = 0; pol[0, :, 4:8] = 255
+    pol[1, 0, :8] = 255; pol[1, 1:, :8] = 0          # rho == 2: far beyond every table (fp64 fix-up of the quad)
+    pol[2, 1] = pol[2, 3]
+    _check_training_output_set(pol)
+    # pitched output: padding columns are zero in all eleven planes, the rest unchanged
+    pol = rng.integers(0, 256, (2, 4, 16, 36), dtype=np.uint8)
+    a = _check_training_output_set(pol)
+    b = _check_training_output_set(pol, out_width=64)
+    for k in ("xolp", "normals"):
+        assert torch.equal(b[k][..., :36], a[k]) and b[k][..., 36:].abs().max().item() == 0
+
+
+def test_training_step_kernel_dolp_on_all_2_32_inputs():
+    """polar_hot_kernel's DoLP (tabulated fp64 sqrt(s4) x tabulated fp64 2 / S, rounding test, literal sequence near fp32
+    midpoints) against PD_POLAR_IEEE_RHO on every uint8 quadruple; AoLP against the general kernel on the same sweep."""
+    idx = torch.arange(1 << 24, dtype=torch.int32, device="cuda")
+    planes = torch.empty((1, 4, 4096, 4096), dtype=torch.uint8, device="cuda")
+    planes[0, 1] = ((idx >> 16) & 255).to(torch.uint8).view(4096, 4096)
+    planes[0, 2] = ((idx >> 8) & 255).to(torch.uint8).view(4096, 4096)
+    planes[0, 3] = (idx & 255).to(torch.uint8).view(4096, 4096)
+    hot, ieee = {}, {}
+    for i0 in range(256):
+        planes[0, 0].fill_(i0)
+        hot = pdpolar.polar_forward(planes, want=("xolp", "normals"), out=hot)
+        ieee = pdpolar.polar_forward(planes, want=("xolp",), out=ieee, ieee_rho=True)
+        assert torch.equal(hot["xolp"].view(torch.int32), ieee["xolp"].view(torch.int32)), f"I0={i0}"
+        assert bool(torch.isfinite(hot["normals"]).all()), f"I0={i0}"
+
+
 def test_random_uint8_and_degenerate():
     rng = np.random.default_rng(5)
     pol = rng.integers(0, 256, (3, 4, 64, 100), dtype=np.uint8)
@@ -127,8 +189,15 @@ def test_full_size_properties():
     pol = torch.randint(0, 256, (8, 4, 512, 612), dtype=torch.uint8, generator=g)
     full = _run(pol.numpy(), want=("xolp", "normals", "ints"))
     # (1) batching invariance: image 5 alone == image 5 inside the batch (bit-exact)
-    one = _run(pol[5:6].numpy(), want=("xolp", "normals"))
+    one = _run(pol[5:6].numpy(), want=("xolp", "normals", "ints"))
     assert torch.equal(one["xolp"][0], full["xolp"][5]) and torch.equal(one["normals"][0], full["normals"][5])
+    # ... and for the training step's output set (polar_hot_kernel): bit-identical inside / outside the batch, DoLP / AoLP
+    # bit-identical to the general kernel, normals within 1e-6 of it
+    hot = _run(pol.numpy(), want=("xolp", "normals"))
+    hot1 = _run(pol[5:6].numpy(), want=("xolp", "normals"))
+    assert torch.equal(hot1["xolp"][0], hot["xolp"][5]) and torch.equal(hot1["normals"][0], hot["normals"][5])
+    assert torch.equal(hot["xolp"], full["xolp"])
+    assert (hot["normals"] - full["normals"]).abs().max().item() < 1e-6
     # (2) swapping 0<->90 and 45<->135 negates (d1,d2): DoLP bit-identical, AoLP shifts by pi/2 mod pi
     sw = _run(pol[:2, [2, 3, 0, 1]].contiguous().numpy(), want=("xolp", "ints"))
     assert torch.equal(sw["xolp"][:, 0], full["xolp"][:2, 0])
