@@ -903,6 +903,10 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
                      pd::aligned16(x) && pd::aligned16(w);
     hipStream_t st = (hipStream_t)stream;
     const int bm = pd_conv2d_tile_m(a.M, Co);
+    // 96 output columns (the data gradient of the decoder's 96 -> 32 layer): three 32-wide column tiles instead of a full and a
+    // half-empty 64-wide one (a quarter of the matrix work of that launch was padding)
+    static const bool n96 = [] { const char* e = getenv("PD_CONV_N96"); return !(e && e[0] == '0'); }();
+    if (Co == 96 && n96 && bm == 128) return launch_conv<128, 32, 32, 32>(a, vec, st);
     if (Co > 32) return bm == 128 ? launch_conv<128, 64, 64, 32>(a, vec, st) : launch_conv<64, 64, 32, 32>(a, vec, st);
     if (Co > 16) return launch_conv<128, 32, 32, 32>(a, vec, st);
     return launch_conv<128, 16, 32, 16>(a, vec, st);   // 16x16x4 MFMA tiles

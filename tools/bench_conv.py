@@ -21,6 +21,7 @@ SHAPES = [  # name, C, H, W, Co, k, s, p, mode
     ("joint.Conv2 5x5 256->512 @32x40", 256, 32, 40, 512, 5, 1, 2, 0),
     ("joint.ResBlock5 3x3 512 @16x20", 512, 16, 20, 512, 3, 1, 1, 0),
     ("dec.upconv(1,1) 96->32 @256x320 refl", 96, 256, 320, 32, 3, 1, 1, 1),
+    ("dec.upconv(1,1) as zero-pad 96->32 @256x320 (dgrad)", 96, 256, 320, 32, 3, 1, 1, 0),
     ("dec.upconv(0,1) 16->16 @512x640 refl", 16, 512, 640, 16, 3, 1, 1, 1),
     ("stem normals 7x7s2 9->64 @512x640", 9, 512, 640, 64, 7, 2, 3, 0),
 ]
