@@ -32,9 +32,14 @@ constexpr float kLog2e = 1.4426950408889634f;
 // what the bf16 probabilities resolve.  Forward 0.46 -> 0.43 ms; with the operands pre-packed into bf16 tile images (below:
 // no conversion / address arithmetic in the loop) 0.37 ms.  Measured without effect or worse on top of that (round 3): a
 // prefetch distance of two blocks, two query groups per wave (half the LDS reads per MFMA, but one wave per SIMD:
-// 0.79 ms), packed fp32 softmax arithmetic with compile-time LDS buffers (0.39 ms) -- the loop is bound by the dependent
-// chain LDS read -> 8 chained MFMAs -> max / exp / sum across the half-waves -> 8 MFMAs of one wave, which three waves
-// per SIMD do not cover.
+// 0.79 ms), packed fp32 softmax arithmetic with compile-time LDS buffers (0.39 ms); 64 keys per step with two independent
+// score chains, one softmax pass and one barrier per 32 MFMAs, tiles staged by direct-to-LDS loads (64 KB of LDS: two
+// workgroups per CU): 0.39 ms, and with five or six waves per workgroup (one round of the chip instead of 1.25) 0.56-0.60.
+// What bounds the loop is LDS bandwidth: with 32 queries per wave every A fragment (1 KiB of K rows or V^T rows) read
+// from LDS feeds exactly ONE 32x32x16 MFMA (32 cycles of one SIMD); four SIMDs at full rate would need 128 B/clk -- all the
+// LDS of a CU delivers -- and the 8-byte reads of the transposed tile run at half that.  A quarter of the bf16 peak is the
+// ceiling of this layout; beyond it a wave has to keep 64 queries (two B operands per A fragment), i.e. one wave per SIMD
+// with the softmax of one query group scheduled by hand into the MFMAs of the other.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ bf16x4 cvt4(float a, float b, float c, float d) {
