@@ -10,7 +10,8 @@
 // An accumulator of the 32x32 tile holds column lane&31 and rows (r&3)+8(r>>2)+4(lane>>5): converted pairwise to
 // bf16, registers 8s..8s+7 ARE the B fragment of k-step s of the next product, with the contraction index permuted
 // to 16s + 8(j>>2) + 4h + (j&3); the A fragments are read in the same order from a TRANSPOSED LDS tile
-// ([channel][token], 8-byte units of 4 tokens), which the staging threads write next to the row-major tile.
+// ([channel][token], 16-byte units holding a fragment's eight tokens in fragment order), which attn_pack_kernel writes next
+// to the row-major tile.
 #include "pd_common.h"
 
 namespace {
@@ -63,8 +64,11 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
 // row-major [32 tokens][128 ch] bf16: 256-byte rows, 16-byte slots XOR-swizzled by the token (conflict-free
 // ds_read_b128 of one slot column over 32 rows)
 __device__ __forceinline__ int row_off(int tok, int slot) { return tok * 256 + 16 * (slot ^ (tok & 15)); }
-// transposed [128 ch][32 tokens] bf16: 64-byte rows, 8-byte units (4 tokens) XOR-swizzled by channel / 4
-__device__ __forceinline__ int tr_off(int ch, int unit) { return ch * 64 + 8 * (unit ^ ((ch >> 2) & 7)); }
+// transposed [128 ch][32 tokens] bf16: 64-byte rows of four 16-byte units; unit 2s + h holds the eight tokens of the A
+// fragment of k-step s, half-wave h, IN FRAGMENT ORDER (16s + 4h + 0..3, then 16s + 8 + 4h + 0..3): one ds_read_b128 per
+// fragment (two ds_read_b64 of a token-ordered row ran the LDS at half its rate -- and the LDS feeds every MFMA of these
+// kernels, see fast_exp2).  Units XOR-swizzled by channel / 2: eight consecutive channels cover all 32 banks.
+__device__ __forceinline__ int tr_off(int ch, int unit16) { return ch * 64 + 16 * (unit16 ^ ((ch >> 1) & 3)); }
 
 // staging: thread t holds tokens 4u .. 4u+3 (u = t >> 5) x channels 4c4 .. 4c4+3 (c4 = t & 31) of a block
 struct Stage { float4 v[4]; };
@@ -85,10 +89,12 @@ __device__ __forceinline__ void store_rows(char* tile, const Stage& s, int tid) 
 }
 __device__ __forceinline__ void store_transposed(char* tile, const Stage& s, int tid) {
     const int c4 = tid & 31, u = tid >> 5;
-    *reinterpret_cast<bf16x4*>(tile + tr_off(4 * c4 + 0, u)) = cvt4(s.v[0].x, s.v[1].x, s.v[2].x, s.v[3].x);
-    *reinterpret_cast<bf16x4*>(tile + tr_off(4 * c4 + 1, u)) = cvt4(s.v[0].y, s.v[1].y, s.v[2].y, s.v[3].y);
-    *reinterpret_cast<bf16x4*>(tile + tr_off(4 * c4 + 2, u)) = cvt4(s.v[0].z, s.v[1].z, s.v[2].z, s.v[3].z);
-    *reinterpret_cast<bf16x4*>(tile + tr_off(4 * c4 + 3, u)) = cvt4(s.v[0].w, s.v[1].w, s.v[2].w, s.v[3].w);
+    // tokens 4u .. 4u+3 = k-step u >> 2, upper / lower four of the fragment (u >> 1) & 1, half-wave u & 1
+    const int unit = 2 * (u >> 2) + (u & 1), half = 8 * ((u >> 1) & 1);
+    *reinterpret_cast<bf16x4*>(tile + tr_off(4 * c4 + 0, unit) + half) = cvt4(s.v[0].x, s.v[1].x, s.v[2].x, s.v[3].x);
+    *reinterpret_cast<bf16x4*>(tile + tr_off(4 * c4 + 1, unit) + half) = cvt4(s.v[0].y, s.v[1].y, s.v[2].y, s.v[3].y);
+    *reinterpret_cast<bf16x4*>(tile + tr_off(4 * c4 + 2, unit) + half) = cvt4(s.v[0].z, s.v[1].z, s.v[2].z, s.v[3].z);
+    *reinterpret_cast<bf16x4*>(tile + tr_off(4 * c4 + 3, unit) + half) = cvt4(s.v[0].w, s.v[1].w, s.v[2].w, s.v[3].w);
 }
 // A fragment of k-step g (channels 16g + 8h ..) of row `tok` of a row-major tile
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int tok, int g, int h) {
@@ -96,11 +102,7 @@ __device__ __forceinline__ bf16x8 row_frag(const char* tile, int tok, int g, int
 }
 // A fragment of k-step s (tokens 16s + 8(j>>2) + 4h + (j&3)) of channel row `ch` of a transposed tile
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int ch, int s, int h) {
-    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tile + tr_off(ch, 4 * s + h));
-    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tile + tr_off(ch, 4 * s + 2 + h));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
+    return *reinterpret_cast<const bf16x8*>(tile + tr_off(ch, 2 * s + h));
 }
 // the wave's own token as eight B fragments: X[tok][16g + 8h + j] * s
 __device__ __forceinline__ void own_frags(const float* row, int h, float s, bf16x8 (&f)[HD / 16]) {
