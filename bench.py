@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--attention", action="store_true",
                     help="BASELINE configs[4] variant (single-head attention at the joint-encoder merge, fp32); "
                          "not the headline workload")
+    ap.add_argument("--normals_decoder", action="store_true",
+                    help="the arch1++_separate_normals_dec variant (README.md:54: a decoder behind the normals encoder predicts "
+                         "normals, supervised by the normals of the ground truth); not the headline workload")
     ap.add_argument("--bf16", action="store_true",
                     help="with --attention: the attention block on the bf16 matrix cores (configs[4] as specified: "
                          "v_mfma_f32_32x32x16_bf16, fp32 softmax statistics and accumulators); the JSON line then carries "
@@ -201,6 +204,8 @@ def main():
     args = ap.parse_args()
     if args.attention:
         os.environ["PD_JOINT_ATTENTION"] = "1"
+    if args.normals_decoder:
+        os.environ["PD_NORMALS_DECODER"] = "1"
     if args.bf16:
         assert args.attention, "--bf16 selects the bf16 attention kernels: use it with --attention"
         os.environ["PD_ATTENTION_BF16"] = "1"
@@ -458,7 +463,8 @@ def main():
         "config": {"workload": "BASELINE configs[2]: full 3-encoder (augment_xolp+augment_normals), multi-scale loss "
                                "scales=[0,1,2,3], batch 16 per GPU, 512x612 frames (network/loss on 512x640 padded), "
                                "dropout 0.1, Adam lr 1e-4, fp32" + (" + joint-encoder attention (configs[4] variant)"
-                                                                   if args.attention else ""),
+                                                                   if args.attention else "") +
+                               (" + separate normals decoder (arch1++_separate_normals_dec variant)" if args.normals_decoder else ""),
                    "global_batch": args.batch * world, "height": H, "width": W, "frame_width": FRAME_W,
                    "parallelism": f"dp{world}"},
         "final_loss": round(loss_val, 6), "host_enqueue_ms_per_step": None if t_host is None else round(t_host * 1e3, 2),
@@ -473,7 +479,7 @@ def main():
         if args.bf16:
             result["dtype"] = "f32 (network) + bf16 attention operands"
             result["config"]["workload"] += " on the bf16 matrix cores"
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.attention:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.attention and not args.normals_decoder:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result), flush=True)

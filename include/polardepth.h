@@ -313,6 +313,17 @@ int pd_sup_loss_fwd(const void* pred, const void* gt, const void* K, const void*
  * floats; the ratio is formed on the device from an ordered fp64 sum of the partials. */
 int pd_normals_loss_masked(const void* pred, const void* gt, const void* K, const void* mask, void* partial_ws, void* out,
                            int N, int H, int W, void* stream);
+/* Loss of PREDICTED normals -- the `arch1++_separate_normals_dec` variant (reference README.md:54: "the decoder directly
+ * predicts normals; these normals are compared with normals calculated from ground truth"; its source is not in the reference
+ * checkout, the formula is trainer.py:1298-1309 with the network's 3-channel output in place of depth_to_normals(pred)):
+ * out[0] = sum((2 - cos(pred, n_gt)) m) / sum(m), out[1] = sum(m); pred pixel-major (NHWC) fp32 with pixel stride ld >= 3,
+ * gt_normals from pd_gt_normals, m = gt depth inside [min_depth, max_depth].  partial_ws: pd_loss_rows(N*H*W) * 2 floats.
+ * _bwd: dpred = gout[0] / out[1] * m * -(d cos / d pred), written for every pixel (zeros outside the mask). */
+int pd_normals_pred_loss_fwd(const void* pred, long ld, const void* gt_normals, const void* gt, void* partial_ws, void* out,
+                             int N, int H, int W, float min_depth, float max_depth, void* stream);
+int pd_normals_pred_loss_bwd(const void* pred, long ld, const void* gt_normals, const void* gt, const void* gout,
+                             const void* loss_count, void* dpred, long ld_dpred, int N, int H, int W, float min_depth,
+                             float max_depth, void* stream);
 /* The loop over scales of trainer.py:1134-1265 in one call: the per-scale kernels above dispatched by blockIdx.y = scale
  * with each scale's own grid (identical partial sums, hence identical bits), the supervised forward pass reading the
  * ground truth once for all scales: 4 launches forward, 4 + a memset backward, whatever S <= 8.

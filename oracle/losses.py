@@ -82,6 +82,14 @@ def normals_loss(depth_gt, depth_pred, intrinsics, mask):
     return ((2 * torch.ones_like(cos) - cos) * mask).sum() / mask.sum()
 
 
+def normals_pred_loss(normals_pred, depth_gt, intrinsics, min_depth=0.1, max_depth=2.0):
+    """Loss of the `arch1++_separate_normals_dec` variant (README.md:54): the formula of trainer.py:1298-1309 with the
+    network's 3-channel output in place of depth_to_normals(depth_pred), masked by the depth range (trainer.py:1242-1243)."""
+    mask = ((depth_gt >= min_depth) & (depth_gt <= max_depth)).float()
+    cos = F.cosine_similarity(depth_to_normals(depth_gt, intrinsics[:, :3, :3]), normals_pred, dim=1).unsqueeze(1)
+    return ((2 * torch.ones_like(cos) - cos) * mask).sum() / mask.sum()
+
+
 def upsample_disp_to_depth(disp, H, W, min_depth, max_depth):
     """trainer.py:538-543."""
     up = F.interpolate(disp, [H, W], mode="bilinear", align_corners=False)

@@ -257,6 +257,24 @@ class DepthDecoder(nn.Module):
         return out
 
 
+class NormalsDecoder(nn.Module):
+    """The `arch1++_separate_normals_dec` variant (reference README.md:54: "an additional decoder after the normals encoder.
+    The decoder directly predicts normals").  Its source is not in the reference checkout; this build defines it with the
+    reference's own decoder blocks (depth_decoder.py:29-67, layers.py:329-380): three times ConvBlock (reflect Conv3x3 + ELU)
+    followed by bilinear x2 -- 64 -> 32 -> 16 -> 16 channels, H/8 -> H -- and a Conv3x3 head with three output channels (the raw
+    normal; the loss normalises it).  ``decoder.0..2`` = the ConvBlocks in execution order, ``decoder.3`` = the head."""
+
+    def __init__(self, num_ch_in=64, num_ch_dec=(32, 16, 16)):
+        super().__init__()
+        chans = [int(num_ch_in)] + [int(c) for c in num_ch_dec]
+        self.decoder = nn.ModuleList([DecConv(chans[i], chans[i + 1]) for i in range(len(num_ch_dec))] + [Conv3x3(chans[-1], 3)])
+
+    def forward(self, x):
+        for blk in list(self.decoder)[:-1]:
+            x = upsample(blk(x))
+        return self.decoder[-1](x)
+
+
 def build_models(augment_xolp=True, augment_normals=True, dropout_rate=0.1, scales=range(4), seed=0):
     """The five modules of trainer.py:192-216 with a seeded init."""
     torch.manual_seed(seed)

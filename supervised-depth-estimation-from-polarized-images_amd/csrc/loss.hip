@@ -304,6 +304,68 @@ __global__ __launch_bounds__(256) void ratio_of_partials_kernel(const float* __r
     if (threadIdx.x == 0) out[0] = (float)(s0[0] / s1[0]);
 }
 
+// ---- loss of PREDICTED normals (the `arch1++_separate_normals_dec` variant, README.md:54: "the decoder directly predicts
+// normals; these are compared with normals calculated from ground truth"): sum((2 - cos(n_pred, n_gt)) m) / sum(m), the
+// formula of trainer.py:1298-1309 with the network's own 3-channel output in place of the normals of the predicted depth.
+// pred: pixel-major (NHWC) with pixel stride ld >= 3; gtn: pd_gt_normals; m = ground-truth depth inside [min, max].
+__global__ __launch_bounds__(LT) void normals_pred_fwd_kernel(const float* __restrict__ pred, long ld, const float4* __restrict__ gtn,
+                                                              const float* __restrict__ gt, float* __restrict__ partial,
+                                                              long total, float min_d, float max_d) {
+    __shared__ float sm[4 * 2];
+    float acc[2] = {0.f, 0.f};
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const float g = gt[i];
+        if (!(g >= min_d && g <= max_d)) continue;
+        const float4 q = gtn[i];
+        const V3 ng{q.x, q.y, q.z}, np_{pred[i * ld], pred[i * ld + 1], pred[i * ld + 2]};
+        const float n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f), n2 = fmaxf(sqrtf(dot(np_, np_)), 1e-8f);
+        acc[0] += 2.f - ((ng.x / n1) * (np_.x / n2) + (ng.y / n1) * (np_.y / n2) + (ng.z / n1) * (np_.z / n2));
+        acc[1] += 1.f;
+    }
+    block_sum<2>(acc, sm);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = acc[0]; partial[blockIdx.x * 2 + 1] = acc[1]; }
+}
+
+// out[0] = sum(p0) / sum(p1), out[1] = sum(p1): ordered fp64 sums of the partial rows
+__global__ __launch_bounds__(256) void ratio_and_count_kernel(const float* __restrict__ partial, int rows, float* __restrict__ out) {
+    __shared__ double s0[256], s1[256];
+    double a = 0.0, b = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) { a += partial[2 * r]; b += partial[2 * r + 1]; }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { s0[threadIdx.x] += s0[threadIdx.x + k]; s1[threadIdx.x] += s1[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = (float)(s0[0] / s1[0]); out[1] = (float)s1[0]; }
+}
+
+// d loss / d pred = gout / count * m * -(d cos / d pred);  cos = <gh, p> / |p|  =>  d cos / d p = gh / |p| - <gh, p> p / |p|^3
+__global__ __launch_bounds__(LT) void normals_pred_bwd_kernel(const float* __restrict__ pred, long ld, const float4* __restrict__ gtn,
+                                                              const float* __restrict__ gt, const float* __restrict__ gout,
+                                                              const float* __restrict__ loss_count, float* __restrict__ dpred,
+                                                              long ldd, long total, float min_d, float max_d) {
+    const float scale = gout[0] / loss_count[1];
+    for (long i = blockIdx.x * (long)LT + threadIdx.x; i < total; i += (long)gridDim.x * LT) {
+        const float g = gt[i];
+        V3 d{0.f, 0.f, 0.f};
+        if (g >= min_d && g <= max_d) {
+            const float4 q = gtn[i];
+            const V3 ng{q.x, q.y, q.z}, p{pred[i * ld], pred[i * ld + 1], pred[i * ld + 2]};
+            const float n1 = fmaxf(sqrtf(dot(ng, ng)), 1e-8f);
+            const V3 gh{ng.x / n1, ng.y / n1, ng.z / n1};
+            const float pn = sqrtf(dot(p, p));
+            if (pn > 1e-8f) {              // (below the clamp the cosine is linear in p: d cos / d p = gh / 1e-8; never met in training)
+                const float inv = 1.f / pn, c = dot(gh, p) * inv * inv * inv;
+                d = V3{-scale * (gh.x * inv - c * p.x), -scale * (gh.y * inv - c * p.y), -scale * (gh.z * inv - c * p.z)};
+            } else {
+                d = V3{-scale * gh.x * 1e8f, -scale * gh.y * 1e8f, -scale * gh.z * 1e8f};
+            }
+        }
+        dpred[i * ldd] = d.x; dpred[i * ldd + 1] = d.y; dpred[i * ldd + 2] = d.z;
+    }
+}
+
 // (dL/dA_p, dL/dB_p) of the normals term at pixel p = (x, y) of one image (pass A of the backward pass); zero outside the
 // depth-range mask.  i = flat pixel index of p (for the cached ground-truth normal).
 __device__ __forceinline__ void normals_grad_ab(const float* __restrict__ pred_n, const float* __restrict__ gt_n,
@@ -901,6 +963,31 @@ extern "C" int pd_normals_loss_masked(const void* pred, const void* gt, const vo
     hipLaunchKernelGGL(ratio_of_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial_ws, rows,
                        (float*)out);
     return pd::check_launch("pd_normals_loss_masked");
+}
+
+extern "C" int pd_normals_pred_loss_fwd(const void* pred, long ld, const void* gt_normals, const void* gt, void* partial_ws,
+                                        void* out, int N, int H, int W, float min_depth, float max_depth, void* stream) {
+    PD_REQUIRE(pred && gt_normals && gt && partial_ws && out && N > 0 && H > 0 && W > 0 && ld >= 3 && pd::aligned16(gt_normals),
+               "pd_normals_pred_loss_fwd: bad arguments");
+    const long total = (long)N * H * W;
+    const int rows = (int)lgrid(total);
+    hipLaunchKernelGGL(normals_pred_fwd_kernel, dim3(rows), dim3(LT), 0, (hipStream_t)stream, (const float*)pred, ld,
+                       (const float4*)gt_normals, (const float*)gt, (float*)partial_ws, total, min_depth, max_depth);
+    hipLaunchKernelGGL(ratio_and_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial_ws, rows,
+                       (float*)out);
+    return pd::check_launch("pd_normals_pred_loss_fwd");
+}
+
+extern "C" int pd_normals_pred_loss_bwd(const void* pred, long ld, const void* gt_normals, const void* gt, const void* gout,
+                                        const void* loss_count, void* dpred, long ld_dpred, int N, int H, int W, float min_depth,
+                                        float max_depth, void* stream) {
+    PD_REQUIRE(pred && gt_normals && gt && gout && loss_count && dpred && N > 0 && H > 0 && W > 0 && ld >= 3 && ld_dpred >= 3 &&
+                   pd::aligned16(gt_normals), "pd_normals_pred_loss_bwd: bad arguments");
+    const long total = (long)N * H * W;
+    hipLaunchKernelGGL(normals_pred_bwd_kernel, dim3(lgrid(total)), dim3(LT), 0, (hipStream_t)stream, (const float*)pred, ld,
+                       (const float4*)gt_normals, (const float*)gt, (const float*)gout, (const float*)loss_count, (float*)dpred,
+                       ld_dpred, total, min_depth, max_depth);
+    return pd::check_launch("pd_normals_pred_loss_bwd");
 }
 
 extern "C" int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* gt_normals, const void* wts,

@@ -7,6 +7,7 @@ that raise on construction.
 from .resnet_encoder import ShallowResnetEncoder
 from .pre_encoders import ShallowEncoder, ShallowNormalsEncoder, JointEncoder
 from .depth_decoder import DepthDecoder
+from .normals_decoder import NormalsDecoder      # `arch1++_separate_normals_dec` variant (README.md:54)
 
 
 def _out_of_scope(name):

@@ -61,6 +61,12 @@ def _attention_variant(opt):
     return bool(getattr(opt, "joint_attention", False)) or os.environ.get("PD_JOINT_ATTENTION") == "1"
 
 
+def _normals_decoder_variant(opt):
+    """`arch1++_separate_normals_dec` (reference README.md:54): like the attention variant the reference's master parser has
+    no flag for it; selected on the options object (``opt.normals_decoder = True``) or by ``PD_NORMALS_DECODER=1``."""
+    return bool(getattr(opt, "normals_decoder", False)) or os.environ.get("PD_NORMALS_DECODER") == "1"
+
+
 class Trainer:
     def __init__(self, options):
         self.opt = options
@@ -107,6 +113,10 @@ class Trainer:
                                                              include_xolp=self.opt.augment_xolp,
                                                              attention=_attention_variant(self.opt))
         self.models["mono_depth"] = networks.DepthDecoder(self.models["rgb_encoder"].num_ch_enc, self.opt.scales)
+        if _normals_decoder_variant(self.opt):
+            if not self.opt.augment_normals:
+                raise ValueError("the separate normals decoder sits behind the normals encoder: it needs --augment_normals")
+            self.models["normals_decoder"] = networks.NormalsDecoder(64)
         for m in self.models.values():
             m.to(self.device)
         if self.distributed:                    # identical replicas: broadcast rank 0's initialisation
@@ -114,8 +124,8 @@ class Trainer:
                 for t in list(m.parameters()) + list(m.buffers()):
                     torch.distributed.broadcast(t.data, 0)
 
-        order = [n for n in ("rgb_encoder", "xolp_encoder", "normals_encoder", "joint_encoder", "mono_depth")
-                 if n in self.models]
+        order = [n for n in ("rgb_encoder", "xolp_encoder", "normals_encoder", "joint_encoder", "mono_depth",
+                             "normals_decoder") if n in self.models]
         self.store = ParamStore(self.models, order=order, unused=_unused_resnet_param, device=self.device)
         for n in order:
             self.parameters_to_train += list(self.models[n].parameters())
@@ -322,7 +332,10 @@ class Trainer:
                 normals_feats = self.models["normals_encoder"](inputs["xolp", 0, 0].float(), normals=normals)
         enc_feats = self.models["joint_encoder"](feats[-1], xolp_feats, normals_feats)
         feats = list(feats) + enc_feats
-        return dict(self.models['mono_depth'](feats))
+        outputs = dict(self.models['mono_depth'](feats))
+        if "normals_decoder" in self.models:      # `arch1++_separate_normals_dec`: normals straight from the normals encoder
+            outputs[("normals_pred", 0)] = self.models["normals_decoder"](normals_feats)
+        return outputs
 
     def _encoder_stream(self, i):
         while len(self._enc_streams) <= i:
@@ -357,6 +370,13 @@ class Trainer:
             losses[f"supervised_normals_loss/{s}"] = vals[3 + 3 * i]
             outputs[("depth", 0, s)] = depths[i]
             outputs[("mono_depth", 0, s)] = depths[i]
+        if ("normals_pred", 0) in outputs:
+            # `arch1++_separate_normals_dec`: the predicted normals against the normals of the ground truth, weighted like
+            # the normals term of the depth loss (README.md:54,67: normals_loss_weight)
+            nl = PF.normals_pred_loss(outputs[("normals_pred", 0)], inputs["depth"], inputs[("K", 0)], self.opt.min_depth,
+                                      self.opt.max_depth)
+            losses["normals_decoder_loss"] = nl
+            losses["loss"] = losses["loss"] + self.opt.normals_loss_weight * nl
         return losses
 
     def compute_supervised_normals_losses(self, depth_gt, depth_pred, intrinsics, mask=None):
@@ -522,7 +542,7 @@ class Trainer:
         self.models[name].load_state_dict(model_dict, strict=strict)     # copies in place: flat-buffer views stay valid
 
     def load_mono_model(self):
-        for n in ['rgb_encoder', 'mono_depth', 'normals_encoder', 'xolp_encoder', 'joint_encoder']:
+        for n in ['rgb_encoder', 'mono_depth', 'normals_encoder', 'xolp_encoder', 'joint_encoder', 'normals_decoder']:
             path = os.path.join(self.opt.mono_weights_folder, "{}.pth".format(n))
             if n in self.models and os.path.isfile(path):
                 self._load_into(n, path, strict=True)

@@ -77,6 +77,8 @@ SIGNATURES = {
     "pd_gt_normals": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "pd_sup_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "pd_normals_loss_masked": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pd_normals_pred_loss_fwd": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "pd_normals_pred_loss_bwd": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _f, _f, _vp]),
     "pd_multiscale_loss_fwd": (_i, [_vpp, _vpp, _ip, _ip, _i, _vp, _vp, _vp, _vpp, _vpp, _vpp, _vp, _vp, _i, _i, _i, _i, _f, _f,
                                     _i, _vp]),
     "pd_multiscale_loss_bwd": (_i, [_vpp, _vpp, _vpp, _vpp, _vpp, _ip, _ip, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vpp,

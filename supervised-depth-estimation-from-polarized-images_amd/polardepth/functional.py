@@ -1021,6 +1021,47 @@ class MultiScaleLossFn(torch.autograd.Function):
         return (None, None, None, *grads, *([None] * S))
 
 
+class NormalsPredLossFn(torch.autograd.Function):
+    """sum((2 - cos(n_pred, n_gt)) m) / sum(m) for a PREDICTED normal map [N,3,H,W] (the `arch1++_separate_normals_dec`
+    variant, README.md:54; formula of trainer.py:1298-1309, mask of trainer.py:1242-1243): pd_gt_normals +
+    pd_normals_pred_loss_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, K, min_depth, max_depth):
+        pred, ld = nhwc_view(pred)
+        N, C, H, W = pred.shape
+        if C != 3:
+            raise ValueError(f"normals_pred_loss: the prediction must have 3 channels, got {C}")
+        gt = gt.contiguous().float()
+        K = K.contiguous().float()
+        dev = pred.device
+        st = stream_ptr()
+        gtn = _f32(dev, N, H, W, 4)
+        check(lib.pd_gt_normals(ptr(gt), ptr(K), ptr(gtn), N, H, W, float(min_depth), float(max_depth), st), "pd_gt_normals")
+        part = _f32(dev, lib.pd_loss_rows(N * H * W), 2)
+        out = _f32(dev, 2)
+        check(lib.pd_normals_pred_loss_fwd(ptr(pred), ld, ptr(gtn), ptr(gt), ptr(part), ptr(out), N, H, W, float(min_depth),
+                                           float(max_depth), st), "pd_normals_pred_loss_fwd")
+        ctx.geom = (ld, float(min_depth), float(max_depth))
+        ctx.save_for_backward(pred, gtn, gt, out)
+        return out[:1].clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gtn, gt, out = ctx.saved_tensors
+        ld, min_d, max_d = ctx.geom
+        N, _, H, W = pred.shape
+        gout = g.reshape(1).contiguous().float()
+        dpred = ops.empty_nhwc(N, 3, H, W, pred.device)
+        check(lib.pd_normals_pred_loss_bwd(ptr(pred), ld, ptr(gtn), ptr(gt), ptr(gout), ptr(out), ptr(dpred), 3, N, H, W, min_d,
+                                           max_d, stream_ptr()), "pd_normals_pred_loss_bwd")
+        return dpred, None, None, None, None
+
+
+def normals_pred_loss(pred, gt, K, min_depth, max_depth):
+    return NormalsPredLossFn.apply(pred, gt, K, min_depth, max_depth)
+
+
 def multiscale_loss(cfg, gt, K, disps, colors):
     out = MultiScaleLossFn.apply(cfg, gt, K, *disps, *colors)
     return out[0], list(out[1:])

@@ -346,3 +346,53 @@ def test_batched_weight_transposes_follow_the_weights():
     opt.step()
     assert not torch.equal(before, convs[0].weight.data)
     check_all()
+
+
+def test_normals_decoder_variant_matches_oracle():
+    """`arch1++_separate_normals_dec` (README.md:54; defined by this build, see manydepth/networks/normals_decoder.py): the
+    façade NormalsDecoder + the predicted-normals loss kernels vs the same definition on PyTorch-CPU (oracle/nets.py,
+    oracle/losses.py), forward, loss value and every gradient."""
+    from manydepth import networks
+    from oracle import nets as onets, losses as ol
+    from polardepth import functional as PF
+    g = torch.Generator().manual_seed(11)
+    N, H, W = 2, 64, 96
+    feat = torch.randn(N, 64, H // 8, W // 8, generator=g)
+    gt = 0.3 + 1.5 * torch.rand(N, 1, H, W, generator=g)
+    gt = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(gt, (2, 2, 2, 2), mode="replicate"), 5, 1)     # smooth surface
+    gt[:, :, :6, :9] = 0.0                                  # invalid region (outside the depth range)
+    gt[:, :, 40:44, 50:60] = 2.5
+    K = torch.eye(4)[None].repeat(N, 1, 1)
+    K[:, 0, 0] = K[:, 1, 1] = 0.65 * W; K[:, 0, 2] = W / 2; K[:, 1, 2] = H / 2
+    ref = onets.NormalsDecoder(64)
+    fill_state_dict(ref, 0, prefix="normals_decoder.")
+    mod = networks.NormalsDecoder(64)
+    fill_state_dict(mod, 0, prefix="normals_decoder.")
+    assert list(ref.state_dict()) == list(mod.state_dict())
+    mod.cuda()
+    fr = feat.clone().requires_grad_(True)
+    yr = ref(fr)
+    lr = ol.normals_pred_loss(yr, gt, K, 0.1, 2.0)
+    lr.backward()
+    fg = feat.cuda().requires_grad_(True)
+    yg = mod(fg)
+    lg = PF.normals_pred_loss(yg, gt.cuda(), K.cuda(), 0.1, 2.0)
+    (3.0 * lg).backward()
+    PF.sync_wgrad_stream()
+    _close(yg, yr, FWD_TOL, "normals_pred")
+    assert abs(lg.item() - lr.item()) <= 1e-5 * abs(lr.item()), (lg.item(), lr.item())
+    _close(fg.grad / 3.0, fr.grad, GRAD_TOL, "feature gradient")
+    pr = dict(ref.named_parameters())
+    for k, p in mod.named_parameters():
+        _close(p.grad / 3.0, pr[k].grad, GRAD_TOL, k)
+    # the loss alone, on a prediction with a zero vector and a huge one: value and gradient
+    pred = torch.randn(N, 3, H, W, generator=g)
+    pred[0, :, 20, 30] = 0.0
+    pred[1, :, 10, 10] *= 1e4
+    pc = pred.clone().requires_grad_(True)
+    ol.normals_pred_loss(pc, gt, K, 0.1, 2.0).backward()
+    pgpu = pred.cuda().requires_grad_(True)
+    l2 = PF.normals_pred_loss(pgpu, gt.cuda(), K.cuda(), 0.1, 2.0)
+    l2.backward()
+    keep = torch.ones(N, 1, H, W, dtype=torch.bool); keep[0, :, 20, 30] = False     # (the clamp's gradient at exactly zero differs)
+    _close((pgpu.grad.cpu() * keep), pc.grad * keep, 1e-5, "d loss / d pred")

@@ -134,3 +134,24 @@ def test_depth_to_normals_restatement_properties():
     n = losses.depth_to_normals(depth, K)[0, :, 3:-3, 3:-3]
     exp = torch.tensor([-a, 0.0, 1.0]) / (1 + a * a) ** 0.5
     assert (n - exp[:, None, None]).abs().max() < 2e-2
+
+
+def test_normals_decoder_variant_oracle_definition():
+    """`arch1++_separate_normals_dec` (README.md:54) as this build defines it: three ConvBlock + bilinear x2 stages from the
+    normals encoder's 64 x H/8 x W/8 features to a 3-channel map at H x W; its loss is 1 for a perfect prediction
+    (2 - cos = 1), 3 for the opposite normal, and ignores pixels outside the depth range."""
+    from oracle import nets as onets, losses as ol
+    torch.manual_seed(0)
+    dec = onets.NormalsDecoder(64)
+    assert list(dec.state_dict()) == [f"decoder.{i}.conv.conv.{p}" for i in range(3) for p in ("weight", "bias")] + \
+        ["decoder.3.conv.weight", "decoder.3.conv.bias"]
+    assert dec(torch.randn(1, 64, 4, 6)).shape == (1, 3, 32, 48)
+    gt = 0.5 + torch.rand(2, 1, 16, 24)
+    gt[:, :, :3] = 0.0
+    K = torch.eye(4)[None].repeat(2, 1, 1)
+    K[:, 0, 0] = K[:, 1, 1] = 20.0; K[:, 0, 2] = 12; K[:, 1, 2] = 8
+    n = ol.depth_to_normals(gt, K[:, :3, :3])
+    assert abs(ol.normals_pred_loss(5.0 * n, gt, K).item() - 1.0) < 1e-6
+    assert abs(ol.normals_pred_loss(-n, gt, K).item() - 3.0) < 1e-6
+    junk = n.clone(); junk[:, :, :3] = 123.0            # rows outside the depth range do not count
+    assert abs(ol.normals_pred_loss(junk, gt, K).item() - 1.0) < 1e-6

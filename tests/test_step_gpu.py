@@ -329,3 +329,39 @@ def test_evaluation_runs_on_the_device_with_per_material_metrics(tmp_path, capsy
     for o, e in errs.items():
         if e:
             np.testing.assert_allclose(res[o], np.array(e).mean(0), rtol=2e-5, atol=1e-6)
+
+
+def test_separate_normals_decoder_variant_trains(tmp_path, monkeypatch):
+    """`arch1++_separate_normals_dec` end to end through the Trainer façade (PD_NORMALS_DECODER=1): the extra model is built,
+    trained (its parameters and the normals encoder's move), its loss is reported and drops, and it is checkpointed and
+    reloaded like the other models."""
+    import glob
+    monkeypatch.setenv("PD_NORMALS_DECODER", "1")
+    from manydepth.trainer import Trainer
+    from polardepth import synthetic
+    tr = Trainer(_opts(tmp_path, ["--dropout_rate", "0.0", "--learning_rate", "1e-3"]))
+    assert "normals_decoder" in tr.models
+    tr.set_train()
+    batch = synthetic.make_batch(2, 64, 96, frame_w=96, device="cuda", seed=3)
+    batch.pop("depth_gt"); batch.pop(("mask", 0, 0))
+    before = [p.detach().clone() for p in tr.models["normals_decoder"].parameters()]
+    first = None
+    for it in range(12):
+        tr.model_optimizer.zero_grad()
+        outputs, losses, _ = tr.process_batch(dict(batch), is_train=True)
+        losses["loss"].backward()
+        tr.model_optimizer.step()
+        if first is None:
+            first = float(losses["normals_decoder_loss"])
+            assert outputs[("normals_pred", 0)].shape == (2, 3, 64, 96)
+    last = float(losses["normals_decoder_loss"])
+    assert 0.9 < first < 3.1 and last < first - 0.05, (first, last)
+    after = list(tr.models["normals_decoder"].parameters())
+    assert all((a - b).abs().max().item() > 0 for a, b in zip(after, before))
+    tr.epoch = 0
+    tr.save_model()
+    folder = glob.glob(os.path.join(tr.log_path, "models", "weights_0"))[0]
+    sd = torch.load(os.path.join(folder, "normals_decoder.pth"))
+    assert list(sd) == list(tr.models["normals_decoder"].state_dict())
+    for k, v in tr.models["normals_decoder"].state_dict().items():
+        assert torch.equal(v.cpu(), sd[k])
