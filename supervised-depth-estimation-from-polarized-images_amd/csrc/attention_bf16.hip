@@ -13,6 +13,8 @@
 // ([channel][token], 16-byte units holding a fragment's eight tokens in fragment order), which attn_pack_kernel writes next
 // to the row-major tile.
 #include "pd_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -213,6 +215,199 @@ __global__ __launch_bounds__(ATT_T, 3) void attn_fwd_bf16_kernel(const float* __
         for (int c = 0; c < HD / 32; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j)      // registers 4j .. 4j+3 are four consecutive channels
+                *reinterpret_cast<float4*>(on + 32 * c + 8 * j + 4 * h) =
+                    make_float4(oacc[c][4 * j] * inv, oacc[c][4 * j + 1] * inv, oacc[c][4 * j + 2] * inv, oacc[c][4 * j + 3] * inv);
+        if (h == 0) lse[(long)n * T + qi] = (m_run + log2f(l_run)) * 0.6931471805599453f;
+    }
+}
+
+// max / sum of a value over the two half-waves (lanes l and l ^ 32) on the VALU: v_permlane32_swap (gfx950) instead of the
+// ds_bpermute of __shfl_xor, whose LDS round trip sat in the middle of the softmax's dependency chain
+__device__ __forceinline__ float halves_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float halves_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// direct-to-LDS copy of 1 KiB (one wave instruction: LDS address = M0 + 16 * lane), issued from inline asm: no staging
+// registers, and the compiler -- which drains vmcnt in front of every LDS read once it knows of a pending LDS-DMA -- does not
+// see it; the loop retires it with an explicit s_waitcnt vmcnt(0) in front of its barrier.  (M0 is a reserved register of
+// the backend, which rewrites it in front of each of its own uses: csrc/conv.hip:dma16.)
+typedef __attribute__((address_space(3))) void att_lds_t;
+__device__ __forceinline__ void att_dma16(__amdgpu_buffer_rsrc_t r, const void* lds_wave_base, unsigned voff) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(att_lds_t*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(m0v), "v"(voff), "s"(r) : "memory");
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t att_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// ------------------------------------------------------------------------------------------------ forward, software-pipelined
+// SQ counters of the loop above (tools/sq_prof_attn.sh, profiles/r03_attention_sq_counters.txt): the vector pipe is the
+// bottleneck, not the matrix pipe -- 8 to 10 vector instructions per MFMA (17 v_exp_f32 at quarter rate, 17 subtractions,
+// 18 sums, the O rescale in ~45 % of the key blocks, ~30 LDS / global address instructions, 8 accumulator clears per 16
+// MFMAs) against a matrix pipe that is busy a third of the time; and the wave runs S MFMAs, softmax and P.V MFMAs one after
+// the other.  This kernel removes vector work and overlaps the rest:
+//   * lazy maximum: the scores leave the matrix pipe already shifted -- the accumulator of S starts at -m instead of 0 -- and m
+//     only moves when a block exceeds it by more than 2^8 (then O, l and the scores in flight are rescaled in a cold path):
+//     no subtraction per score, no rescale of O in the common case.  Exact: any offset cancels in O / l, and exp2 of a
+//     shifted score stays below 2^8 (bf16 keeps its relative precision);
+//   * the scores of block kb + 1 are computed WHILE the softmax of block kb runs: the eight chained S MFMAs are issued one
+//     by one between the exponentials (source order is issue order: sched_barrier), so each finds its predecessor finished;
+//   * four K buffers / two V buffers addressed statically (the loop is unrolled four times): fragment addresses are eight
+//     loop-invariant registers + immediate offsets; tiles go global -> LDS by direct-to-LDS loads (no staging registers);
+//   * the half-wave exchanges of the softmax are v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip).
+// 48 KB of LDS, three workgroups per CU.  Needs T % 128 == 0.
+__global__ __launch_bounds__(ATT_T, 3) void attn_fwd_bf16_pipe_kernel(const float* __restrict__ q, const char* __restrict__ kr,
+                                                                      const char* __restrict__ vt, float* __restrict__ o,
+                                                                      float* __restrict__ lse, int T, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char Ks[4][TILE];
+    __shared__ __attribute__((aligned(16))) char Vt[2][TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.y;
+    const int q0 = blockIdx.x * (4 * QW) + wave * QW;
+    const int ql = lane & 31, h = lane >> 5;
+    const int nkb = T / KB;
+    const unsigned img_bytes = (unsigned)((long)nkb * TILE);
+    const __amdgpu_buffer_rsrc_t rk = att_rsrc(kr + (long)n * img_bytes, img_bytes);
+    const __amdgpu_buffer_rsrc_t rv = att_rsrc(vt + (long)n * img_bytes, img_bytes);
+    // a tile image = eight 1-KiB pieces: wave w copies pieces 2w and 2w + 1
+    const unsigned dma_lane = (2 * wave) * 1024 + lane * 16;
+    const unsigned wave_lds = __builtin_amdgcn_readfirstlane((unsigned)((2 * wave) * 1024));      // uniform: SALU arithmetic below
+    auto dma_tile = [&](const __amdgpu_buffer_rsrc_t r, const char* lds, int blk) {
+        const unsigned m0a = (unsigned)(size_t)(att_lds_t*)lds + wave_lds;
+        const unsigned off = (unsigned)blk * TILE + dma_lane;
+        // (the second piece: + 1 KiB through M0 for the LDS side and through the scalar offset for the global side -- an
+        //  instruction offset would be added to both)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(m0a), "v"(off), "s"(r), "s"(1024u), "s"(m0a + 1024u) : "memory");
+    };
+    bf16x8 qb[HD / 16];
+    own_frags(q + ((long)n * T + (q0 + ql < T ? q0 + ql : T - 1)) * HD, h, scale_log2e, qb);
+    // loop-invariant fragment offsets inside a tile (the buffer and, for V^T, the channel tile are immediates)
+    int koff[HD / 16];
+#pragma unroll
+    for (int g = 0; g < HD / 16; ++g) koff[g] = row_off(ql, 2 * g + h);
+    const int voff0 = tr_off(ql, h), voff1 = tr_off(ql, 2 + h);          // k-steps 0 / 1; channel tile c adds c * 32 * 64 bytes
+#pragma unroll
+    for (int g = 0; g < HD / 16; ++g) asm volatile("" : "+v"(koff[g]));   // keep them as registers (no re-derivation per block)
+    f32x16 oacc[HD / 32];
+#pragma unroll
+    for (int c = 0; c < HD / 32; ++c) zero(oacc[c]);
+
+    // prologue: K0, V0, K1 in LDS; S of block 0, unshifted; m = its exact row maximum
+    dma_tile(rk, Ks[0], 0); dma_tile(rv, Vt[0], 0); dma_tile(rk, Ks[1], 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 sA, sB;                       // the score tiles of blocks kb (even: sA) and kb + 1: they alternate roles, no copies
+    zero(sA);
+#pragma unroll
+    for (int g = 0; g < HD / 16; ++g)
+        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ks[0] + koff[g]), qb[g], sA, 0, 0, 0);
+    float m_run = sA[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m_run = fmaxf(m_run, sA[r]);
+    m_run = halves_max(m_run);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sA[r] -= m_run;
+    float l_run = 0.f;
+
+#define PD_PIN() __builtin_amdgcn_sched_barrier(0)
+    // one key block; J = kb % 4 (compile time): K of block kb in Ks[J], of kb + 1 in Ks[J + 1], V of kb in Vt[J & 1]
+    auto step = [&](auto jtag, int kb) {
+        constexpr int J = decltype(jtag)::value;
+        f32x16& s = (J & 1) ? sB : sA;
+        f32x16& sn = (J & 1) ? sA : sB;
+        const char* const Kn = Ks[(J + 1) & 3];
+        const char* const Vc = Vt[J & 1];
+        dma_tile(rk, Ks[(J + 2) & 3], kb + 2 < nkb ? kb + 2 : nkb - 1);      // (clamped at the end: those copies are unused)
+        dma_tile(rv, Vt[(J + 1) & 1], kb + 1 < nkb ? kb + 1 : nkb - 1);
+        // ---- S^T of block kb + 1, shifted by -m, in the shadow of the softmax of block kb
+        {
+            const float nm = -m_run;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[r] = nm;
+        }
+        bf16x8 ka0 = *reinterpret_cast<const bf16x8*>(Kn + koff[0]), ka1 = *reinterpret_cast<const bf16x8*>(Kn + koff[1]), ka2;
+        PD_PIN();
+        float t = fmaxf(fmaxf(fmaxf(s[0], s[1]), s[2]), fmaxf(fmaxf(s[3], s[4]), s[5]));
+        t = fmaxf(fmaxf(t, s[6]), s[7]);
+        PD_PIN();
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qb[0], sn, 0, 0, 0);
+        ka2 = *reinterpret_cast<const bf16x8*>(Kn + koff[2]);
+        PD_PIN();
+        float u = fmaxf(fmaxf(fmaxf(s[8], s[9]), s[10]), fmaxf(fmaxf(s[11], s[12]), s[13]));
+        u = fmaxf(fmaxf(u, s[14]), s[15]);
+        t = halves_max(fmaxf(t, u));                 // the block's largest shifted score of this query
+        PD_PIN();
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qb[1], sn, 0, 0, 0);
+        ka0 = *reinterpret_cast<const bf16x8*>(Kn + koff[3]);
+        PD_PIN();
+        // the maximum moves only when a score exceeds it by more than 2^8 (cold: O, l, and both score tiles are rescaled)
+        float shift = 0.f;
+        if (__builtin_expect(__any(t > 8.f), 0)) {
+            shift = fmaxf(t, 0.f);
+            const float a = fast_exp2(-shift);
+            m_run += shift;
+            l_run *= a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] -= shift;
+#pragma unroll
+            for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[c][r] *= a;
+        }
+        float lsum = 0.f;
+        // six MFMAs, behind each the exponentials of (up to) three scores: 3 x (v_exp at quarter rate, v_add)
+#define PD_STEP(G, KA, KNEXT, R0, R1, R2, NR)                                                              \
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KA, qb[G], sn, 0, 0, 0);                              \
+        if ((G) + 2 < HD / 16) KNEXT = *reinterpret_cast<const bf16x8*>(Kn + koff[((G) + 2) & 7]);        \
+        PD_PIN();                                                                                          \
+        s[R0] = fast_exp2(s[R0]); lsum += s[R0];                                                           \
+        if ((NR) > 1) { s[R1] = fast_exp2(s[R1]); lsum += s[R1]; }                                         \
+        if ((NR) > 2) { s[R2] = fast_exp2(s[R2]); lsum += s[R2]; }                                         \
+        PD_PIN();
+        PD_STEP(2, ka2, ka1, 0, 1, 2, 3)
+        PD_STEP(3, ka0, ka2, 3, 4, 5, 3)
+        PD_STEP(4, ka1, ka0, 6, 7, 8, 3)
+        PD_STEP(5, ka2, ka1, 9, 10, 11, 3)
+        PD_STEP(6, ka0, ka2, 12, 13, 13, 2)
+        PD_STEP(7, ka1, ka0, 14, 15, 15, 2)
+#undef PD_STEP
+        l_run += halves_sum(lsum);
+        const bf16x8 p0 = acc_frag(s, 0), p1 = acc_frag(s, 1);
+        if (__builtin_expect(shift != 0.f, 0)) {      // (per lane: the scores in flight were shifted by the old maximum)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[r] -= shift;
+        }
+        // ---- O^T += V_blk^T . P^T
+#pragma unroll
+        for (int c = 0; c < HD / 32; ++c) {
+            oacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Vc + c * 2048 + voff0), p0, oacc[c], 0, 0, 0);
+            oacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Vc + c * 2048 + voff1), p1, oacc[c], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the tiles to come
+        __syncthreads();                                       // everyone's pieces; everyone done with this block's tiles
+    };
+    for (int kb = 0; kb < nkb; kb += 4) {
+        step(std::integral_constant<int, 0>{}, kb);
+        step(std::integral_constant<int, 1>{}, kb + 1);
+        step(std::integral_constant<int, 2>{}, kb + 2);
+        step(std::integral_constant<int, 3>{}, kb + 3);
+    }
+#undef PD_PIN
+    const int qi = q0 + ql;
+    if (qi < T) {
+        const float inv = 1.f / l_run;
+        float* on = o + ((long)n * T + qi) * HD;
+#pragma unroll
+        for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<float4*>(on + 32 * c + 8 * j + 4 * h) =
                     make_float4(oacc[c][4 * j] * inv, oacc[c][4 * j + 1] * inv, oacc[c][4 * j + 2] * inv, oacc[c][4 * j + 3] * inv);
         if (h == 0) lse[(long)n * T + qi] = (m_run + log2f(l_run)) * 0.6931471805599453f;
@@ -432,8 +627,13 @@ extern "C" int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, voi
     pack(k, kr, nullptr, nblocks, st);
     pack(v, nullptr, vt, nblocks, st);
     const dim3 grid((unsigned)((T + 4 * QW - 1) / (4 * QW)), (unsigned)N);
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr,
-                       (const char*)vt, (float*)o, (float*)lse, T, scale * kLog2e);
+    static const bool pipe = [] { const char* e = getenv("PD_ATTN_FWD_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
+    if (pipe && T % (4 * KB) == 0 && nblocks / N >= 4)
+        hipLaunchKernelGGL(attn_fwd_bf16_pipe_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr,
+                           (const char*)vt, (float*)o, (float*)lse, T, scale * kLog2e);
+    else
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr,
+                           (const char*)vt, (float*)o, (float*)lse, T, scale * kLog2e);
     return pd::check_launch("pd_attn_bf16_fwd");
 }
 
