@@ -121,8 +121,12 @@ __device__ __forceinline__ void zero(f32x16& a) {
 // into the swizzled layouts there repeated that work 40 times per image, on the VALU, beside the MFMAs.  attn_pack_kernel
 // writes, per 32-token block, the row-major and / or the transposed LDS tile verbatim (8 KB each); the attention kernels
 // then copy a tile with two 16-byte loads + two ds_write_b128 per thread: no conversion, no address arithmetic.
-__global__ __launch_bounds__(ATT_T) void attn_pack_kernel(const float* __restrict__ x, char* __restrict__ rows,
-                                                          char* __restrict__ trans, long nblocks) {
+// several tensors in ONE launch (blockIdx.y selects the job): the forward pass packs K and V, the backward pass K, V, Q and dO
+struct PackJobs { const float* x[4]; char* rows[4]; char* trans[4]; };
+__global__ __launch_bounds__(ATT_T) void attn_pack_multi_kernel(const PackJobs jobs, long nblocks) {
+    const float* x = jobs.x[blockIdx.y];
+    char* rows = jobs.rows[blockIdx.y];
+    char* trans = jobs.trans[blockIdx.y];
     for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const Stage s = load_stage(x + b * (long)KB * HD, 0, threadIdx.x);
         if (rows) store_rows(rows + b * TILE, s, threadIdx.x);
@@ -605,9 +609,9 @@ extern "C" size_t pd_attn_bf16_workspace(int N, int T, int C, int backward) {
     return (size_t)N * T * HD * 2 * (backward ? 7 : 2);       // bf16 tile images: forward K rows + V^T; backward Kr Kt Vr Qr Qt dOr dOt
 }
 
-static void pack(const void* x, char* rows, char* trans, long nblocks, hipStream_t st) {
-    hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)(nblocks > 8192 ? 8192 : nblocks)), dim3(ATT_T), 0, st, (const float*)x,
-                       rows, trans, nblocks);
+static void pack_multi(const PackJobs& jobs, int njobs, long nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(attn_pack_multi_kernel, dim3((unsigned)(nblocks > 4096 ? 4096 : nblocks), (unsigned)njobs), dim3(ATT_T), 0, st,
+                       jobs, nblocks);
 }
 
 extern "C" int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, void* lse, void* workspace,
@@ -624,8 +628,12 @@ extern "C" int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, voi
     const size_t one = (size_t)N * T * HD * 2;
     char* kr = (char*)workspace; char* vt = kr + one;
     const long nblocks = (long)N * T / KB;
-    pack(k, kr, nullptr, nblocks, st);
-    pack(v, nullptr, vt, nblocks, st);
+    {
+        PackJobs jobs{};
+        jobs.x[0] = (const float*)k; jobs.rows[0] = kr;
+        jobs.x[1] = (const float*)v; jobs.trans[1] = vt;
+        pack_multi(jobs, 2, nblocks, st);
+    }
     const dim3 grid((unsigned)((T + 4 * QW - 1) / (4 * QW)), (unsigned)N);
     static const bool pipe = [] { const char* e = getenv("PD_ATTN_FWD_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
     if (pipe && T % (4 * KB) == 0 && nblocks / N >= 4)
@@ -657,10 +665,14 @@ extern "C" int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, con
     char* w = (char*)workspace;
     char *kr = w, *kt = w + one, *vr = w + 2 * one, *qr = w + 3 * one, *qt = w + 4 * one, *dr = w + 5 * one, *dt = w + 6 * one;
     const long nblocks = ntok / KB;
-    pack(k, kr, kt, nblocks, st);
-    pack(v, vr, nullptr, nblocks, st);
-    pack(q, qr, qt, nblocks, st);
-    pack(d_o, dr, dt, nblocks, st);
+    {
+        PackJobs jobs{};
+        jobs.x[0] = (const float*)k; jobs.rows[0] = kr; jobs.trans[0] = kt;
+        jobs.x[1] = (const float*)v; jobs.rows[1] = vr;
+        jobs.x[2] = (const float*)q; jobs.rows[2] = qr; jobs.trans[2] = qt;
+        jobs.x[3] = (const float*)d_o; jobs.rows[3] = dr; jobs.trans[3] = dt;
+        pack_multi(jobs, 4, nblocks, st);
+    }
     const dim3 grid((unsigned)((T + 4 * QW - 1) / (4 * QW)), (unsigned)N);
     constexpr int kDkvLds = 8 * TILE + 4 * KB * 4;
     static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel),
