@@ -249,6 +249,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t att_rsrc(const void* p, unsign
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+__device__ __forceinline__ const char* uniform_cptr(const char* p) {      // a wave-uniform pointer the compiler keeps in an SGPR pair
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u >> 32));
+    return reinterpret_cast<const char*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
 // ------------------------------------------------------------------------------------------------ forward, software-pipelined
 // SQ counters of the loop above (tools/sq_prof_attn.sh, profiles/r03_attention_sq_counters.txt): the vector pipe is the
 // bottleneck, not the matrix pipe -- 8 to 10 vector instructions per MFMA (17 v_exp_f32 at quarter rate, 17 subtractions,
@@ -486,6 +493,136 @@ __global__ __launch_bounds__(ATT_T, 2) void attn_bwd_dq_bf16_kernel(const float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward: dQ, pipelined
+// The same treatment as the forward pass.  lse and delta of the lane's query are constants of the whole loop, so the score
+// accumulators start at -lse (log2 units) and the dP accumulators at -delta: P = exp2(S') and dS = P * dP' need one exponential
+// and one multiplication per score, nothing else.  The 16 chained MFMAs of block kb + 1 (S and dP, two chains taking turns)
+// are issued one by one between the exponentials / products of block kb; tiles arrive by direct-to-LDS loads into statically
+// addressed double buffers (loop unrolled twice).  Needs T % 64 == 0.
+__global__ __launch_bounds__(ATT_T, 2) void attn_bwd_dq_bf16_pipe_kernel(const float* __restrict__ q, const char* __restrict__ kr,
+                                                                         const char* __restrict__ kt, const char* __restrict__ vr,
+                                                                         const float* __restrict__ d_o,
+                                                                         const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                         float* __restrict__ dq, int T, float scale) {
+    __shared__ __attribute__((aligned(16))) char Ks[2][TILE];
+    __shared__ __attribute__((aligned(16))) char Vs[2][TILE];
+    __shared__ __attribute__((aligned(16))) char Kt[2][TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.y;
+    const int q0 = blockIdx.x * (4 * QW) + wave * QW;
+    const int ql = lane & 31, h = lane >> 5;
+    const long base = (long)n * T * HD;
+    const int nkb = T / KB;
+    const unsigned img_bytes = (unsigned)((long)nkb * TILE);
+    const __amdgpu_buffer_rsrc_t rkr = att_rsrc(kr + (long)n * img_bytes, img_bytes);
+    const __amdgpu_buffer_rsrc_t rkt = att_rsrc(kt + (long)n * img_bytes, img_bytes);
+    const __amdgpu_buffer_rsrc_t rvr = att_rsrc(vr + (long)n * img_bytes, img_bytes);
+    const unsigned dma_lane = (2 * wave) * 1024 + lane * 16;
+    const unsigned wave_lds = __builtin_amdgcn_readfirstlane((unsigned)((2 * wave) * 1024));
+    auto dma_tile = [&](const __amdgpu_buffer_rsrc_t r, const char* lds, int blk) {      // eight 1-KiB pieces, two per wave
+        const unsigned m0a = (unsigned)(size_t)(att_lds_t*)lds + wave_lds;
+        const unsigned off = (unsigned)blk * TILE + dma_lane;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(m0a), "v"(off), "s"(r), "s"(1024u), "s"(m0a + 1024u) : "memory");
+    };
+    const int qi = q0 + ql < T ? q0 + ql : T - 1;
+    bf16x8 qb[HD / 16], dob[HD / 16];
+    own_frags(q + base + (long)qi * HD, h, scale * kLog2e, qb);
+    own_frags(d_o + base + (long)qi * HD, h, 1.f, dob);
+    const float nlse = -lse[(long)n * T + qi] * kLog2e;
+    const float ndl = -delta[(long)n * T + qi];
+    int koff[HD / 16];
+#pragma unroll
+    for (int g = 0; g < HD / 16; ++g) koff[g] = row_off(ql, 2 * g + h);
+    const int toff0 = tr_off(ql, h), toff1 = tr_off(ql, 2 + h);
+#pragma unroll
+    for (int g = 0; g < HD / 16; ++g) asm volatile("" : "+v"(koff[g]));
+    f32x16 acc[HD / 32];
+#pragma unroll
+    for (int c = 0; c < HD / 32; ++c) zero(acc[c]);
+
+    // prologue: rows of blocks 0 and 1, K^T of block 0; S' and dP' of block 0
+    dma_tile(rkr, Ks[0], 0); dma_tile(rvr, Vs[0], 0); dma_tile(rkt, Kt[0], 0);
+    dma_tile(rkr, Ks[1], 1); dma_tile(rvr, Vs[1], 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 sA, pA, sB, pB;               // (S', dP') of blocks kb (even: A) and kb + 1: they alternate roles
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sA[r] = nlse; pA[r] = ndl; }
+#pragma unroll
+    for (int g = 0; g < HD / 16; ++g) {
+        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ks[0] + koff[g]), qb[g], sA, 0, 0, 0);
+        pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Vs[0] + koff[g]), dob[g], pA, 0, 0, 0);
+    }
+#define PD_PIN() __builtin_amdgcn_sched_barrier(0)
+    // one key block; J = kb % 2 (compile time): rows of block kb + 1 in Ks / Vs[J ^ 1], K^T of block kb in Kt[J]
+    auto step = [&](auto jtag, int kb) {
+        constexpr int J = decltype(jtag)::value;
+        f32x16& s = J ? sB : sA;
+        f32x16& dp = J ? pB : pA;
+        f32x16& sn = J ? sA : sB;
+        f32x16& dn = J ? pA : pB;
+        const char* const Kn = Ks[J ^ 1];
+        const char* const Vn = Vs[J ^ 1];
+        const char* const Ktc = Kt[J];
+        // rows of block kb + 2 replace those of block kb (read during the previous step), K^T of block kb + 1 that of kb - 1
+        dma_tile(rkr, Ks[J], kb + 2 < nkb ? kb + 2 : nkb - 1);
+        dma_tile(rvr, Vs[J], kb + 2 < nkb ? kb + 2 : nkb - 1);
+        dma_tile(rkt, Kt[J ^ 1], kb + 1 < nkb ? kb + 1 : nkb - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sn[r] = nlse; dn[r] = ndl; }
+        bf16x8 ka = *reinterpret_cast<const bf16x8*>(Kn + koff[0]), va = *reinterpret_cast<const bf16x8*>(Vn + koff[0]);
+        bf16x8 kb2, vb2;
+        PD_PIN();
+        // sixteen MFMAs (the S and dP chains of block kb + 1 taking turns), behind each one score of block kb:
+        // P = exp2(S'), dS = P * dP'  (v_exp at quarter rate + v_mul)
+#define PD_PAIR(G, KA, VA, KB2, VB2)                                                                        \
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KA, qb[G], sn, 0, 0, 0);                              \
+        if ((G) + 1 < HD / 16) KB2 = *reinterpret_cast<const bf16x8*>(Kn + koff[((G) + 1) & 7]);          \
+        PD_PIN();                                                                                          \
+        s[2 * (G)] = fast_exp2(s[2 * (G)]) * dp[2 * (G)];                                                  \
+        PD_PIN();                                                                                          \
+        dn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(VA, dob[G], dn, 0, 0, 0);                             \
+        if ((G) + 1 < HD / 16) VB2 = *reinterpret_cast<const bf16x8*>(Vn + koff[((G) + 1) & 7]);          \
+        PD_PIN();                                                                                          \
+        s[2 * (G) + 1] = fast_exp2(s[2 * (G) + 1]) * dp[2 * (G) + 1];                                      \
+        PD_PIN();
+        PD_PAIR(0, ka, va, kb2, vb2)
+        PD_PAIR(1, kb2, vb2, ka, va)
+        PD_PAIR(2, ka, va, kb2, vb2)
+        PD_PAIR(3, kb2, vb2, ka, va)
+        PD_PAIR(4, ka, va, kb2, vb2)
+        PD_PAIR(5, kb2, vb2, ka, va)
+        PD_PAIR(6, ka, va, kb2, vb2)
+        PD_PAIR(7, kb2, vb2, ka, va)
+#undef PD_PAIR
+        const bf16x8 d0 = acc_frag(s, 0), d1 = acc_frag(s, 1);       // dS (keys x queries)
+        // ---- dQ^T (chan x queries) += K_blk^T (chan x keys) . dS
+#pragma unroll
+        for (int c = 0; c < HD / 32; ++c) {
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ktc + c * 2048 + toff0), d0, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ktc + c * 2048 + toff1), d1, acc[c], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int kb = 0; kb < nkb; kb += 2) {
+        step(std::integral_constant<int, 0>{}, kb);
+        step(std::integral_constant<int, 1>{}, kb + 1);
+    }
+#undef PD_PIN
+    if (q0 + ql < T) {
+        float* out = dq + base + (long)(q0 + ql) * HD;
+#pragma unroll
+        for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(out + 32 * c + 8 * j + 4 * h) =
+                    make_float4(acc[c][4 * j] * scale, acc[c][4 * j + 1] * scale, acc[c][4 * j + 2] * scale, acc[c][4 * j + 3] * scale);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // keys on lanes.  Per query block:  S = Q_blk.K^T,  dP = dO_blk.V^T  (rows = queries),
 //   P = exp2(S - lse[row]),  dS = P (dP - delta[row]),
@@ -589,9 +726,201 @@ __global__ __launch_bounds__(ATT_T, 1) void attn_bwd_dkv_bf16_kernel(const char*
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward: dK, dV, pipelined
+// One wave per SIMD (the two 32x128 accumulators + the wave's own K and V leave no room for a second), so the overlap of the
+// matrix and the vector pipe has to come from inside the wave: the 16 chained MFMAs of query block qb + 1 (S' = Q.K^T - lse and
+// dP' = dO.V^T - delta, the accumulators starting at the rows' -lse / -delta read from LDS) are issued one by one between the
+// exponentials / products of block qb (P = exp2(S'), dS = P * dP'), then the 16 MFMAs of dV^T += dO^T.P and dK^T += Q^T.dS.
+// Tiles arrive by direct-to-LDS loads into statically addressed double buffers (loop unrolled twice).  Needs T % 64 == 0.
+__global__ __launch_bounds__(ATT_T, 1) void attn_bwd_dkv_bf16_pipe_kernel(const char* __restrict__ qr, const char* __restrict__ qt,
+                                                                          const float* __restrict__ k, const float* __restrict__ v,
+                                                                          const char* __restrict__ dr, const char* __restrict__ dt,
+                                                                          const float* __restrict__ nstat,
+                                                                          float* __restrict__ dk, float* __restrict__ dv, int T, int N,
+                                                                          float scale) {
+    extern __shared__ __attribute__((aligned(16))) char dkvp_smem[];
+    // Four slots per tile kind (128 KB): tiles are requested two blocks before their first use.  The LDS base of a
+    // direct-to-LDS load is the low 16 bits of M0: only the first 64 KB can be its target (measured: a target above lands
+    // 64 KB lower).  The row tiles (the ones S' / dP' need first) live there and arrive by direct-to-LDS loads; the transposed
+    // tiles and the row statistics live above and pass through registers -- loaded by inline-asm loads two steps ahead
+    // (invisible to the compiler, whose own loads would be waited for with a full drain), written to LDS a step later.
+    char (*Qs)[TILE] = reinterpret_cast<char (*)[TILE]>(dkvp_smem);
+    char (*Ds)[TILE] = reinterpret_cast<char (*)[TILE]>(dkvp_smem + 4 * TILE);
+    char (*Qt)[TILE] = reinterpret_cast<char (*)[TILE]>(dkvp_smem + 8 * TILE);
+    char (*Dt)[TILE] = reinterpret_cast<char (*)[TILE]>(dkvp_smem + 12 * TILE);
+    float (*St)[2 * KB] = reinterpret_cast<float (*)[2 * KB]>(dkvp_smem + 16 * TILE);       // per slot: -lse (log2 units) | -delta of the rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.y;
+    const int k0 = blockIdx.x * (4 * QW) + wave * QW;
+    const int kl = lane & 31, h = lane >> 5;
+    const long base = (long)n * T * HD;
+    const int nqb = T / KB;
+    const unsigned img_bytes = (unsigned)((long)nqb * TILE);
+    const __amdgpu_buffer_rsrc_t rqr = att_rsrc(qr + (long)n * img_bytes, img_bytes);
+    const __amdgpu_buffer_rsrc_t rdr = att_rsrc(dr + (long)n * img_bytes, img_bytes);
+    const char* const qt_n = uniform_cptr(qt + (long)n * img_bytes);
+    const char* const dt_n = uniform_cptr(dt + (long)n * img_bytes);
+    const unsigned dma_lane = (2 * wave) * 1024 + lane * 16;
+    const unsigned wave_lds = __builtin_amdgcn_readfirstlane((unsigned)((2 * wave) * 1024));
+    auto dma_tile = [&](const __amdgpu_buffer_rsrc_t r, const char* lds, int blk) {      // eight 1-KiB pieces, two per wave
+        const unsigned m0a = (unsigned)(size_t)(att_lds_t*)lds + wave_lds;
+        const unsigned off = (unsigned)blk * TILE + dma_lane;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(m0a), "v"(off), "s"(r), "s"(1024u), "s"(m0a + 1024u) : "memory");
+    };
+    const int ki = k0 + kl < T ? k0 + kl : T - 1;
+    bf16x8 kfr[HD / 16], vfr[HD / 16];
+    own_frags(k + base + (long)ki * HD, h, scale * kLog2e, kfr);
+    own_frags(v + base + (long)ki * HD, h, 1.f, vfr);
+    int koff[HD / 16];
+#pragma unroll
+    for (int g = 0; g < HD / 16; ++g) koff[g] = row_off(kl, 2 * g + h);
+    const int toff0 = tr_off(kl, h), toff1 = tr_off(kl, 2 + h);
+#pragma unroll
+    for (int g = 0; g < HD / 16; ++g) asm volatile("" : "+v"(koff[g]));
+    f32x16 akk[HD / 32], avv[HD / 32];
+#pragma unroll
+    for (int c = 0; c < HD / 32; ++c) { zero(akk[c]); zero(avv[c]); }
+    // register-staged operands: a transposed tile pair (thread t copies bytes [16 t, +16) and [TILE / 2 + 16 t, +16) of each image)
+    // and the block's 64 statistics (attn_delta_bf16_kernel: nstat = [-lse * log2 e | -delta], N * T floats each; lanes 0..31 /
+    // 32..63 of every wave load the same values, wave 0 writes them)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));       // (a register tuple: the asm operands below need one)
+    struct Staged { u32x4 q0, q1, d0, d1; float st; };
+    const char* const st_n = uniform_cptr(reinterpret_cast<const char*>(nstat));
+    const unsigned st_lane = (unsigned)(((lane >> 5) * (long)N * T + (long)n * T + (lane & 31)) * 4);
+    auto issue_staged = [&](Staged& r, int blk_t, int blk_s) {          // five loads
+        const unsigned off = (unsigned)blk_t * TILE + 16u * tid;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.q0) : "v"(off), "s"(qt_n) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.q1) : "v"(off + TILE / 2), "s"(qt_n) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.d0) : "v"(off), "s"(dt_n) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.d1) : "v"(off + TILE / 2), "s"(dt_n) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(r.st) : "v"(st_lane + (unsigned)blk_s * (KB * 4)), "s"(st_n) : "memory");
+    };
+    auto store_staged = [&](const Staged& r, int slot_t, int slot_s) {
+        *reinterpret_cast<u32x4*>(Qt[slot_t] + 16 * tid) = r.q0;
+        *reinterpret_cast<u32x4*>(Qt[slot_t] + TILE / 2 + 16 * tid) = r.q1;
+        *reinterpret_cast<u32x4*>(Dt[slot_t] + 16 * tid) = r.d0;
+        *reinterpret_cast<u32x4*>(Dt[slot_t] + TILE / 2 + 16 * tid) = r.d1;
+        if (wave == 0) St[slot_s][lane] = r.st;
+    };
+    // the accumulators of a block start at its rows' statistics: element r of the tile is row (r & 3) + 8 (r >> 2) + 4 h
+    auto init_rows = [&](f32x16& a, const float* stat) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(stat + 8 * j + 4 * h);
+            a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w;
+        }
+    };
+    // prologue: rows of blocks 0..2 (direct to LDS), transposed tiles of blocks 0 and 1 + statistics of blocks 0..2 (registers)
+    dma_tile(rqr, Qs[0], 0); dma_tile(rdr, Ds[0], 0);
+    dma_tile(rqr, Qs[1], 1); dma_tile(rdr, Ds[1], 1);
+    dma_tile(rqr, Qs[2], 2); dma_tile(rdr, Ds[2], 2);
+    Staged sgA, sgB;                     // staged operands requested at even / odd steps
+    issue_staged(sgA, 0, 0);
+    issue_staged(sgB, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sgA.q0), "+v"(sgA.q1), "+v"(sgA.d0), "+v"(sgA.d1), "+v"(sgA.st), "+v"(sgB.q0), "+v"(sgB.q1),
+                 "+v"(sgB.d0), "+v"(sgB.d1), "+v"(sgB.st) :: "memory");
+    store_staged(sgA, 0, 0);
+    store_staged(sgB, 1, 1);
+    issue_staged(sgB, 1, 2);             // (its transposed pair is rewritten unchanged at the end of step 0, its statistics are block 2's)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sgB.q0), "+v"(sgB.q1), "+v"(sgB.d0), "+v"(sgB.d1), "+v"(sgB.st) :: "memory");
+    store_staged(sgB, 1, 2);
+    issue_staged(sgB, 1, 2);             // in flight into step 0, which retires it like any other step's
+    __syncthreads();
+    f32x16 sA, pA, sB, pB;               // (S', dP') of blocks qb (even: A) and qb + 1: they alternate roles
+    init_rows(sA, St[0]); init_rows(pA, St[0] + KB);
+#pragma unroll
+    for (int g = 0; g < HD / 16; ++g) {
+        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Qs[0] + koff[g]), kfr[g], sA, 0, 0, 0);
+        pA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ds[0] + koff[g]), vfr[g], pA, 0, 0, 0);
+    }
+#define PD_PIN() __builtin_amdgcn_sched_barrier(0)
+    // one query block; J = qb % 4: rows + statistics of block qb + 1 in slot J + 1, transposed tiles of block qb in slot J
+    auto step = [&](auto jtag, int qb) {
+        constexpr int J = decltype(jtag)::value;
+        f32x16& s = (J & 1) ? sB : sA;
+        f32x16& dp = (J & 1) ? pB : pA;
+        f32x16& sn = (J & 1) ? sA : sB;
+        f32x16& dn = (J & 1) ? pA : pB;
+        const char* const Qn = Qs[(J + 1) & 3];
+        const char* const Dn = Ds[(J + 1) & 3];
+        const char* const Qtc = Qt[J];
+        const char* const Dtc = Dt[J];
+        // rows of block qb + 3 into the slot of block qb - 1 (direct to LDS: four operations); transposed tiles of block qb + 2
+        // and statistics of block qb + 3 into this step's register set (five): nine operations per wave and step
+        Staged& mine = (J & 1) ? sgB : sgA;          // requested now, written to LDS at the end of the NEXT step
+        Staged& older = (J & 1) ? sgA : sgB;         // requested a step ago, written at the end of this one
+        const int b3 = qb + 3 < nqb ? qb + 3 : nqb - 1, b2 = qb + 2 < nqb ? qb + 2 : nqb - 1;
+        dma_tile(rqr, Qs[(J + 3) & 3], b3); dma_tile(rdr, Ds[(J + 3) & 3], b3);
+        issue_staged(mine, b2, b3);
+        init_rows(sn, St[(J + 1) & 3]); init_rows(dn, St[(J + 1) & 3] + KB);
+        // With one wave per SIMD nothing hides an LDS round trip: ALL sixteen row fragments of block qb + 1 are requested up
+        // front (64 registers -- there are 512), the sixteen transposed fragments of block qb one per MFMA slot below.
+        bf16x8 qf[HD / 16], df[HD / 16], tq[HD / 16], td[HD / 16];
+#pragma unroll
+        for (int g = 0; g < HD / 16; ++g) {
+            qf[g] = *reinterpret_cast<const bf16x8*>(Qn + koff[g]);
+            df[g] = *reinterpret_cast<const bf16x8*>(Dn + koff[g]);
+        }
+        PD_PIN();
+        // sixteen MFMAs (the S and dP chains of block qb + 1 taking turns), behind each one score of block qb:
+        // P = exp2(S') (kept in s), dS = P * dP' (kept in dp)
+#define PD_PAIR(G)                                                                                          \
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[G], kfr[G], sn, 0, 0, 0);                          \
+        td[G] = *reinterpret_cast<const bf16x8*>(Dtc + ((G) >> 1) * 2048 + (((G) & 1) ? toff1 : toff0));    \
+        PD_PIN();                                                                                          \
+        s[2 * (G)] = fast_exp2(s[2 * (G)]); dp[2 * (G)] *= s[2 * (G)];                                     \
+        PD_PIN();                                                                                          \
+        dn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[G], vfr[G], dn, 0, 0, 0);                          \
+        tq[G] = *reinterpret_cast<const bf16x8*>(Qtc + ((G) >> 1) * 2048 + (((G) & 1) ? toff1 : toff0));    \
+        PD_PIN();                                                                                          \
+        s[2 * (G) + 1] = fast_exp2(s[2 * (G) + 1]); dp[2 * (G) + 1] *= s[2 * (G) + 1];                     \
+        PD_PIN();
+        PD_PAIR(0) PD_PAIR(1) PD_PAIR(2) PD_PAIR(3) PD_PAIR(4) PD_PAIR(5) PD_PAIR(6) PD_PAIR(7)
+#undef PD_PAIR
+        const bf16x8 p0 = acc_frag(s, 0), p1 = acc_frag(s, 1), d0 = acc_frag(dp, 0), d1 = acc_frag(dp, 1);
+        // ---- dV^T (chan x keys) += dO_blk^T . P,   dK^T (chan x keys) += Q_blk^T . dS
+#pragma unroll
+        for (int c = 0; c < HD / 32; ++c) {
+            avv[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[2 * c], p0, avv[c], 0, 0, 0);
+            akk[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[2 * c], d0, akk[c], 0, 0, 0);
+            avv[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[2 * c + 1], p1, avv[c], 0, 0, 0);
+            akk[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[2 * c + 1], d1, akk[c], 0, 0, 0);
+        }
+        // what the NEXT step reads was requested a step ago: the nine operations of this step may stay in flight.  The older
+        // register set has landed: transposed tiles of block qb + 1 -> slot J + 1, statistics of block qb + 2 -> slot J + 2
+        asm volatile("s_waitcnt vmcnt(9)" : "+v"(older.q0), "+v"(older.q1), "+v"(older.d0), "+v"(older.d1), "+v"(older.st) :: "memory");
+        store_staged(older, (J + 1) & 3, (J + 2) & 3);
+        __syncthreads();
+    };
+    for (int qb = 0; qb < nqb; qb += 4) {
+        step(std::integral_constant<int, 0>{}, qb);
+        step(std::integral_constant<int, 1>{}, qb + 1);
+        step(std::integral_constant<int, 2>{}, qb + 2);
+        step(std::integral_constant<int, 3>{}, qb + 3);
+    }
+#undef PD_PIN
+    if (k0 + kl < T) {
+        float* ok = dk + base + (long)(k0 + kl) * HD;
+        float* ov = dv + base + (long)(k0 + kl) * HD;
+#pragma unroll
+        for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = 32 * c + 8 * j + 4 * h;
+                *reinterpret_cast<float4*>(ok + cc) = make_float4(akk[c][4 * j] * scale, akk[c][4 * j + 1] * scale,
+                                                                  akk[c][4 * j + 2] * scale, akk[c][4 * j + 3] * scale);
+                *reinterpret_cast<float4*>(ov + cc) = make_float4(avv[c][4 * j], avv[c][4 * j + 1], avv[c][4 * j + 2], avv[c][4 * j + 3]);
+            }
+    }
+}
+
 // delta[n][t] = sum_c dO[t][c] * O[t][c]   (fp32; memory-bound)
+// nstat (optional): [-lse * log2 e | -delta], ntok floats each -- the form the pipelined dK / dV kernel starts its accumulators from
 __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const float* __restrict__ o, const float* __restrict__ d_o,
-                                                              float* __restrict__ delta, long ntok) {
+                                                              float* __restrict__ delta, long ntok,
+                                                              const float* __restrict__ lse, float* __restrict__ nstat) {
     const long t = blockIdx.x * 8L + (threadIdx.x >> 5);      // 32 lanes per token, float4 each
     if (t >= ntok) return;
     const int l = threadIdx.x & 31;
@@ -599,14 +928,18 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_kernel(const float* __res
     float sum = (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
-    if (l == 0) delta[t] = sum;
+    if (l == 0) {
+        delta[t] = sum;
+        if (nstat) { nstat[t] = -lse[t] * kLog2e; nstat[ntok + t] = -sum; }
+    }
 }
 
 }  // namespace
 
 extern "C" size_t pd_attn_bf16_workspace(int N, int T, int C, int backward) {
     if (N <= 0 || T <= 0 || C != HD || T % KB) return 0;
-    return (size_t)N * T * HD * 2 * (backward ? 7 : 2);       // bf16 tile images: forward K rows + V^T; backward Kr Kt Vr Qr Qt dOr dOt
+    // bf16 tile images: forward K rows + V^T; backward Kr Kt Vr Qr Qt dOr dOt + the negated row statistics (2 N T floats)
+    return (size_t)N * T * HD * 2 * (backward ? 7 : 2) + (backward ? (size_t)N * T * 8 : 0);
 }
 
 static void pack_multi(const PackJobs& jobs, int njobs, long nblocks, hipStream_t st) {
@@ -659,10 +992,11 @@ extern "C" int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, con
                "pd_attn_bf16_bwd: tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long ntok = (long)N * T;
-    hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3((unsigned)((ntok + 7) / 8)), dim3(256), 0, st, (const float*)o,
-                       (const float*)d_o, (float*)delta, ntok);
     const size_t one = (size_t)N * T * HD * 2;
     char* w = (char*)workspace;
+    float* nstat = reinterpret_cast<float*>(w + 7 * one);
+    hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3((unsigned)((ntok + 7) / 8)), dim3(256), 0, st, (const float*)o,
+                       (const float*)d_o, (float*)delta, ntok, (const float*)lse, nstat);
     char *kr = w, *kt = w + one, *vr = w + 2 * one, *qr = w + 3 * one, *qt = w + 4 * one, *dr = w + 5 * one, *dt = w + 6 * one;
     const long nblocks = ntok / KB;
     {
@@ -674,14 +1008,29 @@ extern "C" int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, con
         pack_multi(jobs, 4, nblocks, st);
     }
     const dim3 grid((unsigned)((T + 4 * QW - 1) / (4 * QW)), (unsigned)N);
-    constexpr int kDkvLds = 8 * TILE + 4 * KB * 4;
-    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kDkvLds);
-    PD_REQUIRE(lds_ok == hipSuccess, "pd_attn_bf16_bwd: cannot reserve %d bytes of LDS", kDkvLds);
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(ATT_T), kDkvLds, st, (const char*)qr, (const char*)qt, (const float*)k,
-                       (const float*)v, (const char*)dr, (const char*)dt, (const float*)lse, (const float*)delta, (float*)dk,
-                       (float*)dv, T, scale);
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr, (const char*)kt,
-                       (const char*)vr, (const float*)d_o, (const float*)lse, (const float*)delta, (float*)dq, T, scale);
+    constexpr int kDkvLds = 8 * TILE + 4 * KB * 4, kDkvPipeLds = 16 * TILE + 8 * KB * 4;
+    static const bool pipe_kv = [] { const char* e = getenv("PD_ATTN_BWD_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
+    if (pipe_kv && T % (4 * KB) == 0 && 2L * N * T * 4 < (1L << 31)) {
+        static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_pipe_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kDkvPipeLds);
+        PD_REQUIRE(lds_ok == hipSuccess, "pd_attn_bf16_bwd: cannot reserve %d bytes of LDS", kDkvPipeLds);
+        hipLaunchKernelGGL(attn_bwd_dkv_bf16_pipe_kernel, grid, dim3(ATT_T), kDkvPipeLds, st, (const char*)qr, (const char*)qt,
+                           (const float*)k, (const float*)v, (const char*)dr, (const char*)dt, (const float*)nstat,
+                           (float*)dk, (float*)dv, T, N, scale);
+    } else {
+        static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kDkvLds);
+        PD_REQUIRE(lds_ok == hipSuccess, "pd_attn_bf16_bwd: cannot reserve %d bytes of LDS", kDkvLds);
+        hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, grid, dim3(ATT_T), kDkvLds, st, (const char*)qr, (const char*)qt, (const float*)k,
+                           (const float*)v, (const char*)dr, (const char*)dt, (const float*)lse, (const float*)delta, (float*)dk,
+                           (float*)dv, T, scale);
+    }
+    static const bool pipe = [] { const char* e = getenv("PD_ATTN_BWD_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
+    if (pipe && T % (2 * KB) == 0)
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_pipe_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr, (const char*)kt,
+                           (const char*)vr, (const float*)d_o, (const float*)lse, (const float*)delta, (float*)dq, T, scale);
+    else
+        hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr, (const char*)kt,
+                           (const char*)vr, (const float*)d_o, (const float*)lse, (const float*)delta, (float*)dq, T, scale);
     return pd::check_launch("pd_attn_bf16_bwd");
 }
