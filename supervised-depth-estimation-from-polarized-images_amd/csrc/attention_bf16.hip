@@ -855,39 +855,46 @@ __global__ __launch_bounds__(ATT_T, 1) void attn_bwd_dkv_bf16_pipe_kernel(const 
         dma_tile(rqr, Qs[(J + 3) & 3], b3); dma_tile(rdr, Ds[(J + 3) & 3], b3);
         issue_staged(mine, b2, b3);
         init_rows(sn, St[(J + 1) & 3]); init_rows(dn, St[(J + 1) & 3] + KB);
-        // With one wave per SIMD nothing hides an LDS round trip: ALL sixteen row fragments of block qb + 1 are requested up
-        // front (64 registers -- there are 512), the sixteen transposed fragments of block qb one per MFMA slot below.
-        bf16x8 qf[HD / 16], df[HD / 16], tq[HD / 16], td[HD / 16];
+        // Row fragments of block qb + 1 three MFMA slots ahead (a ring of four per chain), the sixteen transposed fragments of
+        // block qb one per slot.  (All sixteen row fragments up front cost 48 more registers and pushed the score tiles -- which
+        // the vector pipe works on -- into AGPRs: a v_accvgpr move around every exponential.)
+        bf16x8 qf[4], df[4], tf[4];
 #pragma unroll
-        for (int g = 0; g < HD / 16; ++g) {
+        for (int g = 0; g < 3; ++g) {
             qf[g] = *reinterpret_cast<const bf16x8*>(Qn + koff[g]);
             df[g] = *reinterpret_cast<const bf16x8*>(Dn + koff[g]);
         }
         PD_PIN();
         // sixteen MFMAs (the S and dP chains of block qb + 1 taking turns), behind each one score of block qb:
         // P = exp2(S') (kept in s), dS = P * dP' (kept in dp)
+        // transposed fragment i of the second phase (i = 0..15): channel tile i >> 2, k-step (i >> 1) & 1, dO^T (even i) or Q^T
+#define PD_TADDR(I) ((((I) & 1) ? Qtc : Dtc) + ((I) >> 2) * 2048 + ((((I) >> 1) & 1) ? toff1 : toff0))
 #define PD_PAIR(G)                                                                                          \
-        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[G], kfr[G], sn, 0, 0, 0);                          \
-        td[G] = *reinterpret_cast<const bf16x8*>(Dtc + ((G) >> 1) * 2048 + (((G) & 1) ? toff1 : toff0));    \
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(G) & 3], kfr[G], sn, 0, 0, 0);                    \
+        if ((G) + 3 < HD / 16) qf[((G) + 3) & 3] = *reinterpret_cast<const bf16x8*>(Qn + koff[((G) + 3) & 7]); \
         PD_PIN();                                                                                          \
         s[2 * (G)] = fast_exp2(s[2 * (G)]); dp[2 * (G)] *= s[2 * (G)];                                     \
         PD_PIN();                                                                                          \
-        dn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[G], vfr[G], dn, 0, 0, 0);                          \
-        tq[G] = *reinterpret_cast<const bf16x8*>(Qtc + ((G) >> 1) * 2048 + (((G) & 1) ? toff1 : toff0));    \
+        dn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[(G) & 3], vfr[G], dn, 0, 0, 0);                    \
+        if ((G) + 3 < HD / 16) df[((G) + 3) & 3] = *reinterpret_cast<const bf16x8*>(Dn + koff[((G) + 3) & 7]); \
+        if ((G) >= 5) tf[(G) - 5] = *reinterpret_cast<const bf16x8*>(PD_TADDR((G) - 5));                 \
         PD_PIN();                                                                                          \
         s[2 * (G) + 1] = fast_exp2(s[2 * (G) + 1]); dp[2 * (G) + 1] *= s[2 * (G) + 1];                     \
         PD_PIN();
         PD_PAIR(0) PD_PAIR(1) PD_PAIR(2) PD_PAIR(3) PD_PAIR(4) PD_PAIR(5) PD_PAIR(6) PD_PAIR(7)
 #undef PD_PAIR
         const bf16x8 p0 = acc_frag(s, 0), p1 = acc_frag(s, 1), d0 = acc_frag(dp, 0), d1 = acc_frag(dp, 1);
-        // ---- dV^T (chan x keys) += dO_blk^T . P,   dK^T (chan x keys) += Q_blk^T . dS
-#pragma unroll
-        for (int c = 0; c < HD / 32; ++c) {
-            avv[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[2 * c], p0, avv[c], 0, 0, 0);
-            akk[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[2 * c], d0, akk[c], 0, 0, 0);
-            avv[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[2 * c + 1], p1, avv[c], 0, 0, 0);
-            akk[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[2 * c + 1], d1, akk[c], 0, 0, 0);
-        }
+        // ---- dV^T (chan x keys) += dO_blk^T . P,   dK^T (chan x keys) += Q_blk^T . dS: sixteen MFMAs, their transposed
+        // fragments three slots ahead (a ring of four; the first three were requested behind the last S' / dP' MFMAs)
+#define PD_MF(I)                                                                                               \
+        if ((I) & 1) akk[(I) >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[(I) & 3], ((I) & 2) ? d1 : d0, akk[(I) >> 2], 0, 0, 0); \
+        else avv[(I) >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[(I) & 3], ((I) & 2) ? p1 : p0, avv[(I) >> 2], 0, 0, 0);       \
+        if ((I) + 3 < 16) tf[((I) + 3) & 3] = *reinterpret_cast<const bf16x8*>(PD_TADDR((I) + 3));             \
+        PD_PIN();
+        PD_MF(0) PD_MF(1) PD_MF(2) PD_MF(3) PD_MF(4) PD_MF(5) PD_MF(6) PD_MF(7)
+        PD_MF(8) PD_MF(9) PD_MF(10) PD_MF(11) PD_MF(12) PD_MF(13) PD_MF(14) PD_MF(15)
+#undef PD_MF
+#undef PD_TADDR
         // what the NEXT step reads was requested a step ago: the nine operations of this step may stay in flight.  The older
         // register set has landed: transposed tiles of block qb + 1 -> slot J + 1, statistics of block qb + 2 -> slot J + 2
         asm volatile("s_waitcnt vmcnt(9)" : "+v"(older.q0), "+v"(older.q1), "+v"(older.d0), "+v"(older.d1), "+v"(older.st) :: "memory");
