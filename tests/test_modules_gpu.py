@@ -396,3 +396,47 @@ def test_normals_decoder_variant_matches_oracle():
     l2.backward()
     keep = torch.ones(N, 1, H, W, dtype=torch.bool); keep[0, :, 20, 30] = False     # (the clamp's gradient at exactly zero differs)
     _close((pgpu.grad.cpu() * keep), pc.grad * keep, 1e-5, "d loss / d pred")
+
+
+@pytest.mark.parametrize("shape,kind", [((2, 8, 16), "plain"), ((1, 16, 16), "late_peak"), ((2, 16, 40), "peaky"),
+                                        ((1, 8, 24), "plain")])
+def test_bf16_attention_pipelined_kernels(shape, kind):
+    """The software-pipelined bf16 attention kernels (T % 128 == 0: forward / dK,dV; T % 64 == 0: dQ; (1, 8, 24) has T = 192 and
+    mixes the pipelined dQ with the plain forward / dK,dV kernels) across token counts and batch sizes, including the cold
+    path of the forward pass's lazy maximum: "late_peak" plants keys in the LAST blocks whose scores exceed every earlier one
+    by far more than 2^8, so the running maximum has to move, with O, l and the score tile in flight rescaled.  Reference:
+    fp64 softmax attention in torch; tolerances as in the test above."""
+    from polardepth import functional as PF
+    N, Hh, Ww = shape
+    T = Hh * Ww
+    g = torch.Generator().manual_seed(33)
+    q, k, v = (torch.randn(N, 128, Hh, Ww, generator=g) for _ in range(3))
+    if kind == "peaky":
+        q = q * 2.5
+    if kind == "late_peak":
+        kt = k.flatten(2)                       # [N, C, T]
+        qt = q.flatten(2)
+        for j, t in enumerate((T - 70, T - 3)):      # two late keys aligned with the mean query direction / one query
+            kt[:, :, t] = 6.0 * qt[:, :, 5 + j] / qt[:, :, 5 + j].norm(dim=1, keepdim=True) * (1 + j)
+        k = kt.view_as(k)
+    qc, kc, vc = (t.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) for t in (q, k, v))
+    old = PF.USE_BF16_ATTENTION
+    PF.USE_BF16_ATTENTION = True
+    try:
+        o = PF.self_attention(qc, kc, vc)
+        w = torch.randn(N, 128, Hh, Ww, generator=g)
+        (o * w.cuda()).sum().backward()
+    finally:
+        PF.USE_BF16_ATTENTION = old
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    tok = lambda t: t.flatten(2).transpose(1, 2)
+    scores = tok(qr) @ tok(kr).transpose(1, 2) / 128 ** 0.5
+    if kind == "late_peak":      # the planted keys do dominate some rows by more than 2^8 in log2 units
+        s2 = scores.detach() * 1.4426950408889634
+        assert (s2[:, :, T - 70:].max(-1).values - s2[:, :, :T - 70].max(-1).values).max().item() > 8.0
+    ref = (torch.softmax(scores, -1) @ tok(vr)).transpose(1, 2).reshape(N, 128, Hh, Ww)
+    (ref * w.double()).sum().backward()
+    assert bool(torch.isfinite(o).all())
+    _close(o, ref.detach().float(), 1e-2, "bf16 attention fwd")
+    for name, a, b in (("dq", qc, qr), ("dk", kc, kr), ("dv", vc, vr)):
+        _close(a.grad, b.grad.float(), 2e-2, "bf16 attention " + name)
