@@ -417,6 +417,12 @@ int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, void*
 int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const void* lse,
                      void* delta, void* dq, void* dk, void* dv, void* workspace, size_t ws_bytes, int N, int T, int C,
                      float scale, void* stream);
+/* The same in parts (1 = delta + operand packing, 2 = dK / dV, 4 = dQ; 7 = pd_attn_bf16_bwd): the two gradient kernels are
+ * independent, so a caller may enqueue parts 2 and 4 on two streams behind part 1 -- the workgroups of one kernel then fill
+ * the last, partly empty round of the other. */
+int pd_attn_bf16_bwd_parts(const void* q, const void* k, const void* v, const void* o, const void* d_o, const void* lse,
+                           void* delta, void* dq, void* dk, void* dv, void* workspace, size_t ws_bytes, int N, int T, int C,
+                           float scale, int parts, void* stream);
 
 /* ---- disparity heads: sigmoid(Conv3x3(x)) with one output channel
  * (manydepth/networks/depth_decoder.py:52-53,69-71; layers.py:364-380 Conv3x3 = ReflectionPad2d(1) + Conv2d(C,1,3)).

@@ -985,9 +985,23 @@ extern "C" int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, voi
     return pd::check_launch("pd_attn_bf16_fwd");
 }
 
+extern "C" int pd_attn_bf16_bwd_parts(const void* q, const void* k, const void* v, const void* o, const void* d_o, const void* lse,
+                                      void* delta, void* dq, void* dk, void* dv, void* workspace, size_t ws_bytes, int N, int T,
+                                      int C, float scale, int parts, void* stream);
+
 extern "C" int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const void* lse,
                                 void* delta, void* dq, void* dk, void* dv, void* workspace, size_t ws_bytes, int N, int T, int C,
                                 float scale, void* stream) {
+    return pd_attn_bf16_bwd_parts(q, k, v, o, d_o, lse, delta, dq, dk, dv, workspace, ws_bytes, N, T, C, scale, 7, stream);
+}
+
+// parts: 1 = delta + operand packing, 2 = dK / dV, 4 = dQ.  The two gradient kernels are independent of each other: a caller
+// that enqueues parts 2 and 4 on two streams behind part 1 lets the workgroups of one fill the last, partly empty round of
+// the other (their grids are 2.5 and 1.25 rounds of the chip).
+extern "C" int pd_attn_bf16_bwd_parts(const void* q, const void* k, const void* v, const void* o, const void* d_o, const void* lse,
+                                      void* delta, void* dq, void* dk, void* dv, void* workspace, size_t ws_bytes, int N, int T,
+                                      int C, float scale, int parts, void* stream) {
+    PD_REQUIRE(parts > 0 && parts <= 7, "pd_attn_bf16_bwd_parts: parts must be a combination of 1 | 2 | 4");
     PD_REQUIRE(N >= 0 && T > 0, "pd_attn_bf16_bwd: bad shape N=%d T=%d", N, T);
     PD_REQUIRE(C == HD, "pd_attn_bf16_bwd: head dimension must be %d (got %d)", HD, C);
     PD_REQUIRE(T % KB == 0, "pd_attn_bf16_bwd: the token count must be a multiple of %d (got %d)", KB, T);
@@ -1002,11 +1016,12 @@ extern "C" int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, con
     const size_t one = (size_t)N * T * HD * 2;
     char* w = (char*)workspace;
     float* nstat = reinterpret_cast<float*>(w + 7 * one);
-    hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3((unsigned)((ntok + 7) / 8)), dim3(256), 0, st, (const float*)o,
-                       (const float*)d_o, (float*)delta, ntok, (const float*)lse, nstat);
+    if (parts & 1)
+        hipLaunchKernelGGL(attn_delta_bf16_kernel, dim3((unsigned)((ntok + 7) / 8)), dim3(256), 0, st, (const float*)o,
+                           (const float*)d_o, (float*)delta, ntok, (const float*)lse, nstat);
     char *kr = w, *kt = w + one, *vr = w + 2 * one, *qr = w + 3 * one, *qt = w + 4 * one, *dr = w + 5 * one, *dt = w + 6 * one;
     const long nblocks = ntok / KB;
-    {
+    if (parts & 1) {
         PackJobs jobs{};
         jobs.x[0] = (const float*)k; jobs.rows[0] = kr; jobs.trans[0] = kt;
         jobs.x[1] = (const float*)v; jobs.rows[1] = vr;
@@ -1017,7 +1032,8 @@ extern "C" int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, con
     const dim3 grid((unsigned)((T + 4 * QW - 1) / (4 * QW)), (unsigned)N);
     constexpr int kDkvLds = 8 * TILE + 4 * KB * 4, kDkvPipeLds = 16 * TILE + 8 * KB * 4;
     static const bool pipe_kv = [] { const char* e = getenv("PD_ATTN_BWD_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
-    if (pipe_kv && T % (4 * KB) == 0 && 2L * N * T * 4 < (1L << 31)) {
+    if (!(parts & 2)) {
+    } else if (pipe_kv && T % (4 * KB) == 0 && 2L * N * T * 4 < (1L << 31)) {
         static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_pipe_kernel),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, kDkvPipeLds);
         PD_REQUIRE(lds_ok == hipSuccess, "pd_attn_bf16_bwd: cannot reserve %d bytes of LDS", kDkvPipeLds);
@@ -1033,7 +1049,8 @@ extern "C" int pd_attn_bf16_bwd(const void* q, const void* k, const void* v, con
                            (float*)dv, T, scale);
     }
     static const bool pipe = [] { const char* e = getenv("PD_ATTN_BWD_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
-    if (pipe && T % (2 * KB) == 0)
+    if (!(parts & 4)) {
+    } else if (pipe && T % (2 * KB) == 0)
         hipLaunchKernelGGL(attn_bwd_dq_bf16_pipe_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr, (const char*)kt,
                            (const char*)vr, (const float*)d_o, (const float*)lse, (const float*)delta, (float*)dq, T, scale);
     else

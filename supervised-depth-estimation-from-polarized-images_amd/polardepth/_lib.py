@@ -97,6 +97,7 @@ SIGNATURES = {
     "pd_attn_bf16_workspace": (_sz, [_i, _i, _i, _i]),
     "pd_attn_bf16_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _vp]),
     "pd_attn_bf16_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _vp]),
+    "pd_attn_bf16_bwd_parts": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _i, _vp]),
     "pd_disphead_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_disphead_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_disphead_workspace": (_sz, [_i]),

@@ -79,6 +79,7 @@ _WGRAD_STREAMS = {}
 USE_WGRAD_STREAM = os.environ.get("PD_WGRAD_STREAM", "1") == "1"
 USE_FLASH_ATTENTION = os.environ.get("PD_FLASH_ATTENTION", "1") != "0"   # fused attention kernels (config 5)
 USE_BF16_ATTENTION = os.environ.get("PD_ATTENTION_BF16", "0") == "1"     # ... on the bf16 matrix cores (configs[4] as specified)
+USE_ATTN_BWD_STREAMS = os.environ.get("PD_ATTN_BWD_STREAMS", "1") != "0"  # bf16 attention backward: dK/dV and dQ on two streams
 USE_BN_FOLDING = os.environ.get("PD_BN_FOLDING", "1") != "0"   # inference: BatchNorm folded into the conv epilogue
 USE_DISP_HEADS = os.environ.get("PD_DISP_HEADS", "1") != "0"     # direct kernels for the 1-channel disparity heads
 USE_S2D_STEMS = os.environ.get("PD_S2D_STEMS", "1") == "1"
@@ -89,6 +90,18 @@ def wgrad_stream(device):
     if st is None:
         st = torch.cuda.Stream(device=device)
         _WGRAD_STREAMS[device.index] = st
+    return st
+
+
+_ATTN_STREAMS = {}
+
+
+def _attn_side_stream(device):
+    """A stream of its own for the dQ kernel of the bf16 attention backward (the weight-gradient stream may hold a queue of
+    earlier kernels, which would delay the join)."""
+    st = _ATTN_STREAMS.get(device.index)
+    if st is None:
+        st = _ATTN_STREAMS[device.index] = torch.cuda.Stream(device=device)
     return st
 
 
@@ -851,8 +864,23 @@ class FlashAttentionFn(torch.autograd.Function):
         delta = torch.empty_like(lse)
         if ctx.bf16:
             ws = ops._workspace(lib.pd_attn_bf16_workspace(N, T, C, 1), q.device)
-            check(lib.pd_attn_bf16_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                                       ptr(ws), ws.numel(), N, T, C, ctx.scale, stream_ptr()), "pd_attn_bf16_bwd")
+            args = (ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(ws), ws.numel(),
+                    N, T, C, ctx.scale)
+            if USE_ATTN_BWD_STREAMS:
+                # dK / dV and dQ are independent: on two streams behind the packing pass the workgroups of one kernel fill the
+                # last, partly empty round of the other (2.5 and 1.25 rounds of the chip)
+                main = torch.cuda.current_stream()
+                side = _attn_side_stream(q.device)
+                check(lib.pd_attn_bf16_bwd_parts(*args, 1, stream_ptr()), "pd_attn_bf16_bwd_parts")
+                side.wait_stream(main)
+                check(lib.pd_attn_bf16_bwd_parts(*args, 2, stream_ptr()), "pd_attn_bf16_bwd_parts")
+                with torch.cuda.stream(side):
+                    check(lib.pd_attn_bf16_bwd_parts(*args, 4, stream_ptr()), "pd_attn_bf16_bwd_parts")
+                for t in (q, k, v, do, lse, delta, dq, ws):
+                    t.record_stream(side)
+                main.wait_stream(side)
+            else:
+                check(lib.pd_attn_bf16_bwd(*args, stream_ptr()), "pd_attn_bf16_bwd")
         else:
             check(lib.pd_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                   N, T, C, ctx.scale, stream_ptr()), "pd_attn_bwd")
