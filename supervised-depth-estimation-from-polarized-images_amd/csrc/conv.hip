@@ -754,6 +754,332 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
     conv_epilogue<BM, BN, WM, WN, MT>(a, acc, smem_all, mt, m0, n0, wm, wn, lane, wave, tid);
 }
 
+// ===================================================================== fp32 products on the bf16 matrix cores ("x3")
+// gfx950 multiplies bf16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_bf16: 32768 flop in 32 cycles of a SIMD;
+// v_mfma_f32_32x32x2_f32: 4096 flop in 64).  An fp32 number is the exact sum of three bf16 numbers of 8 significant
+// bits each -- hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest, both subtractions exact,
+// |x - hi - mid - lo| <= 2^-27 |x| -- and a product a*b is
+//     hi*hi + (hi*mid + mid*hi) + (mid*mid + hi*lo + lo*hi)   + terms <= 2^-24 |a*b| (mid*lo, lo*mid, lo*lo: dropped),
+// every partial product exact in the fp32 accumulator's input (8 x 8 bits).  Six bf16 MFMAs per 32x32x16 block, summed
+// small terms first, instead of eight fp32 MFMAs of four times the duration: the contraction keeps fp32 accuracy (the
+// dropped terms are of the size of ONE fp32 rounding of the product; tests/test_conv_gpu.py measures the kernel's error
+// against an fp64 convolution next to the fp32 kernel's) at 2.7x the matrix rate.  What it costs is the split: ~4.5
+// vector instructions per operand element (tools/bf16x3_peak.hip: the probe that sized this kernel).  So
+//   * the wave tile is 64 rows x 64 columns: an activation element is split by exactly one wave (4 x 1 waves, each
+//     stages, splits and multiplies its own 64 rows), 3 vector instructions per MFMA;
+//   * the weights of a chunk (64 x 16) are split ONCE per workgroup, by all 256 threads, one chunk ahead, from an fp32
+//     staging tile into three bf16 planes in LDS: no pre-split copies in memory that could go stale, no extra launch;
+//   * chunks are 16 deep (one MFMA k-step; C % 16 == 0), so that three workgroups fit a CU (52 KB each) and the split of
+//     one wave runs under the MFMAs of the two others.
+// Gather, masks and scalar tap state are those of conv_igemm_uni_kernel.  Output tile 256 x 64; the BatchNorm partial
+// sums keep their 128-row granularity (two rows of `stats` per workgroup), so pd_conv2d_stats_rows() does not change.
+namespace x3 {
+constexpr int BM = 256, BN = 64, CK = 16;
+constexpr unsigned A_BYTES = BM * CK * 4;          // 16 KB per ring slot
+constexpr unsigned BS_BYTES = BN * CK * 4;         // 4 KB fp32 staging tile of the weights
+constexpr unsigned BP_BYTES = BN * CK * 2;         // 2 KB per bf16 plane
+constexpr unsigned BS_BASE = 2 * A_BYTES, BP_BASE = BS_BASE + 2 * BS_BYTES;
+constexpr unsigned LDS_BYTES = BP_BASE + 2 * 3 * BP_BYTES;     // 52 KB
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Split { u32x4 hi, mid, lo; };
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// v_cvt_pk_bf16_f32 (round to nearest even) -- through the compiler, not inline asm: the hazard recognizer does not look
+// into asm statements, and a conversion feeding an MFMA right behind it needs its wait states
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// two fp32 -> (hi, mid, lo) packs of two bf16 each
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const f32x2 v = {x0, x1};
+    hi = cvt_pk_bf16(x0, x1);
+    const f32x2 h = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const f32x2 r1 = v - h;
+    mid = cvt_pk_bf16(r1.x, r1.y);
+    const f32x2 m = {__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
+    const f32x2 r2 = r1 - m;
+    lo = cvt_pk_bf16(r2.x, r2.y);
+}
+__device__ __forceinline__ Split split8(const float4 a, const float4 b) {
+    unsigned h[4], m[4], l[4];
+    split2(a.x, a.y, h[0], m[0], l[0]);
+    split2(a.z, a.w, h[1], m[1], l[1]);
+    split2(b.x, b.y, h[2], m[2], l[2]);
+    split2(b.z, b.w, h[3], m[3], l[3]);
+    Split s;
+    s.hi = u32x4{h[0], h[1], h[2], h[3]}; s.mid = u32x4{m[0], m[1], m[2], m[3]}; s.lo = u32x4{l[0], l[1], l[2], l[3]};
+    return s;
+}
+}  // namespace x3
+
+template <int MODE>
+__global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) {
+    using namespace x3;
+    __shared__ __attribute__((aligned(16))) float smem_all[LDS_BYTES / 4];
+
+    const int nblk = a.mtiles * a.ntiles;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (logical >= nblk) return;
+    const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = a.Ho * a.Wo;
+
+    const int img0 = (int)(m0 / hw);
+    const long shift = MODE == MODE_ZERO ? (long)a.pad * a.sH + (long)a.pad_w * a.sW
+                                         : (long)(a.KH - 1 - a.pad) * a.sH + (long)(a.KW - 1 - a.pad_w) * a.sW;
+    const long rest = (((long)a.N - img0) * a.sN + shift) * 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
+    const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, a.w_bytes);
+
+    // ---- gather state: a wave stages its own 64 rows, 16 per LDS-DMA instruction (lane -> row lane/4, physical 16-byte
+    // slot lane%4 of the 64-byte row; it fetches the LOGICAL slot (lane%4) ^ ((row/4)%4): conflict-free fragment reads)
+    const int prow = lane >> 2;
+    const unsigned col4 = 16u * ((lane & 3) ^ ((lane >> 4) & 3));
+    const unsigned ones_kw = (1u << a.KW) - 1u;
+    unsigned va[4], inv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0 + 64 * wave + 16 * i + prow;
+        const unsigned mr = (unsigned)(m - (long)img0 * hw);
+        const unsigned dn = magic_div(mr, a.mg_hw, a.sh_hw);
+        const unsigned rem = mr - dn * (unsigned)hw;
+        const int oh = (int)magic_div(rem, a.mg_wo, a.sh_wo);
+        const int ow = (int)rem - oh * a.Wo;
+        va[i] = (unsigned)((int)dn * (int)a.sN + oh * a.stride * (int)a.sH + ow * a.stride * (int)a.sW) * 4u + col4;
+        int lo_h, hi_h, lo_w, hi_w;       // taps outside the image: a prefix [0, lo) and a suffix [hi, K) per dimension
+        if (MODE == MODE_ZERO) {
+            lo_h = a.pad - oh * a.stride; hi_h = a.H + lo_h;
+            lo_w = a.pad_w - ow * a.stride; hi_w = a.W + lo_w;
+        } else {
+            hi_h = oh + a.pad + 1; lo_h = hi_h - a.H;
+            hi_w = ow + a.pad_w + 1; lo_w = hi_w - a.W;
+        }
+        lo_h = min(max(lo_h, 0), a.KH); hi_h = min(max(hi_h, 0), a.KH);
+        lo_w = min(max(lo_w, 0), a.KW); hi_w = min(max(hi_w, 0), a.KW);
+        const unsigned bad_h = ((1u << lo_h) - 1u) | ~((1u << hi_h) - 1u);
+        const unsigned bad_w = (((1u << lo_w) - 1u) | ~((1u << hi_w) - 1u)) & ones_kw;
+        unsigned mask = 0;
+        for (int kh = a.KH - 1; kh >= 0; --kh)
+            mask = (mask << a.KW) | (((bad_h >> kh) & 1u) ? ones_kw : bad_w);
+        inv[i] = m < a.M ? (mask | 0x80000000u) : 0xffffffffu;
+    }
+    // weights: wave w stages rows 16w .. 16w+15 of the 64 x 16 chunk (same row / slot geometry)
+    const unsigned vb = (unsigned)((n0 + 16 * wave + prow) * a.K) * 4u + col4;
+
+    // ---- scalar state: the activation pieces run one chunk ahead, the weight pieces two
+    const int dW4 = (MODE == MODE_ZERO ? (int)a.sW : -(int)a.sW) * 4, dH4 = (MODE == MODE_ZERO ? (int)a.sH : -(int)a.sH) * 4;
+    const int nchunks = a.K / CK;
+    int s_q = 0, s_tap = 0, s_kw = 0, s_c = 0;
+    unsigned s_aoff = MODE != MODE_TRANSPOSED ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
+    int s_qb = 0;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
+    const unsigned m0_a = lds0 + 4096u * (unsigned)wave, m0_b = lds0 + BS_BASE + 1024u * (unsigned)wave;
+
+    auto load_a = [&](auto dst_tag, auto piece_tag) {
+        constexpr unsigned DST = decltype(dst_tag)::value;
+        constexpr int P = decltype(piece_tag)::value;
+        const unsigned bad = __builtin_amdgcn_ubfe(inv[P], (unsigned)s_tap, 1u);
+        dma16s(rx, m0_a + DST * A_BYTES + 1024u * P, (bad << 31) + va[P], s_aoff);
+    };
+    auto advance_a = [&]() {
+        ++s_q;
+        s_aoff += CK * 4; s_c += CK;
+        if (s_c == a.C) {
+            s_c = 0; ++s_tap; s_aoff += (unsigned)(dW4 - a.C * 4);
+            if (++s_kw == a.KW) { s_kw = 0; s_aoff += (unsigned)(dH4 - a.KW * dW4); }
+        }
+        if (s_q >= nchunks) { s_tap = 31; s_aoff = 0; }          // run-out: every mask drops tap 31
+    };
+    auto load_b = [&](auto dst_tag) {                             // chunk s_qb (past the end: chunk 0 again, never used)
+        constexpr unsigned DST = decltype(dst_tag)::value;
+        const unsigned soff = s_qb < nchunks ? (unsigned)s_qb * (CK * 4) : 0u;
+        dma16s(rw_, m0_b + DST * BS_BYTES, vb, soff);
+        ++s_qb;
+    };
+
+    // ---- fragment addresses (bytes from the start of LDS)
+    // activations: lane -> (row = lane%32 of the block, k half = lane/32): logical slots 2*half, 2*half+1
+    const int frow = lane & 31, fh = lane >> 5;
+    unsigned fa_off[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        fa_off[e] = (unsigned)(64 * wave + frow) * (CK * 4) + 16u * ((2 * fh + e) ^ ((frow >> 2) & 3));
+        asm volatile("" : "+v"(fa_off[e]));
+    }
+    // weight planes: 32-byte rows, two 16-byte k halves, half ^ ((row/8)%2)
+    unsigned fb_off = BP_BASE + (unsigned)frow * (CK * 2) + 16u * (fh ^ ((frow >> 3) & 1));
+    asm volatile("" : "+v"(fb_off));
+    // split pass: thread -> (row tid/4, physical slot tid%4) of the staging tile = its 16 bytes number tid
+    const int srow = tid >> 2, sls = (tid & 3) ^ ((srow >> 2) & 3);            // logical slot: k = 4*sls .. 4*sls+3
+    const unsigned ss_off = BS_BASE + 16u * (unsigned)tid;
+    const unsigned sp_off = BP_BASE + (unsigned)srow * (CK * 2) + 16u * ((sls >> 1) ^ ((srow >> 3) & 1)) + 8u * (sls & 1);
+    char* lds_c = reinterpret_cast<char*>(smem_all);
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto split_b = [&](auto src_tag) {          // staging tile SRC -> planes SRC
+        constexpr unsigned SRC = decltype(src_tag)::value;
+        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + SRC * BS_BYTES);
+        uint2 h, m, l;
+        split2(w4.x, w4.y, h.x, m.x, l.x);
+        split2(w4.z, w4.w, h.y, m.y, l.y);
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 0) * BP_BYTES) = h;
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 1) * BP_BYTES) = m;
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 2) * BP_BYTES) = l;
+    };
+    auto bf = [](u32x4 v) { return __builtin_bit_cast(bf16x8, v); };
+
+    // One chunk: pieces of the next chunks first (they land under everything below), fragments, split, 24 MFMAs, then
+    // the weight split of the next chunk.
+    auto chunk = [&](auto buf_tag) {
+        constexpr unsigned BUF = decltype(buf_tag)::value;
+        const std::integral_constant<unsigned, BUF ^ 1> nxt{};
+        pieces<0, 4>(load_a, nxt);
+        load_b(buf_tag);
+        advance_a();
+        float4 fa[2][2];
+        u32x4 fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                fa[i][e] = *reinterpret_cast<const float4*>(lds_c + fa_off[e] + (BUF * A_BYTES + (unsigned)i * 32 * CK * 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                fb[j][t] = *reinterpret_cast<const u32x4*>(lds_c + fb_off + ((BUF * 3 + t) * BP_BYTES + (unsigned)j * 32 * CK * 2));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const Split sa = split8(fa[i][0], fa[i][1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.lo), bf(fb[j][0]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.hi), bf(fb[j][2]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.mid), bf(fb[j][1]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.mid), bf(fb[j][0]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.hi), bf(fb[j][1]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.hi), bf(fb[j][0]), acc[i][j], 0, 0, 0);
+            }
+        }
+        split_b(nxt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    // ---- prologue: activations of chunk 0, weights of chunks 0 and 1; planes of chunk 0
+    {
+        const std::integral_constant<unsigned, 0> d0{};
+        const std::integral_constant<unsigned, 1> d1{};
+        pieces<0, 4>(load_a, d0);
+        advance_a();
+        load_b(d0);
+        load_b(d1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        split_b(d0);
+        __syncthreads();
+    }
+    for (int q = 0; q < nchunks; q += 2) {
+        chunk(std::integral_constant<unsigned, 0>{});
+        if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
+    }
+
+    // ---- epilogue (full tiles, no bias / scale / activation: the host routes nothing else here): per column block the
+    // wave transposes its 64 x 32 block through LDS and leaves with full 128-byte lines; BatchNorm partial sums per
+    // 128-row half of the tile
+    {
+        float* T = smem_all + wave * (64 * 32);                        // 8 KB per wave; the ring is dead
+        float (*red)[BN][2] = reinterpret_cast<float (*)[BN][2]>(smem_all + 4 * 64 * 32);
+        const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)BM * a.ldy * 4));
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.add ? a.add + m0 * a.ld_add : a.y, a.add ? (unsigned)((long)BM * a.ld_add * 4) : 0u);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 addv[8];
+            if (a.add) {
+                const unsigned off_a = (unsigned)((64 * wave + (lane >> 3)) * (int)a.ld_add + n0 + 32 * j + 4 * (lane & 7)) * 4u;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) addv[t] = buf_ld4(ra, off_a + (unsigned)(t * 8 * (int)a.ld_add * 4));
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r];
+                    T[(32 * i + (r & 3) + 8 * (r >> 2) + rbase) * 32 + col_l] = v;
+                    s1 += v;
+                    s2 = __builtin_fmaf(v, v, s2);
+                }
+            const unsigned off_l = (unsigned)((64 * wave + (lane >> 3)) * (int)a.ldy + n0 + 32 * j + 4 * (lane & 7)) * 4u;
+            const float4* Tq = reinterpret_cast<const float4*>(T) + lane;
+            // All eight lines are formed first and the stores leave back to back: a 128-bit buffer store reads its data
+            // registers for several cycles after issue, and with a scalar offset operand hipcc does not guard them against
+            // the next vector instruction (seen here as the last lanes of every 16 storing the NEXT line's values when the
+            // sum for line t+1 was written into the registers of store t).
+            float4 v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                v[t] = Tq[t * 64];
+                if (a.add) { v[t].x += addv[t].x; v[t].y += addv[t].y; v[t].z += addv[t].z; v[t].w += addv[t].w; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[t]), ry, off_l, t * 8 * (int)a.ldy * 4, 0);
+            asm volatile("s_nop 1");
+            __builtin_amdgcn_sched_barrier(0);
+            if (a.stats) {
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
+            }
+        }
+        if (a.stats) {
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int half = tid >> 6, cl = tid & 63;
+                float* o = a.stats + ((long)(2 * mt + half) * a.Co + n0 + cl) * 2;
+                o[0] = red[2 * half][cl][0] + red[2 * half + 1][cl][0];
+                o[1] = red[2 * half][cl][1] + red[2 * half + 1][cl][1];
+            }
+        }
+    }
+}
+
+static bool x3_eligible(const ConvArgs& a, bool vec) {
+    const char* e = getenv("PD_CONV_X3");          // read per call: the tests compare both kernels in one process
+    const bool on = !(e && e[0] == '0');
+    return on && vec && a.C % x3::CK == 0 && a.Co % x3::BN == 0 && a.M % x3::BM == 0 && a.M >= 64 * 1024 && a.KH * a.KW <= 31 &&
+           a.pad < a.KH && a.pad_w < a.KW && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) && !a.bias &&
+           !a.oscale && a.act == ACT_NONE && (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
+           (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0)) && (long)a.Co * a.K * 4 < 0x7fffffffL;
+}
+
+static int launch_conv_x3(ConvArgs& a, hipStream_t st) {
+    a.mtiles = (int)(a.M / x3::BM);
+    a.ntiles = a.Co / x3::BN;
+    const long nblk = (long)a.mtiles * a.ntiles;
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
+    if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_ZERO>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_TRANSPOSED>), grid, block, 0, st, a);
+    return pd::check_launch("pd_conv2d");
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
     a.mtiles = (int)((a.M + BM - 1) / BM);
@@ -905,6 +1231,7 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
     const int bm = pd_conv2d_tile_m(a.M, Co);
     // 96 output columns (the data gradient of the decoder's 96 -> 32 layer): three 32-wide column tiles instead of a full and a
     // half-empty 64-wide one (a quarter of the matrix work of that launch was padding)
+    if (x3_eligible(a, vec)) return launch_conv_x3(a, st);
     static const bool n96 = [] { const char* e = getenv("PD_CONV_N96"); return !(e && e[0] == '0'); }();
     if (Co == 96 && n96 && bm == 128) return launch_conv<128, 32, 32, 32>(a, vec, st);
     if (Co > 32) return bm == 128 ? launch_conv<128, 64, 64, 32>(a, vec, st) : launch_conv<64, 64, 32, 32>(a, vec, st);
