@@ -999,7 +999,7 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
         if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
     }
 
-    // ---- epilogue (full tiles, no bias / scale / activation: the host routes nothing else here): per column block the
+    // ---- epilogue (full tiles, no scale / activation: the host routes nothing else here): per column block the
     // wave transposes its 64 x 32 block through LDS and leaves with full 128-byte lines; BatchNorm partial sums per
     // 128-row half of the tile
     {
@@ -1017,11 +1017,12 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
                 for (int t = 0; t < 8; ++t) addv[t] = buf_ld4(ra, off_a + (unsigned)(t * 8 * (int)a.ld_add * 4));
             }
             float s1 = 0.f, s2 = 0.f;
+            const float bv = a.bias ? a.bias[n0 + 32 * j + col_l] : 0.f;     // (the statistics are those of conv + bias)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = acc[i][j][r];
+                    const float v = acc[i][j][r] + bv;
                     T[(32 * i + (r & 3) + 8 * (r >> 2) + rbase) * 32 + col_l] = v;
                     s1 += v;
                     s2 = __builtin_fmaf(v, v, s2);
@@ -1046,10 +1047,15 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
             __builtin_amdgcn_sched_barrier(0);
             if (a.stats) {
                 s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
+                if (a.M < 64 * 1024) {             // 64-row statistics tiles (pd_conv2d_tile_m): one row per wave
+                    if (lane < 32) {
+                        float* o = a.stats + ((long)(4 * mt + wave) * a.Co + n0 + 32 * j + col_l) * 2;
+                        o[0] = s1; o[1] = s2;
+                    }
+                } else if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
             }
         }
-        if (a.stats) {
+        if (a.stats && a.M >= 64 * 1024) {
             __syncthreads();
             if (tid < 2 * BN) {
                 const int half = tid >> 6, cl = tid & 63;
@@ -1061,11 +1067,18 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
     }
 }
 
+static long x3_min_wg() {      // fewest workgroups that take the 256-row tiles: two per CU (PD_CONV_X3_MIN_WG: tuning aid).
+    // Below that a SIMD holds one wave most of the time and the split is not hidden by another wave's MFMAs: 320
+    // workgroups run at the fp32 kernel's pace (3x3x256 @32x40: 116 vs 114 TF), 640 at 1.3x (5x5 256 -> 512 @32x40: 167 vs 127).
+    const char* e = getenv("PD_CONV_X3_MIN_WG");
+    return e ? atol(e) : 512;
+}
+
 static bool x3_eligible(const ConvArgs& a, bool vec) {
     const char* e = getenv("PD_CONV_X3");          // read per call: the tests compare both kernels in one process
     const bool on = !(e && e[0] == '0');
-    return on && vec && a.C % x3::CK == 0 && a.Co % x3::BN == 0 && a.M % x3::BM == 0 && a.M >= 64 * 1024 && a.KH * a.KW <= 31 &&
-           a.pad < a.KH && a.pad_w < a.KW && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) && !a.bias &&
+    return on && vec && a.C % x3::CK == 0 && a.Co % x3::BN == 0 && a.M % x3::BM == 0 && (a.M / x3::BM) * (a.Co / x3::BN) >= x3_min_wg() && a.KH * a.KW <= 31 &&
+           a.pad < a.KH && a.pad_w < a.KW && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) &&
            !a.oscale && a.act == ACT_NONE && (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
            (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0)) && (long)a.Co * a.K * 4 < 0x7fffffffL;
 }
@@ -1521,7 +1534,12 @@ struct WgradUniArgs {
 // pair's row / column gets +-2 rows / columns added, selected by four scalar flags of the pair (top, bottom, first,
 // last column): 6 VALU per X piece instead of 2.  BIAS: the kt == 0 tiles also sum dY over their pixels.
 // TCO = 64: waves 2 (co) x 2 (k), 32x64 wave tiles; TCO = 32 (17..32 output channels): waves 1 x 4, 32x32 wave tiles.
-template <bool REFLECT, bool BIAS, int TCO = 64>
+// X3: the products run on the bf16 matrix cores as in conv_igemm_x3_kernel (three-way split of BOTH operands in
+// registers -- dY and X are activations, there is nothing to pre-split): a lane's eight values of a 16-pixel MFMA step
+// are the eight ds_read_b32 the fp32 path issues for those pixels (pixel 2e + lane/32 of the step, e = 0..7: the
+// contraction index may be permuted as long as both operands agree), so staging, LDS image and addresses do not change.
+// Per chunk and wave: 24 bf16 MFMAs (768 cycles instead of 2048) and ~220 vector instructions.
+template <bool REFLECT, bool BIAS, int TCO = 64, bool X3 = false>
 __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs ua) {
     const WgradArgs& a = ua.g;
     constexpr int MT = 32, NW_K = TCO == 64 ? 2 : 4, TK = WG_K / MT / NW_K;   // k waves, 32-wide k sub-tiles per wave
@@ -1703,7 +1721,40 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
                     bv[slot][u][t] = *reinterpret_cast<const float*>(lds_c + fx_off[t] + (BUF * X_BYTES + step * 2 * X_ROW));
             }
         };
-        if constexpr (!HALF) {
+        if constexpr (X3) {
+            // eight steps (16 pixels) per MFMA k-step; HALF: the wave's two fragment groups are ONE k-step
+            constexpr int NKS = HALF ? 1 : 2;
+            float a8[NKS][8], b8[NKS][TK][8];
+#pragma unroll
+            for (int g = 0; g < NKS; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned step = HALF ? (e < 4 ? e : e + 4) : 8 * g + e;
+                    a8[g][e] = *reinterpret_cast<const float*>(lds_c + fd_off + (BUF * D_BYTES + step * 2 * D_ROW));
+#pragma unroll
+                    for (int t = 0; t < TK; ++t)
+                        b8[g][t][e] = *reinterpret_cast<const float*>(lds_c + fx_off[t] + (BUF * X_BYTES + step * 2 * X_ROW));
+                }
+            auto bf = [](u32x4 v) { return __builtin_bit_cast(x3::bf16x8, v); };
+#pragma unroll
+            for (int g = 0; g < NKS; ++g) {
+                const x3::Split sa = x3::split8(make_float4(a8[g][0], a8[g][1], a8[g][2], a8[g][3]),
+                                                make_float4(a8[g][4], a8[g][5], a8[g][6], a8[g][7]));
+#pragma unroll
+                for (int t = 0; t < TK; ++t) {
+                    const x3::Split sb = x3::split8(make_float4(b8[g][t][0], b8[g][t][1], b8[g][t][2], b8[g][t][3]),
+                                                    make_float4(b8[g][t][4], b8[g][t][5], b8[g][t][6], b8[g][t][7]));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.lo), bf(sb.hi), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.hi), bf(sb.lo), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.mid), bf(sb.mid), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.mid), bf(sb.hi), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.hi), bf(sb.mid), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.hi), bf(sb.hi), acc[t], 0, 0, 0);
+                }
+                if (g == 0) pieces<0, NP / NKS>(load_piece, dst);
+                else pieces<NP / 2, NP>(load_piece, dst);
+            }
+        } else if constexpr (!HALF) {
             read_group(0, 0);
 #pragma unroll
             for (int sg = 0; sg < NG; ++sg) {
@@ -1886,6 +1937,11 @@ extern "C" size_t pd_conv2d_wgrad_workspace(long M, int Co, int K) {
     return ((size_t)S * Co * K + (size_t)S * Co) * sizeof(float);
 }
 
+static bool wgrad_x3_on() {                   // read per call: the tests compare both kernels in one process
+    const char* e = getenv("PD_WGRAD_X3");      // default off: 216 vector instructions per 24 MFMAs -- measured 8 % slower
+    return e && e[0] == '1';
+}
+
 extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* workspace, size_t ws_bytes,
                                int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                                int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode,
@@ -1929,6 +1985,14 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
         if (tco == 32) {              // 17..32 output channels (decoder 96->32, 64->32): reflect + bias in this network
             if (mode == MODE_ZERO) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 32>), grid, block, 0, st, ua);
             else hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, true, 32>), grid, block, 0, st, ua);
+        } else if (wgrad_x3_on()) {     // products on the bf16 matrix cores (three-way split, fp32 accuracy)
+            if (mode == MODE_ZERO) {
+                if (dbias) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 64, true>), grid, block, 0, st, ua);
+                else hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, false, 64, true>), grid, block, 0, st, ua);
+            } else {
+                if (dbias) hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, true, 64, true>), grid, block, 0, st, ua);
+                else hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, false, 64, true>), grid, block, 0, st, ua);
+            }
         } else if (mode == MODE_ZERO) {
             if (dbias) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true>), grid, block, 0, st, ua);
             else hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, false>), grid, block, 0, st, ua);

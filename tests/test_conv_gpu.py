@@ -415,15 +415,16 @@ def test_disparity_head_direct_kernels(case, fused, monkeypatch):
 
 
 X3_CASES = [
-    # N, C, H, W, Co, k, s, p -- shapes of the bf16x3 kernel (M >= 65536, M % 256 == 0, C % 16 == 0, Co % 64 == 0): the
-    # 64-channel 3x3 / 5x5 layers of the shallow encoders, a stride-2 layer, 16 | C only, two column tiles, a tile
-    # spanning two images
-    (1, 64, 256, 320, 64, 3, 1, 1),
-    (1, 64, 256, 320, 64, 5, 1, 2),
+    # N, C, H, W, Co, k, s, p -- shapes of the bf16x3 kernel (M % 256 == 0, >= 512 tiles of 256 x 64, C % 16 == 0,
+    # Co % 64 == 0): the 64-channel 3x3 / 5x5 layers of the shallow encoders, a stride-2 layer, 16 | C only, two column
+    # tiles, a tile spanning two images, a small-M layer with 64-row statistics tiles (M < 65536)
+    (2, 64, 256, 320, 64, 3, 1, 1),
+    (2, 64, 256, 320, 64, 5, 1, 2),
     (1, 64, 512, 640, 128, 3, 2, 1),
-    (2, 48, 256, 160, 64, 3, 1, 1),
+    (4, 48, 256, 160, 64, 3, 1, 1),
     (1, 32, 256, 320, 128, 3, 1, 1),
-    (16, 64, 72, 60, 64, 3, 1, 1),
+    (32, 64, 72, 60, 64, 3, 1, 1),
+    (4, 64, 64, 80, 512, 3, 1, 1),
 ]
 
 
@@ -431,16 +432,18 @@ X3_CASES = [
 def test_bf16x3_kernel_keeps_fp32_accuracy(case, monkeypatch):
     """fp32 products as six bf16 MFMAs of a three-way split (conv_igemm_x3_kernel): compared with an fp64 convolution, next
     to the fp32-MFMA kernel on the same input.  Bar: the error of the split kernel is at most 1.5x the fp32 kernel's (both
-    are accumulation-order noise of ~1e-7 of the output scale), and both pass the suite's tolerance."""
+    are accumulation-order noise of ~1e-6 of the output scale at K = 576 .. 1600), and both pass the suite's tolerance."""
     N, C, H, W, Co, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, C, H, W, generator=g)
     x[:, :, : H // 2] *= 37.0                                   # two scales in one tensor
     w = torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5
-    ref = F.conv2d(x.double(), w.double(), None, stride=s, padding=p)
+    b = torch.randn(Co, generator=g) if sum(case) % 2 == 0 else None         # (the encoders' convolutions carry a bias)
+    ref = F.conv2d(x.double(), w.double(), b.double() if b is not None else None, stride=s, padding=p)
     dy = torch.randn(ref.shape, generator=g)
     add = torch.randn(N, C, H, W, generator=g)
     ref_dx = None
+    bd = b.cuda() if b is not None else None
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     wd = w.cuda().contiguous(memory_format=torch.channels_last)
     dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
@@ -449,17 +452,24 @@ def test_bf16x3_kernel_keeps_fp32_accuracy(case, monkeypatch):
         ref_dx = F.conv_transpose2d(dy.double(), w.double(), None, stride=1, padding=p) + add.double()
     scale = ref.abs().max().item()
     errs, stats, dxe = {}, {}, {}
+    dwe = {}
+    ref_dw = torch.autograd.grad(F.conv2d(x.double(), wv := w.double().requires_grad_(True), None, stride=s, padding=p), wv, dy.double())[0]
     for knob in ("1", "0"):
         monkeypatch.setenv("PD_CONV_X3", knob)
-        y, st = ops.conv2d_fwd(xd, wd, None, stride=s, pad=p, want_stats=True)
+        monkeypatch.setenv("PD_WGRAD_X3", knob)
+        dw = ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p)
+        dwe[knob] = (dw.cpu().double() - ref_dw).abs().max().item() / ref_dw.abs().max().item()
+        y, st = ops.conv2d_fwd(xd, wd, bd, stride=s, pad=p, want_stats=True)
         errs[knob] = (y.cpu().double() - ref).abs().max().item() / scale
         stats[knob] = st.double().sum(0).cpu()
         if s == 1:
             dx = ops.conv2d_dgrad(dyd, wd, (H, W), stride=1, pad=p, addend=addd)
             dxe[knob] = (dx.cpu().double() - ref_dx).abs().max().item() / ref_dx.abs().max().item()
-    assert errs["1"] <= 2e-6 and errs["0"] <= 2e-6, errs
+    assert errs["1"] <= 5e-6 and errs["0"] <= 5e-6, errs
     assert errs["1"] <= 1.5 * errs["0"] + 1e-8, errs
     _close(stats["1"][:, 0], ref.sum((0, 2, 3)), 1e-5)
     _close(stats["1"][:, 1], (ref ** 2).sum((0, 2, 3)), 1e-5)
     if s == 1:
-        assert dxe["1"] <= 2e-6 and dxe["1"] <= 1.5 * dxe["0"] + 1e-8, dxe
+        assert dxe["1"] <= 5e-6 and dxe["1"] <= 1.5 * dxe["0"] + 1e-8, dxe
+    # the weight gradient sums 65536+ products per element: slices of <= 4096 pixels in fp32, partial tiles added in order
+    assert dwe["1"] <= 2e-5 and dwe["1"] <= 1.5 * dwe["0"] + 1e-7, dwe
