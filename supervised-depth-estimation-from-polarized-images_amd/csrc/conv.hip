@@ -943,11 +943,16 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
     };
     auto bf = [](u32x4 v) { return __builtin_bit_cast(bf16x8, v); };
 
-    // One chunk: pieces of the next chunks first (they land under everything below), fragments, split, 24 MFMAs, then
-    // the weight split of the next chunk.
+    // One chunk: pieces of the next chunks first (they land under everything below), fragments, then 24 MFMAs with the
+    // vector work threaded between them IN PROGRAM ORDER: a wave issues in order, so a split placed behind a run of MFMAs
+    // waits until the matrix pipe has accepted the last of them (32 cycles each) -- SQ counters of the straightforward
+    // order: matrix pipe busy 61 %, waves waiting for issue 59 % of their cycles.  Here only the split of row block 0 is
+    // exposed; row block 1 is split three instructions at a time behind the MFMAs of block 0, the weights of the next chunk
+    // behind those of block 1.  The two column blocks alternate, so consecutive MFMAs never share an accumulator.
     auto chunk = [&](auto buf_tag) {
         constexpr unsigned BUF = decltype(buf_tag)::value;
         const std::integral_constant<unsigned, BUF ^ 1> nxt{};
+        constexpr unsigned NXT = BUF ^ 1;
         pieces<0, 4>(load_a, nxt);
         load_b(buf_tag);
         advance_a();
@@ -963,20 +968,56 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 fb[j][t] = *reinterpret_cast<const u32x4*>(lds_c + fb_off + ((BUF * 3 + t) * BP_BYTES + (unsigned)j * 32 * CK * 2));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const Split sa = split8(fa[i][0], fa[i][1]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.lo), bf(fb[j][0]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.hi), bf(fb[j][2]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.mid), bf(fb[j][1]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.mid), bf(fb[j][0]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.hi), bf(fb[j][1]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(sa.hi), bf(fb[j][0]), acc[i][j], 0, 0, 0);
+        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + NXT * BS_BYTES);      // next chunk's weights (fp32)
+        const Split s0 = split8(fa[0][0], fa[0][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // three-instruction stages of split2() on pair P of eight values
+        const float xs[8] = {fa[1][0].x, fa[1][0].y, fa[1][0].z, fa[1][0].w, fa[1][1].x, fa[1][1].y, fa[1][1].z, fa[1][1].w};
+        const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+        unsigned h1[4], m1[4], l1[4], hw[2], mw[2], lw[2];
+        f32x2 tf[4], tr[4];
+        auto stage = [&](const float* x, unsigned* h, unsigned* m, unsigned* l, auto p_tag, auto s_tag) {
+            constexpr int P = decltype(p_tag)::value, S = decltype(s_tag)::value;
+            if constexpr (S == 0) {
+                h[P] = cvt_pk_bf16(x[2 * P], x[2 * P + 1]);
+                tf[P] = f32x2{__uint_as_float(h[P] << 16), __uint_as_float(h[P] & 0xffff0000u)};
+            } else if constexpr (S == 1) {
+                tr[P] = f32x2{x[2 * P], x[2 * P + 1]} - tf[P];
+                m[P] = cvt_pk_bf16(tr[P].x, tr[P].y);
+                tf[P].x = __uint_as_float(m[P] << 16);
+            } else {
+                tf[P].y = __uint_as_float(m[P] & 0xffff0000u);
+                const f32x2 r2 = tr[P] - tf[P];
+                l[P] = cvt_pk_bf16(r2.x, r2.y);
             }
-        }
-        split_b(nxt);
+        };
+        // MFMA number N (0..11) of row block I: term pair N/2 (small terms first), column block N%2
+        auto mm = [&](const Split& sa, auto i_tag, auto n_tag) {
+            constexpr int I = decltype(i_tag)::value, N = decltype(n_tag)::value, T = N / 2, J = N % 2;
+            const u32x4 av = T == 0 ? sa.lo : (T == 2 || T == 3) ? sa.mid : sa.hi;
+            const u32x4 bv = T == 0 ? fb[J][0] : T == 1 ? fb[J][2] : T == 2 ? fb[J][1] : T == 3 ? fb[J][0] : T == 4 ? fb[J][1] : fb[J][0];
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(av), bf(bv), acc[I][J], 0, 0, 0);
+        };
+#define PD_I(n) std::integral_constant<int, n>{}
+#define PD_M0(n) mm(s0, PD_I(0), PD_I(n)); stage(xs, h1, m1, l1, PD_I((n) / 3), PD_I((n) % 3)); __builtin_amdgcn_sched_barrier(0);
+        PD_M0(0) PD_M0(1) PD_M0(2) PD_M0(3) PD_M0(4) PD_M0(5) PD_M0(6) PD_M0(7) PD_M0(8) PD_M0(9) PD_M0(10) PD_M0(11)
+#undef PD_M0
+        Split s1;
+        s1.hi = u32x4{h1[0], h1[1], h1[2], h1[3]}; s1.mid = u32x4{m1[0], m1[1], m1[2], m1[3]}; s1.lo = u32x4{l1[0], l1[1], l1[2], l1[3]};
+#define PD_M1(n) mm(s1, PD_I(1), PD_I(n)); stage(ws, hw, mw, lw, PD_I((n) / 3), PD_I((n) % 3)); __builtin_amdgcn_sched_barrier(0);
+        PD_M1(0) PD_M1(1) PD_M1(2) PD_M1(3) PD_M1(4) PD_M1(5)
+#undef PD_M1
+        mm(s1, PD_I(1), PD_I(6));
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{hw[0], hw[1]};
+        __builtin_amdgcn_sched_barrier(0);
+        mm(s1, PD_I(1), PD_I(7));
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{mw[0], mw[1]};
+        __builtin_amdgcn_sched_barrier(0);
+        mm(s1, PD_I(1), PD_I(8));
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{lw[0], lw[1]};
+        __builtin_amdgcn_sched_barrier(0);
+        mm(s1, PD_I(1), PD_I(9)); mm(s1, PD_I(1), PD_I(10)); mm(s1, PD_I(1), PD_I(11));
+#undef PD_I
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
