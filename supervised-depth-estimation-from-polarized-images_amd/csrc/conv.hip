@@ -947,8 +947,10 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
     // vector work threaded between them IN PROGRAM ORDER: a wave issues in order, so a split placed behind a run of MFMAs
     // waits until the matrix pipe has accepted the last of them (32 cycles each) -- SQ counters of the straightforward
     // order: matrix pipe busy 61 %, waves waiting for issue 59 % of their cycles.  Here only the split of row block 0 is
-    // exposed; row block 1 is split three instructions at a time behind the MFMAs of block 0, the weights of the next chunk
-    // behind those of block 1.  The two column blocks alternate, so consecutive MFMAs never share an accumulator.
+    // exposed... and of that only its four hi conversions: the products are issued largest terms first (hi*hi, hi*mid, hi*lo,
+    // mid*hi, mid*mid, lo*hi), in the order the split yields the terms, and mid / lo of a block are computed behind the
+    // MFMAs that need only hi; the split of row block 1 and of the next chunk's weights ride behind the rest.  The two column
+    // blocks alternate, so consecutive MFMAs never share an accumulator.
     auto chunk = [&](auto buf_tag) {
         constexpr unsigned BUF = decltype(buf_tag)::value;
         const std::integral_constant<unsigned, BUF ^ 1> nxt{};
@@ -969,54 +971,72 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
             for (int t = 0; t < 3; ++t)
                 fb[j][t] = *reinterpret_cast<const u32x4*>(lds_c + fb_off + ((BUF * 3 + t) * BP_BYTES + (unsigned)j * 32 * CK * 2));
         const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + NXT * BS_BYTES);      // next chunk's weights (fp32)
-        const Split s0 = split8(fa[0][0], fa[0][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        // three-instruction stages of split2() on pair P of eight values
-        const float xs[8] = {fa[1][0].x, fa[1][0].y, fa[1][0].z, fa[1][0].w, fa[1][1].x, fa[1][1].y, fa[1][1].z, fa[1][1].w};
+        const float x0[8] = {fa[0][0].x, fa[0][0].y, fa[0][0].z, fa[0][0].w, fa[0][1].x, fa[0][1].y, fa[0][1].z, fa[0][1].w};
+        const float x1[8] = {fa[1][0].x, fa[1][0].y, fa[1][0].z, fa[1][0].w, fa[1][1].x, fa[1][1].y, fa[1][1].z, fa[1][1].w};
         const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
-        unsigned h1[4], m1[4], l1[4], hw[2], mw[2], lw[2];
-        f32x2 tf[4], tr[4];
-        auto stage = [&](const float* x, unsigned* h, unsigned* m, unsigned* l, auto p_tag, auto s_tag) {
-            constexpr int P = decltype(p_tag)::value, S = decltype(s_tag)::value;
-            if constexpr (S == 0) {
-                h[P] = cvt_pk_bf16(x[2 * P], x[2 * P + 1]);
-                tf[P] = f32x2{__uint_as_float(h[P] << 16), __uint_as_float(h[P] & 0xffff0000u)};
-            } else if constexpr (S == 1) {
-                tr[P] = f32x2{x[2 * P], x[2 * P + 1]} - tf[P];
-                m[P] = cvt_pk_bf16(tr[P].x, tr[P].y);
-                tf[P].x = __uint_as_float(m[P] << 16);
-            } else {
-                tf[P].y = __uint_as_float(m[P] & 0xffff0000u);
-                const f32x2 r2 = tr[P] - tf[P];
-                l[P] = cvt_pk_bf16(r2.x, r2.y);
-            }
+        // split2() on pair P of a value array, in steps: H (hi, 1 instruction), M (mid, 5), L (lo, 3)
+        struct Terms { unsigned h[4], m[4], l[4]; f32x2 tf[4], tr[4]; };
+        Terms t0, t1, tw;
+        auto sp_h = [&](const float* x, Terms& t, auto p_tag) {
+            constexpr int P = decltype(p_tag)::value;
+            t.h[P] = cvt_pk_bf16(x[2 * P], x[2 * P + 1]);
         };
-        // MFMA number N (0..11) of row block I: term pair N/2 (small terms first), column block N%2
-        auto mm = [&](const Split& sa, auto i_tag, auto n_tag) {
+        auto sp_m = [&](const float* x, Terms& t, auto p_tag) {
+            constexpr int P = decltype(p_tag)::value;
+            t.tf[P] = f32x2{__uint_as_float(t.h[P] << 16), __uint_as_float(t.h[P] & 0xffff0000u)};
+            t.tr[P] = f32x2{x[2 * P], x[2 * P + 1]} - t.tf[P];
+            t.m[P] = cvt_pk_bf16(t.tr[P].x, t.tr[P].y);
+            t.tf[P].x = __uint_as_float(t.m[P] << 16);
+        };
+        auto sp_l = [&](Terms& t, auto p_tag) {
+            constexpr int P = decltype(p_tag)::value;
+            t.tf[P].y = __uint_as_float(t.m[P] & 0xffff0000u);
+            const f32x2 r2 = t.tr[P] - t.tf[P];
+            t.l[P] = cvt_pk_bf16(r2.x, r2.y);
+        };
+        // MFMA number N (0..11) of row block I, largest terms first (what a block needs first is what its split yields
+        // first): hi*hi, hi*mid, hi*lo, mid*hi, mid*mid, lo*hi; column block N % 2
+        auto mm = [&](const Terms& t, auto i_tag, auto n_tag) {
             constexpr int I = decltype(i_tag)::value, N = decltype(n_tag)::value, T = N / 2, J = N % 2;
-            const u32x4 av = T == 0 ? sa.lo : (T == 2 || T == 3) ? sa.mid : sa.hi;
-            const u32x4 bv = T == 0 ? fb[J][0] : T == 1 ? fb[J][2] : T == 2 ? fb[J][1] : T == 3 ? fb[J][0] : T == 4 ? fb[J][1] : fb[J][0];
-            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(av), bf(bv), acc[I][J], 0, 0, 0);
+            const unsigned* av = T < 3 ? t.h : T < 5 ? t.m : t.l;
+            const u32x4 bv = T == 0 ? fb[J][0] : T == 1 ? fb[J][1] : T == 2 ? fb[J][2] : T == 3 ? fb[J][0] : T == 4 ? fb[J][1] : fb[J][0];
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(u32x4{av[0], av[1], av[2], av[3]}), bf(bv), acc[I][J], 0, 0, 0);
         };
 #define PD_I(n) std::integral_constant<int, n>{}
-#define PD_M0(n) mm(s0, PD_I(0), PD_I(n)); stage(xs, h1, m1, l1, PD_I((n) / 3), PD_I((n) % 3)); __builtin_amdgcn_sched_barrier(0);
-        PD_M0(0) PD_M0(1) PD_M0(2) PD_M0(3) PD_M0(4) PD_M0(5) PD_M0(6) PD_M0(7) PD_M0(8) PD_M0(9) PD_M0(10) PD_M0(11)
-#undef PD_M0
-        Split s1;
-        s1.hi = u32x4{h1[0], h1[1], h1[2], h1[3]}; s1.mid = u32x4{m1[0], m1[1], m1[2], m1[3]}; s1.lo = u32x4{l1[0], l1[1], l1[2], l1[3]};
-#define PD_M1(n) mm(s1, PD_I(1), PD_I(n)); stage(ws, hw, mw, lw, PD_I((n) / 3), PD_I((n) % 3)); __builtin_amdgcn_sched_barrier(0);
-        PD_M1(0) PD_M1(1) PD_M1(2) PD_M1(3) PD_M1(4) PD_M1(5)
-#undef PD_M1
-        mm(s1, PD_I(1), PD_I(6));
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{hw[0], hw[1]};
-        __builtin_amdgcn_sched_barrier(0);
-        mm(s1, PD_I(1), PD_I(7));
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{mw[0], mw[1]};
-        __builtin_amdgcn_sched_barrier(0);
-        mm(s1, PD_I(1), PD_I(8));
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{lw[0], lw[1]};
-        __builtin_amdgcn_sched_barrier(0);
-        mm(s1, PD_I(1), PD_I(9)); mm(s1, PD_I(1), PD_I(10)); mm(s1, PD_I(1), PD_I(11));
+#define PD_SB __builtin_amdgcn_sched_barrier(0);
+        sp_h(x0, t0, PD_I(0)); sp_h(x0, t0, PD_I(1)); sp_h(x0, t0, PD_I(2)); sp_h(x0, t0, PD_I(3));
+        PD_SB
+        // row block 0: its mid terms behind MFMAs 0..3, the weights' first pair behind 4..5, its lo terms (and block 1's hi)
+        // behind 6..9
+        mm(t0, PD_I(0), PD_I(0)); sp_m(x0, t0, PD_I(0)); PD_SB
+        mm(t0, PD_I(0), PD_I(1)); sp_m(x0, t0, PD_I(1)); PD_SB
+        mm(t0, PD_I(0), PD_I(2)); sp_m(x0, t0, PD_I(2)); PD_SB
+        mm(t0, PD_I(0), PD_I(3)); sp_m(x0, t0, PD_I(3)); PD_SB
+        mm(t0, PD_I(0), PD_I(4)); sp_h(ws, tw, PD_I(0)); sp_h(ws, tw, PD_I(1)); PD_SB
+        mm(t0, PD_I(0), PD_I(5)); sp_m(ws, tw, PD_I(0)); PD_SB
+        mm(t0, PD_I(0), PD_I(6)); sp_l(t0, PD_I(0)); sp_h(x1, t1, PD_I(0)); PD_SB
+        mm(t0, PD_I(0), PD_I(7)); sp_l(t0, PD_I(1)); sp_h(x1, t1, PD_I(1)); PD_SB
+        mm(t0, PD_I(0), PD_I(8)); sp_l(t0, PD_I(2)); sp_h(x1, t1, PD_I(2)); PD_SB
+        mm(t0, PD_I(0), PD_I(9)); sp_l(t0, PD_I(3)); sp_h(x1, t1, PD_I(3)); PD_SB
+        mm(t0, PD_I(0), PD_I(10)); sp_m(ws, tw, PD_I(1)); PD_SB
+        mm(t0, PD_I(0), PD_I(11)); sp_l(tw, PD_I(0)); PD_SB
+        // row block 1
+        mm(t1, PD_I(1), PD_I(0)); sp_m(x1, t1, PD_I(0)); PD_SB
+        mm(t1, PD_I(1), PD_I(1)); sp_m(x1, t1, PD_I(1)); PD_SB
+        mm(t1, PD_I(1), PD_I(2)); sp_m(x1, t1, PD_I(2)); PD_SB
+        mm(t1, PD_I(1), PD_I(3)); sp_m(x1, t1, PD_I(3)); PD_SB
+        mm(t1, PD_I(1), PD_I(4)); sp_l(tw, PD_I(1)); PD_SB
+        mm(t1, PD_I(1), PD_I(5));
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
+        PD_SB
+        mm(t1, PD_I(1), PD_I(6)); sp_l(t1, PD_I(0)); PD_SB
+        mm(t1, PD_I(1), PD_I(7)); sp_l(t1, PD_I(1)); PD_SB
+        mm(t1, PD_I(1), PD_I(8)); sp_l(t1, PD_I(2)); PD_SB
+        mm(t1, PD_I(1), PD_I(9)); sp_l(t1, PD_I(3)); PD_SB
+        mm(t1, PD_I(1), PD_I(10)); mm(t1, PD_I(1), PD_I(11));
+#undef PD_SB
 #undef PD_I
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
