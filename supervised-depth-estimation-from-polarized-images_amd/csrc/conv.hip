@@ -1207,6 +1207,16 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int pd_conv2d_uses_x3(long M, int Co, int C, int KH, int KW, int stride, int pad, int mode, int act,
+                                 int has_out_scale) {
+    ConvArgs a{};
+    a.M = M; a.Co = Co; a.C = C; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = a.pad_w = pad; a.mode = mode; a.act = act;
+    a.K = KH * KW * C; a.ldy = Co;
+    a.oscale = has_out_scale ? reinterpret_cast<const float*>(16) : nullptr;
+    while ((1 << a.sshift) < stride) ++a.sshift;
+    return x3_eligible(a, true) ? 1 : 0;
+}
+
 extern "C" int pd_conv2d_tile_m(long M, int Co) {
     if (Co <= 32) return 128;   // 128x32 tile: four waves of one 32x32 MFMA tile each
     static const int forced = getenv("PD_CONV_BM") ? atoi(getenv("PD_CONV_BM")) : 0;   // tuning aid: 64 or 128

@@ -27,8 +27,10 @@ def _profiled(label, flops, fn, shape=None):
     return r
 
 
-def _igemm_label(M, Co, vec, kind, C=0, KH=1, KW=1, stride=1, pad=0, mode=0):
+def _igemm_label(M, Co, vec, kind, C=0, KH=1, KW=1, stride=1, pad=0, mode=0, act=ACT_NONE, out_scale=False):
     """Profiler label = the kernel family pd_conv2d launches for this call (same rule as launch_conv in conv.hip)."""
+    if vec and lib.pd_conv2d_uses_x3(M, Co, C, KH, KW, stride, pad, mode, act, int(out_scale)):
+        return "conv_igemm_x3_kernel<256,64>"
     bm = lib.pd_conv2d_tile_m(M, Co)
     bn = 64 if Co > 32 else (32 if Co > 16 else 16)
     uni = (vec and bn >= 32 and C % 32 == 0 and C > 0 and KH * KW <= 31 and pad < KH and pad < KW and
@@ -111,7 +113,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
                                               0, act, stream_ptr()), "pd_conv16"),
                   shape=("fwd", N, C, H, W, Co, KH, stride, mode))
         return out
-    _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd", C, KH, KW, stride, pad, mode), 2.0 * N * Ho * Wo * Co * (alg_k if alg_k is not None else C * KH * KW),
+    _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd", C, KH, KW, stride, pad, mode, act, out_scale is not None), 2.0 * N * Ho * Wo * Co * (alg_k if alg_k is not None else C * KH * KW),
               lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out_scale), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
                                           Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub,
                                           div, ldy, stream_ptr()), "pd_conv2d"),

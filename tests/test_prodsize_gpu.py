@@ -56,8 +56,12 @@ PROD_CASES = [
 ]
 
 
+@pytest.mark.parametrize("x3", ["0", "1"])
 @pytest.mark.parametrize("case", PROD_CASES)
-def test_production_tile_conv_forward_dgrad_wgrad(case):
+def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
+    """x3 = "0": every launch on the fp32-MFMA production tiles; "1" (the default): the shapes pd_conv2d_uses_x3 accepts go
+    to the bf16-split kernel (256 x 64 tiles), the others stay where they were."""
+    monkeypatch.setenv("PD_CONV_X3", x3)
     N, C, H, W, Co, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, C, H, W, generator=g)
@@ -71,8 +75,13 @@ def test_production_tile_conv_forward_dgrad_wgrad(case):
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     wd = w.cuda().contiguous(memory_format=torch.channels_last)
 
+    def expect(Mx, Cox, Cx, sx, mode):
+        uses = ops.lib.pd_conv2d_uses_x3(Mx, Cox, Cx, k, k, sx, p, mode, 0, 0)
+        assert uses == (x3 == "1" and Mx % 256 == 0 and Cox % 64 == 0 and Cx % 16 == 0 and (Mx // 256) * (Cox // 64) >= 512)
+        return ["conv_igemm_x3_kernel<256,64>" if uses else "conv_igemm_uni_kernel<128,64>"]
+
     (y, stats), lab = _labels(lambda: ops.conv2d_fwd(xd, wd, None, stride=s, pad=p, want_stats=True))
-    assert lab == ["conv_igemm_uni_kernel<128,64>"], lab
+    assert lab == expect(M, Co, C, s, 0), lab
     _close(y.cpu(), ref.detach(), what="fwd")
     # BatchNorm partials of the transposed epilogue: one row per 128-pixel tile
     assert stats.shape[0] == (M + 127) // 128
@@ -93,7 +102,7 @@ def test_production_tile_conv_forward_dgrad_wgrad(case):
 
     dx, lab = _labels(lambda: ops.conv2d_dgrad(dyd, wd, (H, W), stride=s, pad=p))
     if s == 1:
-        assert lab == ["conv_igemm_uni_kernel<128,64>"], lab
+        assert lab == expect(N * H * W, C, Co, 1, 2), lab
     else:
         assert lab == ["conv_dgrad_s2_phases"], lab
     _close(dx.cpu(), xr.grad, what="dgrad")
@@ -265,7 +274,8 @@ def test_full_resolution_training_step_matches_oracle(tmp_path):
         return outputs, losses
     (outputs, losses), lab = _labels(step)
     torch.cuda.synchronize()
-    assert lab.count("conv_igemm_uni_kernel<128,64>") >= 30, f"production tile not exercised: {lab.count('conv_igemm_uni_kernel<128,64>')}"
+    n_prod = lab.count("conv_igemm_uni_kernel<128,64>") + lab.count("conv_igemm_x3_kernel<256,64>")
+    assert n_prod >= 30, f"production tiles not exercised: {n_prod}"
     gpu_grads = {f"{mn}.{k}": v.grad.detach().cpu().clone() for mn in tr.models for k, v in tr.models[mn].named_parameters()
                  if v.grad is not None}
 
