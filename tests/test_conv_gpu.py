@@ -467,7 +467,10 @@ def test_bf16x3_kernel_keeps_fp32_accuracy(case, monkeypatch):
             dxe[knob] = (dx.cpu().double() - ref_dx).abs().max().item() / ref_dx.abs().max().item()
     assert errs["1"] <= 5e-6 and errs["0"] <= 5e-6, errs
     assert errs["1"] <= 1.5 * errs["0"] + 1e-8, errs
-    _close(stats["1"][:, 0], ref.sum((0, 2, 3)), 1e-5)
+    # mean of the output vs the reference's, in units of the output's rms (the bf16 MFMA aligns its addends by truncation:
+    # a shift of ~ -1e-7 rms at K = 1600 that a sum over M outputs multiplies by M; see test_prodsize_gpu.py)
+    M = ref.numel() // Co
+    assert (stats["1"][:, 0] - ref.sum((0, 2, 3))).abs().max().item() / M <= 2.5e-7 * ref.pow(2).mean().sqrt().item()
     _close(stats["1"][:, 1], (ref ** 2).sum((0, 2, 3)), 1e-5)
     if s == 1:
         assert dxe["1"] <= 5e-6 and dxe["1"] <= 1.5 * dxe["0"] + 1e-8, dxe

@@ -87,7 +87,14 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
     assert stats.shape[0] == (M + 127) // 128
     tot = stats.double().sum(0).cpu()
     rf = ref.detach().double()
-    _close(tot[:, 0], rf.sum((0, 2, 3)), 1e-5, "stats sum")
+    # The column sums are sums of M zero-mean outputs: their own magnitude (~ sqrt(M)) is no yardstick.  (a) the epilogue's
+    # sums against the sums of the tensor it stored; (b) the mean of the output against the reference's, in units of the
+    # output's rms: the bf16 MFMA truncates (two's complement) where it aligns its addends, which shifts every output of
+    # the split kernel by about -1e-7 rms at K = 1600 (fp32 MFMA: 2e-10) -- far below what a BatchNorm mean can see, but
+    # M times that in the sum
+    yd = y.cpu().double()
+    _close(tot[:, 0], yd.sum((0, 2, 3)), 1e-6, "stats sum vs stored tensor")
+    assert ((tot[:, 0] - rf.sum((0, 2, 3))).abs().max().item() / M) <= 2.5e-7 * rf.pow(2).mean().sqrt().item(), "stats mean"
     _close(tot[:, 1], (rf ** 2).sum((0, 2, 3)), 1e-5, "stats sumsq")
     # ... and the epilogue without statistics, with bias + ReLU (element-wise epilogue of the same tile)
     b = torch.randn(Co, generator=g)
@@ -137,7 +144,8 @@ def test_production_tile_reflection_padded_conv(case):
         PF.sync_wgrad_stream()
         return y
     y, lab = _labels(run)
-    assert lab.count("conv_igemm_uni_kernel<128,64>") == 2 and "conv_wgrad_kernel" in lab, lab
+    # (forward on the REFLECT instantiation; the pad-1 data gradient is a zero-padding launch: fp32 or bf16-split kernel)
+    assert lab.count("conv_igemm_uni_kernel<128,64>") + lab.count("conv_igemm_x3_kernel<256,64>") == 2 and "conv_wgrad_kernel" in lab, lab
     _close(y.detach().cpu(), ref.detach(), 3e-5, "fwd")
     _close(xc.grad.cpu(), xr.grad, 3e-5, "dgrad")
     _close(conv.weight.grad.cpu(), wr.grad, 3e-5, "wgrad")
