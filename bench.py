@@ -378,8 +378,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc):
             with open(pmc) as f:
-                dom_pmc = json.load(f).get("dominant", {})
-            if dom_pmc.get("kernel") == dname:
+                pmc_all = json.load(f)
+            dom_pmc = pmc_all.get("kernels", {}).get(dname) or (pmc_all.get("dominant", {}) if pmc_all.get("dominant", {}).get("kernel") == dname else None)
+            if dom_pmc:
                 traffic, traffic_src = dom_pmc.get("hbm_bytes_per_launch"), "profiles/" + pmc_name
                 break
     # peak of a kernel family: the fp32 MFMA peak, or -- for the kernel that forms every fp32 product from six bf16 MFMAs

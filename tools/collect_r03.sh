@@ -1,7 +1,7 @@
 #!/bin/bash
 # Evidence pass of round 3 (GPU box): bench line (eager + hipGraph), rocprofv3 kernel stats (serial + overlapped), step
 # breakdown, per-layer conv table, HBM traffic PMC passes, K1 timeline / read-schedule microbenchmarks, attention bench.
-# usage: collect_r03.sh a | b   (two gpurun calls: a = bench + kernel stats + PMC traffic, b = per-layer / K1 / attention)
+# usage: collect_r03.sh a | b | k1  (gpurun calls: a = bench + kernel stats + PMC traffic, b = per-layer / bf16x3 / attention, k1 = K1)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ev; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 STAGE=${1:-a}
 if [ "$STAGE" = a ]; then
@@ -18,11 +18,17 @@ python3 $R/tools/pmc_hbm_summary.py $O/fetch $O/write $O/r03_pmc_hbm_traffic.jso
 rm -rf $O/serial $O/overlap $O/fetch $O/write
 echo done a; exit 0
 fi
-python3 $R/tools/profile_layers.py > $O/r03_conv_layers.log 2>&1 || exit 4
+if [ "$STAGE" = k1 ]; then     # K1 evidence (unchanged by the convolution work: run once)
 cd $R
 python3 tools/k1_trace.py 2>&1 | grep event > $O/r03_k1_timeline.log
 tools/bin/membench3 > $O/r03_membench3_read_schedules.log 2>&1
 bash tools/k1_threads.sh 2>&1 | grep GBps > $O/r03_polar_kernel_gbps.log
+echo done k1; exit 0
+fi
+python3 $R/tools/profile_layers.py > $O/r03_conv_layers.log 2>&1 || exit 4
+cd $R
+tools/bin/bf16x3_peak > $O/r03_bf16x3_peak.log 2>&1
+bash tools/sq_prof_k.sh conv_igemm x3_run.py > $O/r03_x3_sq_counters.txt 2>&1
 python3 bench.py --attention --bf16 --no_graph --steps 5 > $O/r03_bench_attention_bf16.json 2> $O/att.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/att -- python3 $R/bench.py --attention --bf16 --steps 2 --warmup 1 --no_cpu_baseline --no_graph > $O/att.log 2>&1

@@ -23,6 +23,10 @@ def short(name):
     m = re.match(r"conv_igemm_uni_kernel<(\d+), (\d+), \d+, \d+, \d+, \d+>", name)
     if m:                      # forward and data-gradient instantiations of one tile share bench.py's label
         return f"conv_igemm_uni_kernel<{m.group(1)},{m.group(2)}>"
+    if name.startswith("conv_igemm_x3_kernel"):      # forward and data gradient of the bf16-split kernel: one label
+        return "conv_igemm_x3_kernel<256,64>"
+    if name.startswith("conv_wgrad"):                # bench.py times every weight-gradient kernel under one label
+        return "conv_wgrad_kernel"
     return name.split("(")[0]
 
 
