@@ -300,8 +300,9 @@ def main():
     # the same eager step with every convolution on the fp32 MFMA (PD_CONV_X3=0 is read per launch): what the bf16x3
     # kernels buy, measured in this process on this GPU
     fp32_only = None
-    if world == 1 and os.environ.get("PD_CONV_X3", "1") != "0" and not args.attention and not args.normals_decoder:
+    if world == 1 and os.environ.get("PD_CONV_X3", "1") != "0" and os.environ.get("PD_WGRAD_X3C", "1") != "0" and not args.attention and not args.normals_decoder:
         os.environ["PD_CONV_X3"] = "0"
+        os.environ["PD_WGRAD_X3C"] = "0"
         try:
             n_ref = min(args.steps, 10)
             for _ in range(2):
@@ -316,6 +317,7 @@ def main():
                          "steps": n_ref, "launch": "eager"}
         finally:
             del os.environ["PD_CONV_X3"]
+            del os.environ["PD_WGRAD_X3C"]
     dp_info = None
     if dist.is_initialized():
         # per-rank view for diagnosing a scaling run: every rank's own loop time (before the MAX) and the part of the last

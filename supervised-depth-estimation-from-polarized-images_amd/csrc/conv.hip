@@ -811,6 +811,21 @@ __device__ __forceinline__ Split split8(const float4 a, const float4 b) {
     s.hi = u32x4{h[0], h[1], h[2], h[3]}; s.mid = u32x4{m[0], m[1], m[2], m[3]}; s.lo = u32x4{l[0], l[1], l[2], l[3]};
     return s;
 }
+// split2() on pair P of a value array in three steps -- hi (1 instruction), mid (5), lo (3) -- so that a kernel can
+// thread them between its MFMAs (program order is issue order)
+struct Terms { unsigned h[4], m[4], l[4]; f32x2 tf[4], tr[4]; };
+template <int P> __device__ __forceinline__ void sp_h(const float* x, Terms& t) { t.h[P] = cvt_pk_bf16(x[2 * P], x[2 * P + 1]); }
+template <int P> __device__ __forceinline__ void sp_m(const float* x, Terms& t) {
+    t.tf[P] = f32x2{__uint_as_float(t.h[P] << 16), __uint_as_float(t.h[P] & 0xffff0000u)};
+    t.tr[P] = f32x2{x[2 * P], x[2 * P + 1]} - t.tf[P];
+    t.m[P] = cvt_pk_bf16(t.tr[P].x, t.tr[P].y);
+    t.tf[P].x = __uint_as_float(t.m[P] << 16);
+}
+template <int P> __device__ __forceinline__ void sp_l(Terms& t) {
+    t.tf[P].y = __uint_as_float(t.m[P] & 0xffff0000u);
+    const f32x2 r2 = t.tr[P] - t.tf[P];
+    t.l[P] = cvt_pk_bf16(r2.x, r2.y);
+}
 }  // namespace x3
 
 template <int MODE>
@@ -1909,6 +1924,281 @@ __global__ __launch_bounds__(NT) void conv_wgrad_uni_kernel(const WgradUniArgs u
     if (do_bias && tid < TCO && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = bsum;
 }
 
+// ===================================================================== weight gradient, bf16-split products ("x3c")
+// The weight gradient contracts over pixels and BOTH operands are activations: split in registers by every wave that
+// needs them (the X3 branch above: 2 x 2 waves, each element split twice) the vector pipe has 216 instructions per 24
+// MFMAs and the kernel loses.  Here every element is split once:
+//   * the four waves take 32 of the 128 k columns each and all 64 output channels (wave tile 64 x 32): a wave's X values
+//     are its own -- eight ds_read_b32 per 16-pixel MFMA step, split in registers (36 instructions per step);
+//   * dY (32 pixels x 64 channels per chunk) is needed by all four waves: it is split ONCE per workgroup, one chunk
+//     ahead, by all 256 threads (thread = channel x pixel octet: eight ds_read_b32 of the fp32 staging tile, 36
+//     instructions, three ds_write_b128) into bf16 planes laid out in fragment order -- an A fragment of the MFMA is one
+//     ds_read_b128;
+//   * dY is staged two chunks ahead (its two-slot ring holds chunk q+1 being split and chunk q+2 in flight), X one;
+//   * the 24 MFMAs of a chunk carry the vector work between them in program order, as in conv_igemm_x3_kernel.
+// Same staging (LDS-DMA pieces, scalar pixel state, border-class masks) as conv_wgrad_uni_kernel; zero padding, 64-wide
+// co tile only.  LDS: 48 KB staging + 2 x 12 KB planes = 72 KB (dynamic), two workgroups per CU.
+namespace x3c {
+constexpr unsigned D_ROW = 64 * 4, X_ROW = WG_K * 4;
+constexpr unsigned D_BYTES = WG_MC * D_ROW, X_BYTES = WG_MC * X_ROW;          // 8 KB, 16 KB
+constexpr unsigned P_BASE = 2 * D_BYTES + 2 * X_BYTES;                        // planes behind the staging tiles (48 KB)
+constexpr unsigned P_BYTES = 3 * 4 * 64 * 16;                                 // [term][k-step][half][co][8 x bf16]
+constexpr unsigned LDS_BYTES = P_BASE + 2 * P_BYTES;                          // 72 KB
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArgs ua) {
+    using namespace x3c;
+    const WgradArgs& a = ua.g;
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    float* smem_all = smem_dyn;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = a.ktiles * a.ctiles * a.S;
+    int b = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (b >= nwg) return;
+    const int kt = b % a.ktiles; b /= a.ktiles;
+    const int ct = b % a.ctiles; b /= a.ctiles;
+    const int s = b;
+    const int co0 = ct * 64, k0 = kt * WG_K;
+    const long mbeg = (long)s * a.mper;
+    const long mend = (mbeg + a.mper < a.M) ? mbeg + a.mper : a.M;
+    const int nrows = (int)(mend - mbeg);
+    const int nchunks = nrows > 0 ? (nrows + WG_MC - 1) / WG_MC : 0;
+    const int hw = a.Ho * a.Wo;
+
+    const int img0 = (int)(mbeg / hw);
+    const long shift = (long)a.pad * (a.sH + a.sW);
+    const long rest = (((long)a.N - img0) * a.sN + shift) * 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
+    const float* dy0 = a.dy + mbeg * a.ldd;
+
+    // ---- per-lane invariants of the staging (see conv_wgrad_uni_kernel)
+    const int xh = lane >> 5;
+    const int kx = k0 + 4 * ((lane & 31) ^ (8 * xh));
+    const int tap = kx / a.C;
+    const int xc = kx - tap * a.C, xkh = tap / a.KW, xkw = tap - xkh * a.KW;
+    const unsigned vx = (unsigned)(xkh * (int)a.sH + (xkw + xh * a.stride) * (int)a.sW + xc) * 4u;
+    const int ncw = 2 * ua.nbw + 1;
+    unsigned xmask = 0x80000000u;
+    if (kx < a.K) {
+        for (int ch = 0; ch <= 2 * ua.nb; ++ch) {
+            const int oh = ch <= ua.nb ? ch : a.Ho - ua.nb + (ch - ua.nb - 1);
+            const bool bad_h = (unsigned)(oh * a.stride - a.pad + xkh) >= (unsigned)a.H;
+            for (int cw = 0; cw < ncw; ++cw) {
+                const int ow = (cw <= ua.nbw ? 2 * cw : a.Wo - 2 * ua.nbw + 2 * (cw - ua.nbw - 1)) + xh;
+                const bool bad_w = (unsigned)(ow * a.stride - a.pad + xkw) >= (unsigned)a.W;
+                xmask |= (unsigned)(bad_h | bad_w) << (ch * ncw + cw);
+            }
+        }
+    } else {
+        xmask = 0xffffffffu;
+    }
+    const int dpi = lane >> 4;                                               // dY piece: lane -> (pixel of the quad, 16-byte slot)
+    const int dco = co0 + 4 * ((lane & 15) ^ (8 * (dpi & 1)));
+    const unsigned vd = dco < a.Co ? (unsigned)(dpi * (int)a.ldd + dco) * 4u : OOB;
+
+    const int st_h4 = a.stride * (int)a.sH * 4, st_w4 = a.stride * (int)a.sW * 4, sn4 = (int)a.sN * 4;
+    const int d_row4 = st_h4 - a.Wo * st_w4, d_img4 = sn4 - a.Ho * st_h4;
+    int s_p = 8 * wave;
+    int s_oh, s_ow, s_soff;
+    {
+        const int m = (int)(mbeg - (long)img0 * hw) + s_p;
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        s_oh = rem / a.Wo; s_ow = rem - s_oh * a.Wo;
+        s_soff = n * sn4 + s_oh * st_h4 + s_ow * st_w4;
+        s_oh = __builtin_amdgcn_readfirstlane(s_oh); s_ow = __builtin_amdgcn_readfirstlane(s_ow);
+        s_soff = __builtin_amdgcn_readfirstlane(s_soff);
+    }
+    int s_qd = 0;                                                            // chunk the next dY pieces fetch
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
+    const unsigned m0_d = lds0 + (unsigned)wave * 8 * D_ROW, m0_x = lds0 + 2 * D_BYTES + (unsigned)wave * 8 * X_ROW;
+
+    // dY pieces of chunk s_qd (four pixels each; rows >= nrows read as zero through the per-instruction descriptor)
+    auto load_d = [&](auto dst_tag) {
+        constexpr unsigned DST = decltype(dst_tag)::value;
+#pragma unroll
+        for (int P = 0; P < 2; ++P) {
+            const int r0 = WG_MC * s_qd + 8 * wave + 4 * P, left = nrows - r0;
+            const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy0 + (long)r0 * a.ldd, left > 0 ? (unsigned)(left * (int)a.ldd) * 4u : 0u);
+            dma16s(rd, m0_d + DST * D_BYTES + P * 4 * D_ROW, vd, 0u);
+        }
+        ++s_qd;
+    };
+    // X piece J (one pixel pair) of the chunk the scalar pixel state points at
+    auto load_x = [&](auto dst_tag, auto piece_tag) {
+        constexpr unsigned DST = decltype(dst_tag)::value;
+        constexpr int J = decltype(piece_tag)::value;
+        const int ch = min(s_oh, ua.nb) + max(s_oh - (a.Ho - ua.nb) + 1, 0);
+        const int pw = s_ow >> 1;
+        const int cw = min(pw, ua.nbw) + max(pw - ((a.Wo >> 1) - ua.nbw) + 1, 0);
+        const unsigned cls = (unsigned)(ch * ncw + cw) | (s_p < nrows ? 0u : 31u);
+        const unsigned bad = __builtin_amdgcn_ubfe(xmask, cls, 1u);
+        dma16s(rx, m0_x + DST * X_BYTES + J * 2 * X_ROW, (bad << 31) + vx, (unsigned)s_soff);
+        constexpr int STEP = J < 3 ? 2 : WG_MC - 6;
+        s_p += STEP; s_ow += STEP; s_soff += STEP * st_w4;
+#pragma unroll
+        for (int w = 0; w < (J < 3 ? 1 : 2); ++w) {
+            const int ow0 = s_ow;
+            s_ow = ow0 >= a.Wo ? ow0 - a.Wo : ow0;
+            s_soff += ow0 >= a.Wo ? d_row4 : 0;
+            const int oh1 = ow0 >= a.Wo ? s_oh + 1 : s_oh;
+            s_soff += oh1 == a.Ho ? d_img4 : 0;
+            s_oh = oh1 == a.Ho ? 0 : oh1;
+        }
+    };
+
+    // ---- fragment / split addresses: lane -> (index inside a 32-wide block = lane % 32, pixel half = lane / 32); the eight
+    // pixels of (k-step g, half h) are 16 g + 2 e + h, e = 0..7 (even | odd pixels: the staging tiles keep odd pixels
+    // XOR 32 floats, so the two half-waves of a ds_read_b32 sit on different banks).
+    // (A k tile with at most 64 valid columns -- the last of K = 576: 4.5 tiles -- leaves waves 2 and 3 multiplying zeros.
+    //  Giving them the second k-step of waves 0 and 1, as conv_wgrad_uni_kernel does, was measured: 141 -> 128 TF on
+    //  5x5x64 @256x320 -- the second copy of the chunk body costs more than the idle MFMAs.)
+    const int fi = lane & 31, fk = lane >> 5;
+    unsigned fx_off = 2 * D_BYTES + fk * X_ROW + 4u * ((unsigned)(wave * 32 + fi) ^ (32u * fk));
+    unsigned pa_off = P_BASE + (unsigned)fk * 1024u + (unsigned)fi * 16u;     // + ((term*2 + g)*2)*1024 + blk*512
+    // dY split: thread -> (channel = lane, octet = wave: k-step wave / 2, half wave % 2)
+    const int sg = wave >> 1, sh = wave & 1;
+    unsigned sd_off = (unsigned)(16 * sg + sh) * D_ROW + 4u * ((unsigned)lane ^ (32u * sh));     // + e * 2 * D_ROW
+    unsigned sp_off = P_BASE + (unsigned)(sg * 2 + sh) * 1024u + (unsigned)lane * 16u;          // + term * 4096
+    asm volatile("" : "+v"(fx_off), "+v"(pa_off), "+v"(sd_off), "+v"(sp_off));
+    char* lds_c = reinterpret_cast<char*>(smem_all);
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = BIAS && a.bpart != nullptr && kt == 0;
+    auto bf = [](u32x4 v) { return __builtin_bit_cast(x3::bf16x8, v); };
+
+    // dY staging slot SRC -> planes SRC (and the bias partial of this thread's channel and pixel octet): prologue only
+    auto split_d = [&](auto src_tag) {
+        constexpr unsigned SRC = decltype(src_tag)::value;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(lds_c + sd_off + (SRC * D_BYTES + (unsigned)e * 2 * D_ROW));
+        if constexpr (BIAS) bsum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        const x3::Split sd = x3::split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+        *reinterpret_cast<u32x4*>(lds_c + sp_off + (SRC * P_BYTES + 0 * 4096u)) = sd.hi;
+        *reinterpret_cast<u32x4*>(lds_c + sp_off + (SRC * P_BYTES + 1 * 4096u)) = sd.mid;
+        *reinterpret_cast<u32x4*>(lds_c + sp_off + (SRC * P_BYTES + 2 * 4096u)) = sd.lo;
+    };
+
+    // One chunk: 24 MFMAs with the vector work threaded between them in program order (see conv_igemm_x3_kernel).  X is the
+    // B operand: products in the order its split yields the terms -- (hi, mid, lo of dY) x hi, (hi, mid) x mid, hi x lo.
+    auto chunk = [&](auto buf_tag) {
+        constexpr unsigned BUF = decltype(buf_tag)::value, NXT = BUF ^ 1;
+        const std::integral_constant<unsigned, NXT> nxt{};
+        load_x(nxt, std::integral_constant<int, 0>{});
+        load_x(nxt, std::integral_constant<int, 1>{});
+        load_d(buf_tag);                                   // chunk q + 2 into the slot whose chunk q was split during chunk q - 1
+        load_x(nxt, std::integral_constant<int, 2>{});
+        load_x(nxt, std::integral_constant<int, 3>{});
+        float x0[8], x1[8], dv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x0[e] = *reinterpret_cast<const float*>(lds_c + fx_off + (BUF * X_BYTES + (unsigned)e * 2 * X_ROW));
+        u32x4 fa[2][2][3];                                 // [k-step][co block][term]
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    fa[g][blk][t] = *reinterpret_cast<const u32x4*>(lds_c + pa_off + (BUF * P_BYTES + (unsigned)((t * 2 + g) * 2) * 1024u + blk * 512u));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x1[e] = *reinterpret_cast<const float*>(lds_c + fx_off + (BUF * X_BYTES + (unsigned)(8 + e) * 2 * X_ROW));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dv[e] = *reinterpret_cast<const float*>(lds_c + sd_off + (NXT * D_BYTES + (unsigned)e * 2 * D_ROW));
+        x3::Terms t0, t1, td;
+        // MFMA number N (0..11) of k-step G: term pair N / 2, co block N % 2
+        auto mm = [&](const x3::Terms& t, auto g_tag, auto n_tag) {
+            constexpr int G = decltype(g_tag)::value, N = decltype(n_tag)::value, T = N / 2, BLK = N % 2;
+            const unsigned* bv = T < 3 ? t.h : T < 5 ? t.m : t.l;
+            const u32x4 av = T == 0 ? fa[G][BLK][0] : T == 1 ? fa[G][BLK][1] : T == 2 ? fa[G][BLK][2] : T == 3 ? fa[G][BLK][0] : T == 4 ? fa[G][BLK][1] : fa[G][BLK][0];
+            acc[BLK] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(av), bf(u32x4{bv[0], bv[1], bv[2], bv[3]}), acc[BLK], 0, 0, 0);
+        };
+#define PD_I(n) std::integral_constant<int, n>{}
+#define PD_SB __builtin_amdgcn_sched_barrier(0);
+        x3::sp_h<0>(x0, t0); x3::sp_h<1>(x0, t0); x3::sp_h<2>(x0, t0); x3::sp_h<3>(x0, t0);
+        PD_SB
+        mm(t0, PD_I(0), PD_I(0)); x3::sp_m<0>(x0, t0); PD_SB
+        mm(t0, PD_I(0), PD_I(1)); x3::sp_m<1>(x0, t0); PD_SB
+        mm(t0, PD_I(0), PD_I(2)); x3::sp_m<2>(x0, t0); PD_SB
+        mm(t0, PD_I(0), PD_I(3)); x3::sp_m<3>(x0, t0); PD_SB
+        mm(t0, PD_I(0), PD_I(4)); x3::sp_h<0>(dv, td); x3::sp_h<1>(dv, td); x3::sp_h<2>(dv, td); x3::sp_h<3>(dv, td); PD_SB
+        mm(t0, PD_I(0), PD_I(5)); x3::sp_m<0>(dv, td); PD_SB
+        mm(t0, PD_I(0), PD_I(6)); x3::sp_l<0>(t0); x3::sp_h<0>(x1, t1); PD_SB
+        mm(t0, PD_I(0), PD_I(7)); x3::sp_l<1>(t0); x3::sp_h<1>(x1, t1); PD_SB
+        mm(t0, PD_I(0), PD_I(8)); x3::sp_l<2>(t0); x3::sp_h<2>(x1, t1); PD_SB
+        mm(t0, PD_I(0), PD_I(9)); x3::sp_l<3>(t0); x3::sp_h<3>(x1, t1); PD_SB
+        mm(t0, PD_I(0), PD_I(10)); x3::sp_m<1>(dv, td); PD_SB
+        mm(t0, PD_I(0), PD_I(11)); x3::sp_m<2>(dv, td); PD_SB
+        mm(t1, PD_I(1), PD_I(0)); x3::sp_m<0>(x1, t1); PD_SB
+        mm(t1, PD_I(1), PD_I(1)); x3::sp_m<1>(x1, t1); PD_SB
+        mm(t1, PD_I(1), PD_I(2)); x3::sp_m<2>(x1, t1); PD_SB
+        mm(t1, PD_I(1), PD_I(3)); x3::sp_m<3>(x1, t1); PD_SB
+        mm(t1, PD_I(1), PD_I(4)); x3::sp_m<3>(dv, td); PD_SB
+        mm(t1, PD_I(1), PD_I(5)); x3::sp_l<0>(td); x3::sp_l<1>(td); PD_SB
+        mm(t1, PD_I(1), PD_I(6)); x3::sp_l<0>(t1); PD_SB
+        mm(t1, PD_I(1), PD_I(7)); x3::sp_l<1>(t1); PD_SB
+        mm(t1, PD_I(1), PD_I(8)); x3::sp_l<2>(t1); PD_SB
+        mm(t1, PD_I(1), PD_I(9)); x3::sp_l<3>(t1); PD_SB
+        mm(t1, PD_I(1), PD_I(10)); x3::sp_l<2>(td); x3::sp_l<3>(td); PD_SB
+        mm(t1, PD_I(1), PD_I(11));
+        if constexpr (BIAS) bsum += ((dv[0] + dv[1]) + (dv[2] + dv[3])) + ((dv[4] + dv[5]) + (dv[6] + dv[7]));
+        *reinterpret_cast<u32x4*>(lds_c + sp_off + (NXT * P_BYTES + 0 * 4096u)) = u32x4{td.h[0], td.h[1], td.h[2], td.h[3]};
+        *reinterpret_cast<u32x4*>(lds_c + sp_off + (NXT * P_BYTES + 1 * 4096u)) = u32x4{td.m[0], td.m[1], td.m[2], td.m[3]};
+        *reinterpret_cast<u32x4*>(lds_c + sp_off + (NXT * P_BYTES + 2 * 4096u)) = u32x4{td.l[0], td.l[1], td.l[2], td.l[3]};
+#undef PD_SB
+#undef PD_I
+        dma_wait();
+        __syncthreads();
+    };
+
+    // ---- prologue: X of chunk 0, dY of chunks 0 and 1; planes of chunk 0
+    {
+        const std::integral_constant<unsigned, 0> d0{};
+        const std::integral_constant<unsigned, 1> d1{};
+        load_x(d0, std::integral_constant<int, 0>{}); load_x(d0, std::integral_constant<int, 1>{});
+        load_x(d0, std::integral_constant<int, 2>{}); load_x(d0, std::integral_constant<int, 3>{});
+        load_d(d0);
+        load_d(d1);
+        dma_wait();
+        __syncthreads();
+        split_d(d0);
+        __syncthreads();
+    }
+    for (int q = 0; q < nchunks; q += 2) {
+        chunk(std::integral_constant<unsigned, 0>{});
+        if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
+    }
+
+    // C/D layout: col = lane % 32 -> k; row -> co: (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int k = k0 + wave * 32 + fi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * fk;
+            if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc[blk][r];
+        }
+    }
+    if constexpr (BIAS) {
+        if (do_bias) {        // (uniform per workgroup; the rings are drained)  The splits of the prologue and of every chunk saw
+            // each pixel of the slice once -- plus one chunk past the end, which reads as zero
+            float* red = smem_all;
+            red[wave * 64 + lane] = bsum;
+            __syncthreads();
+            if (tid < 64 && co0 + tid < a.Co) a.bpart[(long)s * a.Co + co0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+        }
+    }
+}
+
 // out[i] (+)= sum_s part[s][i]: 64 columns x 4 slice lanes per workgroup; every lane keeps four independent
 // loads in flight; the lane partials are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -2013,6 +2303,11 @@ static bool wgrad_x3_on() {                   // read per call: the tests compar
     return e && e[0] == '1';
 }
 
+static bool wgrad_x3c_on() {                  // read per call (PD_WGRAD_X3C=0: weight gradients on the fp32 MFMA)
+    const char* e = getenv("PD_WGRAD_X3C");
+    return !(e && e[0] == '0');
+}
+
 extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* workspace, size_t ws_bytes,
                                int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                                int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode,
@@ -2056,6 +2351,14 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
         if (tco == 32) {              // 17..32 output channels (decoder 96->32, 64->32): reflect + bias in this network
             if (mode == MODE_ZERO) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 32>), grid, block, 0, st, ua);
             else hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, true, 32>), grid, block, 0, st, ua);
+        } else if (mode == MODE_ZERO && wgrad_x3c_on()) {   // bf16-split products, every element split once
+            static const hipError_t lds_b = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<true>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, x3c::LDS_BYTES);
+            static const hipError_t lds_n = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<false>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, x3c::LDS_BYTES);
+            PD_REQUIRE(lds_b == hipSuccess && lds_n == hipSuccess, "pd_conv2d_wgrad: cannot reserve %u bytes of LDS", x3c::LDS_BYTES);
+            if (dbias) hipLaunchKernelGGL((conv_wgrad_x3c_kernel<true>), grid, block, x3c::LDS_BYTES, st, ua);
+            else hipLaunchKernelGGL((conv_wgrad_x3c_kernel<false>), grid, block, x3c::LDS_BYTES, st, ua);
         } else if (wgrad_x3_on()) {     // products on the bf16 matrix cores (three-way split, fp32 accuracy)
             if (mode == MODE_ZERO) {
                 if (dbias) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 64, true>), grid, block, 0, st, ua);

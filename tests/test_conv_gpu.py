@@ -454,11 +454,20 @@ def test_bf16x3_kernel_keeps_fp32_accuracy(case, monkeypatch):
     errs, stats, dxe = {}, {}, {}
     dwe = {}
     ref_dw = torch.autograd.grad(F.conv2d(x.double(), wv := w.double().requires_grad_(True), None, stride=s, padding=p), wv, dy.double())[0]
+    dbe = {}
+    ref_db = dy.double().sum((0, 2, 3))
     for knob in ("1", "0"):
         monkeypatch.setenv("PD_CONV_X3", knob)
-        monkeypatch.setenv("PD_WGRAD_X3", knob)
-        dw = ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p)
+        monkeypatch.setenv("PD_WGRAD_X3C", knob)          # weight gradient: every element split once (conv_wgrad_x3c_kernel)
+        monkeypatch.setenv("PD_WGRAD_X3", "0")
+        dw, db = ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p, want_bias=True)
         dwe[knob] = (dw.cpu().double() - ref_dw).abs().max().item() / ref_dw.abs().max().item()
+        dbe[knob] = (db.cpu().double() - ref_db).abs().max().item() / ref_db.abs().max().item()
+        if knob == "1":                                   # ... and the in-register split of the uniform-tap kernel
+            monkeypatch.setenv("PD_WGRAD_X3C", "0"); monkeypatch.setenv("PD_WGRAD_X3", "1")
+            dw = ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p)
+            dwe["r"] = (dw.cpu().double() - ref_dw).abs().max().item() / ref_dw.abs().max().item()
+            monkeypatch.setenv("PD_WGRAD_X3", "0")
         y, st = ops.conv2d_fwd(xd, wd, bd, stride=s, pad=p, want_stats=True)
         errs[knob] = (y.cpu().double() - ref).abs().max().item() / scale
         stats[knob] = st.double().sum(0).cpu()
@@ -475,4 +484,5 @@ def test_bf16x3_kernel_keeps_fp32_accuracy(case, monkeypatch):
     if s == 1:
         assert dxe["1"] <= 5e-6 and dxe["1"] <= 1.5 * dxe["0"] + 1e-8, dxe
     # the weight gradient sums 65536+ products per element: slices of <= 4096 pixels in fp32, partial tiles added in order
-    assert dwe["1"] <= 2e-5 and dwe["1"] <= 1.5 * dwe["0"] + 1e-7, dwe
+    assert dwe["1"] <= 2e-5 and dwe["1"] <= 1.5 * dwe["0"] + 1e-7 and dwe["r"] <= 1.5 * dwe["0"] + 1e-7, dwe
+    assert dbe["1"] <= 2e-5 and dbe["0"] <= 2e-5, dbe
