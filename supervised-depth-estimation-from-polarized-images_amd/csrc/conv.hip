@@ -2308,6 +2308,16 @@ static bool wgrad_x3c_on() {                  // read per call (PD_WGRAD_X3C=0: 
     return !(e && e[0] == '0');
 }
 
+// 1 when pd_conv2d_wgrad sends this zero-padded shape (16-byte aligned NHWC operands assumed) to conv_wgrad_x3c_kernel
+extern "C" int pd_conv2d_wgrad_uses_x3(long M, int Co, int C, int KH, int KW, int stride, int pad, int H, int W, int Ho, int Wo) {
+    static const bool uni_on = !(getenv("PD_WGRAD_UNI") && getenv("PD_WGRAD_UNI")[0] == '0');
+    int S = 0; long mper = 0;
+    wgrad_plan(M, Co, KH * KW * C, &S, &mper);
+    const int nb = (pad + stride - 1) / stride, nbw = (nb + 1) / 2;
+    return uni_on && wgrad_x3c_on() && wgrad_tco(Co) == 64 && C % 4 == 0 && Co % 4 == 0 && Wo % 2 == 0 && Ho >= 2 * nb &&
+           Wo >= 4 * nbw && Wo >= 14 && (2 * nb + 1) * (2 * nbw + 1) <= 31 && mper % WG_MC == 0 && M % 4 == 0 && KH * KW * C >= 4;
+}
+
 extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* workspace, size_t ws_bytes,
                                int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                                int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode,

@@ -62,6 +62,7 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
     """x3 = "0": every launch on the fp32-MFMA production tiles; "1" (the default): the shapes pd_conv2d_uses_x3 accepts go
     to the bf16-split kernel (256 x 64 tiles), the others stay where they were."""
     monkeypatch.setenv("PD_CONV_X3", x3)
+    monkeypatch.setenv("PD_WGRAD_X3C", x3)        # weight gradient: conv_wgrad_x3c_kernel | the fp32-MFMA scalar-pixel kernel
     N, C, H, W, Co, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, C, H, W, generator=g)
@@ -104,7 +105,8 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
     dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
     S = ops.lib.pd_conv2d_wgrad_workspace(M, Co, k * k * C) // (4 * (Co * k * k * C + Co))
     assert S >= 15, f"weight gradient not in the many-slice regime (S = {S})"
-    dw = ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p)
+    dw, lab = _labels(lambda: ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p))
+    assert lab == (["conv_wgrad_x3c_kernel"] if x3 == "1" else ["conv_wgrad_kernel"]), lab
     _close(dw.cpu(), wr.grad, what="wgrad")
 
     dx, lab = _labels(lambda: ops.conv2d_dgrad(dyd, wd, (H, W), stride=s, pad=p))

@@ -25,7 +25,9 @@ def short(name):
         return f"conv_igemm_uni_kernel<{m.group(1)},{m.group(2)}>"
     if name.startswith("conv_igemm_x3_kernel"):      # forward and data gradient of the bf16-split kernel: one label
         return "conv_igemm_x3_kernel<256,64>"
-    if name.startswith("conv_wgrad"):                # bench.py times every weight-gradient kernel under one label
+    if name.startswith("conv_wgrad_x3c"):
+        return "conv_wgrad_x3c_kernel"
+    if name.startswith("conv_wgrad"):                # bench.py times the other weight-gradient kernels under one label
         return "conv_wgrad_kernel"
     return name.split("(")[0]
 
