@@ -828,9 +828,14 @@ template <int P> __device__ __forceinline__ void sp_l(Terms& t) {
 }
 }  // namespace x3
 
-template <int MODE>
-__global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) {
+// RB = row blocks (of 32) per wave: 2 -> 256-row tiles (52 KB of LDS, three workgroups per CU); 1 -> 128-row tiles (36 KB,
+// four per CU) for the layers whose 256-row tiles would not fill the chip twice.
+template <int MODE, int RB = 2>
+__global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(const ConvArgs a) {
     using namespace x3;
+    constexpr int BM = 128 * RB;
+    constexpr unsigned A_BYTES = BM * CK * 4, BS_BASE = 2 * A_BYTES, BP_BASE = BS_BASE + 2 * BS_BYTES;
+    constexpr unsigned LDS_BYTES = BP_BASE + 2 * 3 * BP_BYTES;
     __shared__ __attribute__((aligned(16))) float smem_all[LDS_BYTES / 4];
 
     const int nblk = a.mtiles * a.ntiles;
@@ -858,10 +863,10 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
     const int prow = lane >> 2;
     const unsigned col4 = 16u * ((lane & 3) ^ ((lane >> 4) & 3));
     const unsigned ones_kw = (1u << a.KW) - 1u;
-    unsigned va[4], inv[4];
+    unsigned va[2 * RB], inv[2 * RB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long m = m0 + 64 * wave + 16 * i + prow;
+    for (int i = 0; i < 2 * RB; ++i) {
+        const long m = m0 + 32 * RB * wave + 16 * i + prow;
         const unsigned mr = (unsigned)(m - (long)img0 * hw);
         const unsigned dn = magic_div(mr, a.mg_hw, a.sh_hw);
         const unsigned rem = mr - dn * (unsigned)hw;
@@ -895,7 +900,7 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
     unsigned s_aoff = MODE != MODE_TRANSPOSED ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
     int s_qb = 0;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
-    const unsigned m0_a = lds0 + 4096u * (unsigned)wave, m0_b = lds0 + BS_BASE + 1024u * (unsigned)wave;
+    const unsigned m0_a = lds0 + 2048u * RB * (unsigned)wave, m0_b = lds0 + BS_BASE + 1024u * (unsigned)wave;
 
     auto load_a = [&](auto dst_tag, auto piece_tag) {
         constexpr unsigned DST = decltype(dst_tag)::value;
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
     unsigned fa_off[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        fa_off[e] = (unsigned)(64 * wave + frow) * (CK * 4) + 16u * ((2 * fh + e) ^ ((frow >> 2) & 3));
+        fa_off[e] = (unsigned)(32 * RB * wave + frow) * (CK * 4) + 16u * ((2 * fh + e) ^ ((frow >> 2) & 3));
         asm volatile("" : "+v"(fa_off[e]));
     }
     // weight planes: 32-byte rows, two 16-byte k halves, half ^ ((row/8)%2)
@@ -938,9 +943,9 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
     char* lds_c = reinterpret_cast<char*>(smem_all);
 
     typedef float accv_t __attribute__((ext_vector_type(16)));
-    accv_t acc[2][2];
+    accv_t acc[RB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -970,13 +975,13 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
         constexpr unsigned BUF = decltype(buf_tag)::value;
         const std::integral_constant<unsigned, BUF ^ 1> nxt{};
         constexpr unsigned NXT = BUF ^ 1;
-        pieces<0, 4>(load_a, nxt);
+        pieces<0, 2 * RB>(load_a, nxt);
         load_b(buf_tag);
         advance_a();
-        float4 fa[2][2];
+        float4 fa[RB][2];
         u32x4 fb[2][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
                 fa[i][e] = *reinterpret_cast<const float4*>(lds_c + fa_off[e] + (BUF * A_BYTES + (unsigned)i * 32 * CK * 4));
@@ -987,7 +992,8 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
                 fb[j][t] = *reinterpret_cast<const u32x4*>(lds_c + fb_off + ((BUF * 3 + t) * BP_BYTES + (unsigned)j * 32 * CK * 2));
         const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + NXT * BS_BYTES);      // next chunk's weights (fp32)
         const float x0[8] = {fa[0][0].x, fa[0][0].y, fa[0][0].z, fa[0][0].w, fa[0][1].x, fa[0][1].y, fa[0][1].z, fa[0][1].w};
-        const float x1[8] = {fa[1][0].x, fa[1][0].y, fa[1][0].z, fa[1][0].w, fa[1][1].x, fa[1][1].y, fa[1][1].z, fa[1][1].w};
+        const float x1[8] = {fa[RB - 1][0].x, fa[RB - 1][0].y, fa[RB - 1][0].z, fa[RB - 1][0].w,
+                             fa[RB - 1][1].x, fa[RB - 1][1].y, fa[RB - 1][1].z, fa[RB - 1][1].w};     // (RB == 1: unused)
         const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
         // split2() on pair P of a value array, in steps: H (hi, 1 instruction), M (mid, 5), L (lo, 3)
         struct Terms { unsigned h[4], m[4], l[4]; f32x2 tf[4], tr[4]; };
@@ -1021,6 +1027,22 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
 #define PD_SB __builtin_amdgcn_sched_barrier(0);
         sp_h(x0, t0, PD_I(0)); sp_h(x0, t0, PD_I(1)); sp_h(x0, t0, PD_I(2)); sp_h(x0, t0, PD_I(3));
         PD_SB
+        if constexpr (RB == 1) {       // one row block: 12 MFMAs, its mid / lo terms and the weights' split behind them
+            mm(t0, PD_I(0), PD_I(0)); sp_m(x0, t0, PD_I(0)); PD_SB
+            mm(t0, PD_I(0), PD_I(1)); sp_m(x0, t0, PD_I(1)); PD_SB
+            mm(t0, PD_I(0), PD_I(2)); sp_m(x0, t0, PD_I(2)); PD_SB
+            mm(t0, PD_I(0), PD_I(3)); sp_m(x0, t0, PD_I(3)); PD_SB
+            mm(t0, PD_I(0), PD_I(4)); sp_h(ws, tw, PD_I(0)); sp_h(ws, tw, PD_I(1)); PD_SB
+            mm(t0, PD_I(0), PD_I(5)); sp_m(ws, tw, PD_I(0)); PD_SB
+            mm(t0, PD_I(0), PD_I(6)); sp_l(t0, PD_I(0)); sp_l(tw, PD_I(0)); PD_SB
+            mm(t0, PD_I(0), PD_I(7)); sp_l(t0, PD_I(1)); sp_m(ws, tw, PD_I(1)); PD_SB
+            mm(t0, PD_I(0), PD_I(8)); sp_l(t0, PD_I(2)); sp_l(tw, PD_I(1)); PD_SB
+            mm(t0, PD_I(0), PD_I(9)); sp_l(t0, PD_I(3)); PD_SB
+            *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
+            *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
+            *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
+            mm(t0, PD_I(0), PD_I(10)); mm(t0, PD_I(0), PD_I(11));
+        } else {
         // row block 0: its mid terms behind MFMAs 0..3, the weights' first pair behind 4..5, its lo terms (and block 1's hi)
         // behind 6..9
         mm(t0, PD_I(0), PD_I(0)); sp_m(x0, t0, PD_I(0)); PD_SB
@@ -1036,21 +1058,22 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
         mm(t0, PD_I(0), PD_I(10)); sp_m(ws, tw, PD_I(1)); PD_SB
         mm(t0, PD_I(0), PD_I(11)); sp_l(tw, PD_I(0)); PD_SB
         // row block 1
-        mm(t1, PD_I(1), PD_I(0)); sp_m(x1, t1, PD_I(0)); PD_SB
-        mm(t1, PD_I(1), PD_I(1)); sp_m(x1, t1, PD_I(1)); PD_SB
-        mm(t1, PD_I(1), PD_I(2)); sp_m(x1, t1, PD_I(2)); PD_SB
-        mm(t1, PD_I(1), PD_I(3)); sp_m(x1, t1, PD_I(3)); PD_SB
-        mm(t1, PD_I(1), PD_I(4)); sp_l(tw, PD_I(1)); PD_SB
-        mm(t1, PD_I(1), PD_I(5));
+        mm(t1, PD_I(RB - 1), PD_I(0)); sp_m(x1, t1, PD_I(0)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(1)); sp_m(x1, t1, PD_I(1)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(2)); sp_m(x1, t1, PD_I(2)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(3)); sp_m(x1, t1, PD_I(3)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(4)); sp_l(tw, PD_I(1)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(5));
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
         PD_SB
-        mm(t1, PD_I(1), PD_I(6)); sp_l(t1, PD_I(0)); PD_SB
-        mm(t1, PD_I(1), PD_I(7)); sp_l(t1, PD_I(1)); PD_SB
-        mm(t1, PD_I(1), PD_I(8)); sp_l(t1, PD_I(2)); PD_SB
-        mm(t1, PD_I(1), PD_I(9)); sp_l(t1, PD_I(3)); PD_SB
-        mm(t1, PD_I(1), PD_I(10)); mm(t1, PD_I(1), PD_I(11));
+        mm(t1, PD_I(RB - 1), PD_I(6)); sp_l(t1, PD_I(0)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(7)); sp_l(t1, PD_I(1)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(8)); sp_l(t1, PD_I(2)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(9)); sp_l(t1, PD_I(3)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(10)); mm(t1, PD_I(RB - 1), PD_I(11));
+        }
 #undef PD_SB
 #undef PD_I
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1061,7 +1084,7 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
     {
         const std::integral_constant<unsigned, 0> d0{};
         const std::integral_constant<unsigned, 1> d1{};
-        pieces<0, 4>(load_a, d0);
+        pieces<0, 2 * RB>(load_a, d0);
         advance_a();
         load_b(d0);
         load_b(d1);
@@ -1079,23 +1102,24 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
     // wave transposes its 64 x 32 block through LDS and leaves with full 128-byte lines; BatchNorm partial sums per
     // 128-row half of the tile
     {
-        float* T = smem_all + wave * (64 * 32);                        // 8 KB per wave; the ring is dead
-        float (*red)[BN][2] = reinterpret_cast<float (*)[BN][2]>(smem_all + 4 * 64 * 32);
+        constexpr int RW = 32 * RB;                                    // rows of the wave
+        float* T = smem_all + wave * (RW * 32);                        // 4 | 8 KB per wave; the ring is dead
+        float (*red)[BN][2] = reinterpret_cast<float (*)[BN][2]>(smem_all + 4 * RW * 32);
         const int col_l = lane & 31, rbase = 4 * (lane >> 5);
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)BM * a.ldy * 4));
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.add ? a.add + m0 * a.ld_add : a.y, a.add ? (unsigned)((long)BM * a.ld_add * 4) : 0u);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float4 addv[8];
+            float4 addv[4 * RB];
             if (a.add) {
-                const unsigned off_a = (unsigned)((64 * wave + (lane >> 3)) * (int)a.ld_add + n0 + 32 * j + 4 * (lane & 7)) * 4u;
+                const unsigned off_a = (unsigned)((RW * wave + (lane >> 3)) * (int)a.ld_add + n0 + 32 * j + 4 * (lane & 7)) * 4u;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) addv[t] = buf_ld4(ra, off_a + (unsigned)(t * 8 * (int)a.ld_add * 4));
+                for (int t = 0; t < 4 * RB; ++t) addv[t] = buf_ld4(ra, off_a + (unsigned)(t * 8 * (int)a.ld_add * 4));
             }
             float s1 = 0.f, s2 = 0.f;
             const float bv = a.bias ? a.bias[n0 + 32 * j + col_l] : 0.f;     // (the statistics are those of conv + bias)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[i][j][r] + bv;
@@ -1103,69 +1127,78 @@ __global__ __launch_bounds__(NT, 3) void conv_igemm_x3_kernel(const ConvArgs a) 
                     s1 += v;
                     s2 = __builtin_fmaf(v, v, s2);
                 }
-            const unsigned off_l = (unsigned)((64 * wave + (lane >> 3)) * (int)a.ldy + n0 + 32 * j + 4 * (lane & 7)) * 4u;
+            const unsigned off_l = (unsigned)((RW * wave + (lane >> 3)) * (int)a.ldy + n0 + 32 * j + 4 * (lane & 7)) * 4u;
             const float4* Tq = reinterpret_cast<const float4*>(T) + lane;
             // All eight lines are formed first and the stores leave back to back: a 128-bit buffer store reads its data
             // registers for several cycles after issue, and with a scalar offset operand hipcc does not guard them against
             // the next vector instruction (seen here as the last lanes of every 16 storing the NEXT line's values when the
             // sum for line t+1 was written into the registers of store t).
-            float4 v[8];
+            float4 v[4 * RB];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 4 * RB; ++t) {
                 v[t] = Tq[t * 64];
                 if (a.add) { v[t].x += addv[t].x; v[t].y += addv[t].y; v[t].z += addv[t].z; v[t].w += addv[t].w; }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int t = 0; t < 4 * RB; ++t)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[t]), ry, off_l, t * 8 * (int)a.ldy * 4, 0);
             asm volatile("s_nop 1");
             __builtin_amdgcn_sched_barrier(0);
             if (a.stats) {
                 s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                if (a.M < 64 * 1024) {             // 64-row statistics tiles (pd_conv2d_tile_m): one row per wave
-                    if (lane < 32) {
-                        float* o = a.stats + ((long)(4 * mt + wave) * a.Co + n0 + 32 * j + col_l) * 2;
-                        o[0] = s1; o[1] = s2;
-                    }
-                } else if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
+                if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
             }
         }
-        if (a.stats && a.M >= 64 * 1024) {
+        if (a.stats) {
+            // one row of `stats` per 128 output pixels (64 when M < 65536, pd_conv2d_tile_m): WPS waves each
+            const int sgr = a.M < 64 * 1024 ? 64 : 128, wps = sgr / RW, nrow = BM / sgr;
             __syncthreads();
-            if (tid < 2 * BN) {
-                const int half = tid >> 6, cl = tid & 63;
-                float* o = a.stats + ((long)(2 * mt + half) * a.Co + n0 + cl) * 2;
-                o[0] = red[2 * half][cl][0] + red[2 * half + 1][cl][0];
-                o[1] = red[2 * half][cl][1] + red[2 * half + 1][cl][1];
+            if (tid < nrow * BN) {
+                const int row_l = tid >> 6, cl = tid & 63;
+                float t1 = 0.f, t2 = 0.f;
+                for (int w = 0; w < wps; ++w) { t1 += red[row_l * wps + w][cl][0]; t2 += red[row_l * wps + w][cl][1]; }
+                float* o = a.stats + ((long)(mt * nrow + row_l) * a.Co + n0 + cl) * 2;
+                o[0] = t1; o[1] = t2;
             }
         }
     }
 }
 
-static long x3_min_wg() {      // fewest workgroups that take the 256-row tiles: two per CU (PD_CONV_X3_MIN_WG: tuning aid).
+static long x3_min_wg() {      // fewest workgroups that take the bf16-split kernel: two per CU (PD_CONV_X3_MIN_WG: tuning aid).
     // Below that a SIMD holds one wave most of the time and the split is not hidden by another wave's MFMAs: 320
     // workgroups run at the fp32 kernel's pace (3x3x256 @32x40: 116 vs 114 TF), 640 at 1.3x (5x5 256 -> 512 @32x40: 167 vs 127).
     const char* e = getenv("PD_CONV_X3_MIN_WG");
     return e ? atol(e) : 512;
 }
 
-static bool x3_eligible(const ConvArgs& a, bool vec) {
+// 0: not for the bf16-split kernel; 2 | 1: its row blocks per wave (256- | 128-row tiles)
+static int x3_eligible(const ConvArgs& a, bool vec) {
     const char* e = getenv("PD_CONV_X3");          // read per call: the tests compare both kernels in one process
     const bool on = !(e && e[0] == '0');
-    return on && vec && a.C % x3::CK == 0 && a.Co % x3::BN == 0 && a.M % x3::BM == 0 && (a.M / x3::BM) * (a.Co / x3::BN) >= x3_min_wg() && a.KH * a.KW <= 31 &&
-           a.pad < a.KH && a.pad_w < a.KW && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) &&
-           !a.oscale && a.act == ACT_NONE && (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
-           (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0)) && (long)a.Co * a.K * 4 < 0x7fffffffL;
+    if (!(on && vec && a.C % x3::CK == 0 && a.Co % x3::BN == 0 && a.M % 128 == 0 && a.KH * a.KW <= 31 &&
+          a.pad < a.KH && a.pad_w < a.KW && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) &&
+          !a.oscale && a.act == ACT_NONE && (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
+          (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0)) && (long)a.Co * a.K * 4 < 0x7fffffffL))
+        return 0;
+    const long ct = a.Co / x3::BN;
+    if (a.M % 256 == 0 && (a.M / 256) * ct >= x3_min_wg()) return 2;
+    static const bool rb1 = !(getenv("PD_CONV_X3_RB1") && getenv("PD_CONV_X3_RB1")[0] == '0');
+    return rb1 && (a.M / 128) * ct >= x3_min_wg() ? 1 : 0;
 }
 
-static int launch_conv_x3(ConvArgs& a, hipStream_t st) {
-    a.mtiles = (int)(a.M / x3::BM);
+static int launch_conv_x3(ConvArgs& a, int rb, hipStream_t st) {
+    a.mtiles = (int)(a.M / (128 * rb));
     a.ntiles = a.Co / x3::BN;
     const long nblk = (long)a.mtiles * a.ntiles;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
-    if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_ZERO>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_TRANSPOSED>), grid, block, 0, st, a);
+    if (rb == 2) {
+        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_ZERO, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_TRANSPOSED, 2>), grid, block, 0, st, a);
+    } else {
+        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_ZERO, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_TRANSPOSED, 1>), grid, block, 0, st, a);
+    }
     return pd::check_launch("pd_conv2d");
 }
 
@@ -1229,7 +1262,7 @@ extern "C" int pd_conv2d_uses_x3(long M, int Co, int C, int KH, int KW, int stri
     a.K = KH * KW * C; a.ldy = Co;
     a.oscale = has_out_scale ? reinterpret_cast<const float*>(16) : nullptr;
     while ((1 << a.sshift) < stride) ++a.sshift;
-    return x3_eligible(a, true) ? 1 : 0;
+    return x3_eligible(a, true);
 }
 
 extern "C" int pd_conv2d_tile_m(long M, int Co) {
@@ -1330,7 +1363,7 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
     const int bm = pd_conv2d_tile_m(a.M, Co);
     // 96 output columns (the data gradient of the decoder's 96 -> 32 layer): three 32-wide column tiles instead of a full and a
     // half-empty 64-wide one (a quarter of the matrix work of that launch was padding)
-    if (x3_eligible(a, vec)) return launch_conv_x3(a, st);
+    if (const int rb = x3_eligible(a, vec)) return launch_conv_x3(a, rb, st);
     static const bool n96 = [] { const char* e = getenv("PD_CONV_N96"); return !(e && e[0] == '0'); }();
     if (Co == 96 && n96 && bm == 128) return launch_conv<128, 32, 32, 32>(a, vec, st);
     if (Co > 32) return bm == 128 ? launch_conv<128, 64, 64, 32>(a, vec, st) : launch_conv<64, 64, 32, 32>(a, vec, st);
@@ -2053,9 +2086,11 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
     // ---- fragment / split addresses: lane -> (index inside a 32-wide block = lane % 32, pixel half = lane / 32); the eight
     // pixels of (k-step g, half h) are 16 g + 2 e + h, e = 0..7 (even | odd pixels: the staging tiles keep odd pixels
     // XOR 32 floats, so the two half-waves of a ds_read_b32 sit on different banks).
-    // (A k tile with at most 64 valid columns -- the last of K = 576: 4.5 tiles -- leaves waves 2 and 3 multiplying zeros.
-    //  Giving them the second k-step of waves 0 and 1, as conv_wgrad_uni_kernel does, was measured: 141 -> 128 TF on
-    //  5x5x64 @256x320 -- the second copy of the chunk body costs more than the idle MFMAs.)
+    // A k tile with at most 64 valid columns (the last of K = 576: 4.5 tiles) has nothing for waves 2 and 3 to multiply:
+    // they skip the MFMAs and the X split and only take part in staging and in the dY split.  (Giving them the second
+    // k-step of waves 0 and 1, as conv_wgrad_uni_kernel does, was measured: 141 -> 128 TF on 5x5x64 @256x320 -- a second
+    // copy of the chunk body costs more than it saves.)
+    const bool active = k0 + 32 * wave < a.K;
     const int fi = lane & 31, fk = lane >> 5;
     unsigned fx_off = 2 * D_BYTES + fk * X_ROW + 4u * ((unsigned)(wave * 32 + fi) ^ (32u * fk));
     unsigned pa_off = P_BASE + (unsigned)fk * 1024u + (unsigned)fi * 16u;     // + ((term*2 + g)*2)*1024 + blk*512
@@ -2099,6 +2134,12 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
         load_d(buf_tag);                                   // chunk q + 2 into the slot whose chunk q was split during chunk q - 1
         load_x(nxt, std::integral_constant<int, 2>{});
         load_x(nxt, std::integral_constant<int, 3>{});
+        if (!active) {                                     // (wave-uniform) no valid k column: only its share of the dY split
+            split_d(nxt);
+            dma_wait();
+            __syncthreads();
+            return;
+        }
         float x0[8], x1[8], dv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x0[e] = *reinterpret_cast<const float*>(lds_c + fx_off + (BUF * X_BYTES + (unsigned)e * 2 * X_ROW));

@@ -29,8 +29,9 @@ def _profiled(label, flops, fn, shape=None):
 
 def _igemm_label(M, Co, vec, kind, C=0, KH=1, KW=1, stride=1, pad=0, mode=0, act=ACT_NONE, out_scale=False):
     """Profiler label = the kernel family pd_conv2d launches for this call (same rule as launch_conv in conv.hip)."""
-    if vec and lib.pd_conv2d_uses_x3(M, Co, C, KH, KW, stride, pad, mode, act, int(out_scale)):
-        return "conv_igemm_x3_kernel<256,64>"
+    rb = lib.pd_conv2d_uses_x3(M, Co, C, KH, KW, stride, pad, mode, act, int(out_scale)) if vec else 0
+    if rb:
+        return f"conv_igemm_x3_kernel<{128 * rb},64>"
     bm = lib.pd_conv2d_tile_m(M, Co)
     bn = 64 if Co > 32 else (32 if Co > 16 else 16)
     uni = (vec and bn >= 32 and C % 32 == 0 and C > 0 and KH * KW <= 31 and pad < KH and pad < KW and

@@ -77,9 +77,12 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
     wd = w.cuda().contiguous(memory_format=torch.channels_last)
 
     def expect(Mx, Cox, Cx, sx, mode):
-        uses = ops.lib.pd_conv2d_uses_x3(Mx, Cox, Cx, k, k, sx, p, mode, 0, 0)
-        assert uses == (x3 == "1" and Mx % 256 == 0 and Cox % 64 == 0 and Cx % 16 == 0 and (Mx // 256) * (Cox // 64) >= 512)
-        return ["conv_igemm_x3_kernel<256,64>" if uses else "conv_igemm_uni_kernel<128,64>"]
+        rb = ops.lib.pd_conv2d_uses_x3(Mx, Cox, Cx, k, k, sx, p, mode, 0, 0)
+        want = 0
+        if x3 == "1" and Cox % 64 == 0 and Cx % 16 == 0:
+            want = 2 if (Mx % 256 == 0 and (Mx // 256) * (Cox // 64) >= 512) else 1 if (Mx % 128 == 0 and (Mx // 128) * (Cox // 64) >= 512) else 0
+        assert rb == want, (rb, want)
+        return [f"conv_igemm_x3_kernel<{128 * rb},64>" if rb else "conv_igemm_uni_kernel<128,64>"]
 
     (y, stats), lab = _labels(lambda: ops.conv2d_fwd(xd, wd, None, stride=s, pad=p, want_stats=True))
     assert lab == expect(M, Co, C, s, 0), lab
@@ -147,7 +150,7 @@ def test_production_tile_reflection_padded_conv(case):
         return y
     y, lab = _labels(run)
     # (forward on the REFLECT instantiation; the pad-1 data gradient is a zero-padding launch: fp32 or bf16-split kernel)
-    assert lab.count("conv_igemm_uni_kernel<128,64>") + lab.count("conv_igemm_x3_kernel<256,64>") == 2 and "conv_wgrad_kernel" in lab, lab
+    assert sum(l.startswith(("conv_igemm_uni_kernel<128,64>", "conv_igemm_x3_kernel")) for l in lab) == 2 and "conv_wgrad_kernel" in lab, lab
     _close(y.detach().cpu(), ref.detach(), 3e-5, "fwd")
     _close(xc.grad.cpu(), xr.grad, 3e-5, "dgrad")
     _close(conv.weight.grad.cpu(), wr.grad, 3e-5, "wgrad")
@@ -244,7 +247,7 @@ def test_conv_block_with_more_than_4096_stat_rows_matches_torch():
     _close(blk.bn.bias.grad.cpu(), ref[1].bias.grad, 1e-4, "dbeta")
 
 
-def test_full_resolution_training_step_matches_oracle(tmp_path):
+def test_full_resolution_training_step_matches_oracle(tmp_path, monkeypatch):
     """BASELINE configs[2] at batch 4: K1 -> three encoders -> joint encoder -> decoder -> multi-scale loss -> backward on
     512x640 frames (dropout 0, BatchNorm in training mode), HIP path vs the CPU oracle with identical weights and batch.
     At this size every 256x320 / 128x160 layer runs the 128x64 tile, the weight gradients their many-slice plans, the
@@ -275,51 +278,61 @@ def test_full_resolution_training_step_matches_oracle(tmp_path):
     batch = synthetic.make_batch(B, H, W, frame_w=bench.FRAME_W, device="cuda", seed=21)
     cpu = {k: v.cpu() for k, v in batch.items()}
 
-    tr.model_optimizer.zero_grad()
-
     def step():
         outputs, losses, _ = tr.process_batch(dict(batch), is_train=True)
         losses["loss"].backward()
         PF.sync_wgrad_stream()
         return outputs, losses
-    (outputs, losses), lab = _labels(step)
-    torch.cuda.synchronize()
-    n_prod = lab.count("conv_igemm_uni_kernel<128,64>") + lab.count("conv_igemm_x3_kernel<256,64>")
-    assert n_prod >= 30, f"production tiles not exercised: {n_prod}"
-    gpu_grads = {f"{mn}.{k}": v.grad.detach().cpu().clone() for mn in tr.models for k, v in tr.models[mn].named_parameters()
-                 if v.grad is not None}
 
     # Three-way comparison (tools/grad_calibration.py prints the table): the oracle in fp32 is the reference's arithmetic,
     # the oracle in fp64 the yardstick.  Training-mode BatchNorm through ~25 layers amplifies fp32 rounding of the
     # encoder gradients to ~1e-2 relative on BOTH fp32 paths (decoder gradients, in front of the first BatchNorm: 1e-5),
-    # so "equal to the fp32 oracle within 5e-3" is not a meaningful bar at this size; "at least as close to exact
-    # arithmetic as the fp32 oracle is" (factor 1.5 for the tensor-to-tensor scatter) is.
+    # so "equal to the fp32 oracle within 5e-3" is not a meaningful bar at this size; "as close to exact arithmetic as the
+    # fp32 oracle is" is.  Both kernel families run the same step from the same weights:
+    #   fp32 MFMA (PD_CONV_X3=0, PD_WGRAD_X3C=0): every tensor within 1.5x the fp32 oracle's distance (measured: median of
+    #     the ratios 0.84, worst 1.15);
+    #   bf16-split kernels (the default): median ratio <= 1.25, every tensor within 2x (measured: 1.07, worst 1.52 -- the
+    #     split kernels are as close to fp64 as the CPU's fp32 arithmetic, the fp32-MFMA kernels a little closer).
     g64, L64, d64 = oracle_grads(ref, cpu, H, W, torch.float64)
     g32, L32, d32 = oracle_grads(ref, cpu, H, W, torch.float32)
-    for s in range(4):
-        d = outputs[("disp", s)].detach().cpu()
-        assert (d - d32[s]).abs().max().item() < 2e-5, f"disp {s} vs fp32 oracle"
-        assert (d.double() - d64[s]).abs().max().item() < 2e-5, f"disp {s} vs fp64 oracle"
-    for k in ("loss", "loss/0", "loss/1", "loss/2", "loss/3", "supervised_depth_loss/0", "supervised_depth_loss/3"):
-        assert abs(losses[k].item() - L32[k]) <= 1e-4 * abs(L32[k]), (k, losses[k].item(), L32[k])
-        assert abs(losses[k].item() - L64[k]) <= 1e-4 * abs(L64[k]), (k, losses[k].item(), L64[k])
-    bad, rows = [], []
-    for k, g in g64.items():
-        if k.endswith("conv.bias") and not k.startswith("mono_depth"):
-            continue                         # bias in front of BatchNorm: exactly 0 here, rounding noise in torch
-        n = g.norm().item() + 1e-30
-        e_hip = (gpu_grads[k].double() - g).norm().item() / n
-        e_cpu = (g32[k] - g).norm().item() / n
-        rows.append((k, e_hip, e_cpu))
-        if e_hip > max(1e-4, 1.5 * e_cpu):
-            bad.append((k, e_hip, e_cpu))
-    assert len(rows) > 150
     import os
-    if os.environ.get("PD_TEST_VERBOSE"):
-        for r in rows:
-            print("%-60s hip-fp64 %.2e  cpu32-fp64 %.2e" % r)
-    assert not bad, bad
-    dec = [r for r in rows if r[0].startswith("mono_depth")]
-    assert max(r[1] for r in dec) < 2e-4, "decoder gradients (no BatchNorm between them and the loss)"
-    print("full-resolution step: %d gradient tensors; worst hip-fp64 %.2e, worst cpu32-fp64 %.2e; hip closer on %d" % (
-        len(rows), max(r[1] for r in rows), max(r[2] for r in rows), sum(r[1] <= r[2] for r in rows)))
+    import statistics
+    for family, knob, per_tensor, median_bar in (("bf16-split", "1", 2.0, 1.25), ("fp32 MFMA", "0", 1.5, 1.25)):
+        monkeypatch.setenv("PD_CONV_X3", knob)
+        monkeypatch.setenv("PD_WGRAD_X3C", knob)
+        tr.model_optimizer.zero_grad()
+        (outputs, losses), lab = _labels(step)
+        torch.cuda.synchronize()
+        n_prod = sum(l.startswith(("conv_igemm_uni_kernel<128,64>", "conv_igemm_x3_kernel")) for l in lab)
+        assert n_prod >= 30, f"production tiles not exercised: {n_prod}"
+        assert any(l.startswith("conv_igemm_x3_kernel") for l in lab) == (knob == "1")
+        gpu_grads = {f"{mn}.{k}": v.grad.detach().cpu().clone() for mn in tr.models for k, v in tr.models[mn].named_parameters()
+                     if v.grad is not None}
+        for s in range(4):
+            d = outputs[("disp", s)].detach().cpu()
+            assert (d - d32[s]).abs().max().item() < 2e-5, f"{family}: disp {s} vs fp32 oracle"
+            assert (d.double() - d64[s]).abs().max().item() < 2e-5, f"{family}: disp {s} vs fp64 oracle"
+        for k in ("loss", "loss/0", "loss/1", "loss/2", "loss/3", "supervised_depth_loss/0", "supervised_depth_loss/3"):
+            assert abs(losses[k].item() - L32[k]) <= 1e-4 * abs(L32[k]), (family, k, losses[k].item(), L32[k])
+            assert abs(losses[k].item() - L64[k]) <= 1e-4 * abs(L64[k]), (family, k, losses[k].item(), L64[k])
+        bad, rows = [], []
+        for k, g in g64.items():
+            if k.endswith("conv.bias") and not k.startswith("mono_depth"):
+                continue                         # bias in front of BatchNorm: exactly 0 here, rounding noise in torch
+            n = g.norm().item() + 1e-30
+            e_hip = (gpu_grads[k].double() - g).norm().item() / n
+            e_cpu = (g32[k] - g).norm().item() / n
+            rows.append((k, e_hip, e_cpu))
+            if e_hip > max(1e-4, per_tensor * e_cpu):
+                bad.append((k, e_hip, e_cpu))
+        assert len(rows) > 150
+        if os.environ.get("PD_TEST_VERBOSE"):
+            for r in rows:
+                print("%-12s %-60s hip-fp64 %.2e  cpu32-fp64 %.2e" % ((family,) + r))
+        assert not bad, (family, bad)
+        med = statistics.median(r[1] / r[2] for r in rows if r[2] > 1e-6)
+        assert med <= median_bar, (family, med)
+        dec = [r for r in rows if r[0].startswith("mono_depth")]
+        assert max(r[1] for r in dec) < 2e-4, f"{family}: decoder gradients (no BatchNorm between them and the loss)"
+        print("full-resolution step, %s kernels: %d gradient tensors; worst hip-fp64 %.2e, worst cpu32-fp64 %.2e; median ratio %.2f; "
+              "hip closer on %d" % (family, len(rows), max(r[1] for r in rows), max(r[2] for r in rows), med, sum(r[1] <= r[2] for r in rows)))

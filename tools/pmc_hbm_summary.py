@@ -23,8 +23,9 @@ def short(name):
     m = re.match(r"conv_igemm_uni_kernel<(\d+), (\d+), \d+, \d+, \d+, \d+>", name)
     if m:                      # forward and data-gradient instantiations of one tile share bench.py's label
         return f"conv_igemm_uni_kernel<{m.group(1)},{m.group(2)}>"
-    if name.startswith("conv_igemm_x3_kernel"):      # forward and data gradient of the bf16-split kernel: one label
-        return "conv_igemm_x3_kernel<256,64>"
+    m = re.match(r"conv_igemm_x3_kernel<\d+, (\d+)>", name)
+    if m:                      # forward and data gradient of the bf16-split kernel: one label per tile height
+        return f"conv_igemm_x3_kernel<{128 * int(m.group(1))},64>"
     if name.startswith("conv_wgrad_x3c"):
         return "conv_wgrad_x3c_kernel"
     if name.startswith("conv_wgrad"):                # bench.py times the other weight-gradient kernels under one label
