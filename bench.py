@@ -262,6 +262,28 @@ def main():
     dt, t_host, loss = timed_loop(lambda: train_step(tr, batch))
     eager = {"images_per_s": round(args.batch * args.steps / dt, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
              "host_enqueue_ms_per_step": None if t_host is None else round(t_host * 1e3, 2), "final_loss": round(float(loss.detach()), 6)}
+    # (before the graph section: a second trainer and the graph's memory pool slow this trainer's allocations afterwards)
+    # the same eager step with every convolution on the fp32 MFMA (PD_CONV_X3=0 is read per launch): what the bf16x3
+    # kernels buy, measured in this process on this GPU
+    fp32_only = None
+    if world == 1 and os.environ.get("PD_CONV_X3", "1") != "0" and os.environ.get("PD_WGRAD_X3C", "1") != "0" and not args.attention and not args.normals_decoder:
+        os.environ["PD_CONV_X3"] = "0"
+        os.environ["PD_WGRAD_X3C"] = "0"
+        try:
+            n_ref = min(args.steps, 10)
+            for _ in range(2):
+                train_step(tr, batch)
+            torch.cuda.synchronize()
+            t_r0 = time.perf_counter()
+            for _ in range(n_ref):
+                train_step(tr, batch)
+            torch.cuda.synchronize()
+            dt_ref = time.perf_counter() - t_r0
+            fp32_only = {"images_per_s": round(args.batch * n_ref / dt_ref, 3), "ms_per_step": round(dt_ref / n_ref * 1e3, 3),
+                         "steps": n_ref, "launch": "eager"}
+        finally:
+            del os.environ["PD_CONV_X3"]
+            del os.environ["PD_WGRAD_X3C"]
     graph_info = None
     if world == 1 and not dist.is_initialized() and not args.no_graph:
         # the same step replayed from a hipGraph (polardepth/graph.py).  A second trainer with the same seed, so that both
@@ -297,27 +319,6 @@ def main():
                 dt, t_host = dt_g, t_host_g
         except Exception as exc:           # the bench line must not depend on the capture
             graph_info = {"error": f"{type(exc).__name__}: {exc}"[:400]}
-    # the same eager step with every convolution on the fp32 MFMA (PD_CONV_X3=0 is read per launch): what the bf16x3
-    # kernels buy, measured in this process on this GPU
-    fp32_only = None
-    if world == 1 and os.environ.get("PD_CONV_X3", "1") != "0" and os.environ.get("PD_WGRAD_X3C", "1") != "0" and not args.attention and not args.normals_decoder:
-        os.environ["PD_CONV_X3"] = "0"
-        os.environ["PD_WGRAD_X3C"] = "0"
-        try:
-            n_ref = min(args.steps, 10)
-            for _ in range(2):
-                train_step(tr, batch)
-            torch.cuda.synchronize()
-            t_r0 = time.perf_counter()
-            for _ in range(n_ref):
-                train_step(tr, batch)
-            torch.cuda.synchronize()
-            dt_ref = time.perf_counter() - t_r0
-            fp32_only = {"images_per_s": round(args.batch * n_ref / dt_ref, 3), "ms_per_step": round(dt_ref / n_ref * 1e3, 3),
-                         "steps": n_ref, "launch": "eager"}
-        finally:
-            del os.environ["PD_CONV_X3"]
-            del os.environ["PD_WGRAD_X3C"]
     dp_info = None
     if dist.is_initialized():
         # per-rank view for diagnosing a scaling run: every rank's own loop time (before the MAX) and the part of the last

@@ -896,9 +896,17 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     // ---- scalar state: the activation pieces run one chunk ahead, the weight pieces two
     const int dW4 = (MODE == MODE_ZERO ? (int)a.sW : -(int)a.sW) * 4, dH4 = (MODE == MODE_ZERO ? (int)a.sH : -(int)a.sH) * 4;
     const int nchunks = a.K / CK;
+    // Chunk order: the 16-channel group is the OUTER loop, the taps the inner one.  With the taps outside (the order of
+    // the fp32 kernels) every input row is fetched once per filter row: the workgroups resident on an XCD hold ~25 000
+    // pixels x 256 B = 6.3 MB of input in flight, more than its 4 MB L2, and the row a tile reads at tap row kh is read by
+    // its neighbour one tap row later -- rocprofv3 FETCH_SIZE was 4.3x the input on the 5x5 layers.  With the channel
+    // group outside, all KH*KW taps of a 64-byte segment follow each other and the footprint between reuses is a quarter.
+    const int ntaps = a.KH * a.KW;
+    const unsigned aoff0 = MODE != MODE_TRANSPOSED ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
     int s_q = 0, s_tap = 0, s_kw = 0, s_c = 0;
-    unsigned s_aoff = MODE != MODE_TRANSPOSED ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
-    int s_qb = 0;
+    unsigned s_aoff = aoff0;
+    int s_qb = 0, sb_tap = 0;
+    unsigned s_boff = 0, sb_c4 = 0;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
     const unsigned m0_a = lds0 + 2048u * RB * (unsigned)wave, m0_b = lds0 + BS_BASE + 1024u * (unsigned)wave;
 
@@ -910,18 +918,17 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     };
     auto advance_a = [&]() {
         ++s_q;
-        s_aoff += CK * 4; s_c += CK;
-        if (s_c == a.C) {
-            s_c = 0; ++s_tap; s_aoff += (unsigned)(dW4 - a.C * 4);
-            if (++s_kw == a.KW) { s_kw = 0; s_aoff += (unsigned)(dH4 - a.KW * dW4); }
-        }
+        ++s_tap; s_aoff += (unsigned)dW4;
+        if (++s_kw == a.KW) { s_kw = 0; s_aoff += (unsigned)(dH4 - a.KW * dW4); }
+        if (s_tap == ntaps) { s_tap = 0; s_c += CK; s_aoff = aoff0 + (unsigned)s_c * 4u; }
         if (s_q >= nchunks) { s_tap = 31; s_aoff = 0; }          // run-out: every mask drops tap 31
     };
     auto load_b = [&](auto dst_tag) {                             // chunk s_qb (past the end: chunk 0 again, never used)
         constexpr unsigned DST = decltype(dst_tag)::value;
-        const unsigned soff = s_qb < nchunks ? (unsigned)s_qb * (CK * 4) : 0u;
-        dma16s(rw_, m0_b + DST * BS_BYTES, vb, soff);
+        dma16s(rw_, m0_b + DST * BS_BYTES, vb, s_qb < nchunks ? s_boff : 0u);
         ++s_qb;
+        s_boff += (unsigned)a.C * 4u;                             // next tap of the same channel group
+        if (++sb_tap == ntaps) { sb_tap = 0; sb_c4 += CK * 4; s_boff = sb_c4; }
     };
 
     // ---- fragment addresses (bytes from the start of LDS)
