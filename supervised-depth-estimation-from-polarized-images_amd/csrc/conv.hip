@@ -1002,29 +1002,10 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         const float x1[8] = {fa[RB - 1][0].x, fa[RB - 1][0].y, fa[RB - 1][0].z, fa[RB - 1][0].w,
                              fa[RB - 1][1].x, fa[RB - 1][1].y, fa[RB - 1][1].z, fa[RB - 1][1].w};     // (RB == 1: unused)
         const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
-        // split2() on pair P of a value array, in steps: H (hi, 1 instruction), M (mid, 5), L (lo, 3)
-        struct Terms { unsigned h[4], m[4], l[4]; f32x2 tf[4], tr[4]; };
-        Terms t0, t1, tw;
-        auto sp_h = [&](const float* x, Terms& t, auto p_tag) {
-            constexpr int P = decltype(p_tag)::value;
-            t.h[P] = cvt_pk_bf16(x[2 * P], x[2 * P + 1]);
-        };
-        auto sp_m = [&](const float* x, Terms& t, auto p_tag) {
-            constexpr int P = decltype(p_tag)::value;
-            t.tf[P] = f32x2{__uint_as_float(t.h[P] << 16), __uint_as_float(t.h[P] & 0xffff0000u)};
-            t.tr[P] = f32x2{x[2 * P], x[2 * P + 1]} - t.tf[P];
-            t.m[P] = cvt_pk_bf16(t.tr[P].x, t.tr[P].y);
-            t.tf[P].x = __uint_as_float(t.m[P] << 16);
-        };
-        auto sp_l = [&](Terms& t, auto p_tag) {
-            constexpr int P = decltype(p_tag)::value;
-            t.tf[P].y = __uint_as_float(t.m[P] & 0xffff0000u);
-            const f32x2 r2 = t.tr[P] - t.tf[P];
-            t.l[P] = cvt_pk_bf16(r2.x, r2.y);
-        };
+        x3::Terms t0, t1, tw;                            // staged split (x3::sp_h / sp_m / sp_l) of row blocks 0, 1 and the weights
         // MFMA number N (0..11) of row block I, largest terms first (what a block needs first is what its split yields
         // first): hi*hi, hi*mid, hi*lo, mid*hi, mid*mid, lo*hi; column block N % 2
-        auto mm = [&](const Terms& t, auto i_tag, auto n_tag) {
+        auto mm = [&](const x3::Terms& t, auto i_tag, auto n_tag) {
             constexpr int I = decltype(i_tag)::value, N = decltype(n_tag)::value, T = N / 2, J = N % 2;
             const unsigned* av = T < 3 ? t.h : T < 5 ? t.m : t.l;
             const u32x4 bv = T == 0 ? fb[J][0] : T == 1 ? fb[J][1] : T == 2 ? fb[J][2] : T == 3 ? fb[J][0] : T == 4 ? fb[J][1] : fb[J][0];
@@ -1032,19 +1013,19 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         };
 #define PD_I(n) std::integral_constant<int, n>{}
 #define PD_SB __builtin_amdgcn_sched_barrier(0);
-        sp_h(x0, t0, PD_I(0)); sp_h(x0, t0, PD_I(1)); sp_h(x0, t0, PD_I(2)); sp_h(x0, t0, PD_I(3));
+        x3::sp_h<0>(x0, t0); x3::sp_h<1>(x0, t0); x3::sp_h<2>(x0, t0); x3::sp_h<3>(x0, t0);
         PD_SB
         if constexpr (RB == 1) {       // one row block: 12 MFMAs, its mid / lo terms and the weights' split behind them
-            mm(t0, PD_I(0), PD_I(0)); sp_m(x0, t0, PD_I(0)); PD_SB
-            mm(t0, PD_I(0), PD_I(1)); sp_m(x0, t0, PD_I(1)); PD_SB
-            mm(t0, PD_I(0), PD_I(2)); sp_m(x0, t0, PD_I(2)); PD_SB
-            mm(t0, PD_I(0), PD_I(3)); sp_m(x0, t0, PD_I(3)); PD_SB
-            mm(t0, PD_I(0), PD_I(4)); sp_h(ws, tw, PD_I(0)); sp_h(ws, tw, PD_I(1)); PD_SB
-            mm(t0, PD_I(0), PD_I(5)); sp_m(ws, tw, PD_I(0)); PD_SB
-            mm(t0, PD_I(0), PD_I(6)); sp_l(t0, PD_I(0)); sp_l(tw, PD_I(0)); PD_SB
-            mm(t0, PD_I(0), PD_I(7)); sp_l(t0, PD_I(1)); sp_m(ws, tw, PD_I(1)); PD_SB
-            mm(t0, PD_I(0), PD_I(8)); sp_l(t0, PD_I(2)); sp_l(tw, PD_I(1)); PD_SB
-            mm(t0, PD_I(0), PD_I(9)); sp_l(t0, PD_I(3)); PD_SB
+            mm(t0, PD_I(0), PD_I(0)); x3::sp_m<0>(x0, t0); PD_SB
+            mm(t0, PD_I(0), PD_I(1)); x3::sp_m<1>(x0, t0); PD_SB
+            mm(t0, PD_I(0), PD_I(2)); x3::sp_m<2>(x0, t0); PD_SB
+            mm(t0, PD_I(0), PD_I(3)); x3::sp_m<3>(x0, t0); PD_SB
+            mm(t0, PD_I(0), PD_I(4)); x3::sp_h<0>(ws, tw); x3::sp_h<1>(ws, tw); PD_SB
+            mm(t0, PD_I(0), PD_I(5)); x3::sp_m<0>(ws, tw); PD_SB
+            mm(t0, PD_I(0), PD_I(6)); x3::sp_l<0>(t0); x3::sp_l<0>(tw); PD_SB
+            mm(t0, PD_I(0), PD_I(7)); x3::sp_l<1>(t0); x3::sp_m<1>(ws, tw); PD_SB
+            mm(t0, PD_I(0), PD_I(8)); x3::sp_l<2>(t0); x3::sp_l<1>(tw); PD_SB
+            mm(t0, PD_I(0), PD_I(9)); x3::sp_l<3>(t0); PD_SB
             *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
             *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
             *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
@@ -1052,33 +1033,33 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         } else {
         // row block 0: its mid terms behind MFMAs 0..3, the weights' first pair behind 4..5, its lo terms (and block 1's hi)
         // behind 6..9
-        mm(t0, PD_I(0), PD_I(0)); sp_m(x0, t0, PD_I(0)); PD_SB
-        mm(t0, PD_I(0), PD_I(1)); sp_m(x0, t0, PD_I(1)); PD_SB
-        mm(t0, PD_I(0), PD_I(2)); sp_m(x0, t0, PD_I(2)); PD_SB
-        mm(t0, PD_I(0), PD_I(3)); sp_m(x0, t0, PD_I(3)); PD_SB
-        mm(t0, PD_I(0), PD_I(4)); sp_h(ws, tw, PD_I(0)); sp_h(ws, tw, PD_I(1)); PD_SB
-        mm(t0, PD_I(0), PD_I(5)); sp_m(ws, tw, PD_I(0)); PD_SB
-        mm(t0, PD_I(0), PD_I(6)); sp_l(t0, PD_I(0)); sp_h(x1, t1, PD_I(0)); PD_SB
-        mm(t0, PD_I(0), PD_I(7)); sp_l(t0, PD_I(1)); sp_h(x1, t1, PD_I(1)); PD_SB
-        mm(t0, PD_I(0), PD_I(8)); sp_l(t0, PD_I(2)); sp_h(x1, t1, PD_I(2)); PD_SB
-        mm(t0, PD_I(0), PD_I(9)); sp_l(t0, PD_I(3)); sp_h(x1, t1, PD_I(3)); PD_SB
-        mm(t0, PD_I(0), PD_I(10)); sp_m(ws, tw, PD_I(1)); PD_SB
-        mm(t0, PD_I(0), PD_I(11)); sp_l(tw, PD_I(0)); PD_SB
+        mm(t0, PD_I(0), PD_I(0)); x3::sp_m<0>(x0, t0); PD_SB
+        mm(t0, PD_I(0), PD_I(1)); x3::sp_m<1>(x0, t0); PD_SB
+        mm(t0, PD_I(0), PD_I(2)); x3::sp_m<2>(x0, t0); PD_SB
+        mm(t0, PD_I(0), PD_I(3)); x3::sp_m<3>(x0, t0); PD_SB
+        mm(t0, PD_I(0), PD_I(4)); x3::sp_h<0>(ws, tw); x3::sp_h<1>(ws, tw); PD_SB
+        mm(t0, PD_I(0), PD_I(5)); x3::sp_m<0>(ws, tw); PD_SB
+        mm(t0, PD_I(0), PD_I(6)); x3::sp_l<0>(t0); x3::sp_h<0>(x1, t1); PD_SB
+        mm(t0, PD_I(0), PD_I(7)); x3::sp_l<1>(t0); x3::sp_h<1>(x1, t1); PD_SB
+        mm(t0, PD_I(0), PD_I(8)); x3::sp_l<2>(t0); x3::sp_h<2>(x1, t1); PD_SB
+        mm(t0, PD_I(0), PD_I(9)); x3::sp_l<3>(t0); x3::sp_h<3>(x1, t1); PD_SB
+        mm(t0, PD_I(0), PD_I(10)); x3::sp_m<1>(ws, tw); PD_SB
+        mm(t0, PD_I(0), PD_I(11)); x3::sp_l<0>(tw); PD_SB
         // row block 1
-        mm(t1, PD_I(RB - 1), PD_I(0)); sp_m(x1, t1, PD_I(0)); PD_SB
-        mm(t1, PD_I(RB - 1), PD_I(1)); sp_m(x1, t1, PD_I(1)); PD_SB
-        mm(t1, PD_I(RB - 1), PD_I(2)); sp_m(x1, t1, PD_I(2)); PD_SB
-        mm(t1, PD_I(RB - 1), PD_I(3)); sp_m(x1, t1, PD_I(3)); PD_SB
-        mm(t1, PD_I(RB - 1), PD_I(4)); sp_l(tw, PD_I(1)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(0)); x3::sp_m<0>(x1, t1); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(1)); x3::sp_m<1>(x1, t1); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(2)); x3::sp_m<2>(x1, t1); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(3)); x3::sp_m<3>(x1, t1); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(4)); x3::sp_l<1>(tw); PD_SB
         mm(t1, PD_I(RB - 1), PD_I(5));
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
         PD_SB
-        mm(t1, PD_I(RB - 1), PD_I(6)); sp_l(t1, PD_I(0)); PD_SB
-        mm(t1, PD_I(RB - 1), PD_I(7)); sp_l(t1, PD_I(1)); PD_SB
-        mm(t1, PD_I(RB - 1), PD_I(8)); sp_l(t1, PD_I(2)); PD_SB
-        mm(t1, PD_I(RB - 1), PD_I(9)); sp_l(t1, PD_I(3)); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(6)); x3::sp_l<0>(t1); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(7)); x3::sp_l<1>(t1); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(8)); x3::sp_l<2>(t1); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(9)); x3::sp_l<3>(t1); PD_SB
         mm(t1, PD_I(RB - 1), PD_I(10)); mm(t1, PD_I(RB - 1), PD_I(11));
         }
 #undef PD_SB

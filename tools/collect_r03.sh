@@ -29,6 +29,7 @@ python3 $R/tools/profile_layers.py > $O/r03_conv_layers.log 2>&1 || exit 4
 cd $R
 tools/bin/bf16x3_peak > $O/r03_bf16x3_peak.log 2>&1
 bash tools/sq_prof_k.sh conv_igemm x3_run.py > $O/r03_x3_sq_counters.txt 2>&1
+bash tools/sq_prof_k.sh conv_wgrad x3c_run.py > $O/r03_x3c_sq_counters.txt 2>&1
 python3 bench.py --attention --bf16 --no_graph --steps 5 > $O/r03_bench_attention_bf16.json 2> $O/att.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/att -- python3 $R/bench.py --attention --bf16 --steps 2 --warmup 1 --no_cpu_baseline --no_graph > $O/att.log 2>&1
