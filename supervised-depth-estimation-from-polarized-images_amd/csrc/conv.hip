@@ -1342,8 +1342,8 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
     const long wbytes = (long)Co * a.K * 4;
     PD_REQUIRE(wbytes < 0x7fffffffL, "pd_conv2d: weight tensor too large for 32-bit offsets");
     a.w_bytes = (unsigned)wbytes;
-    // 32-bit byte offsets are relative to the first image of a tile: a tile may span ceil(128/(Ho*Wo))+1 images
-    const long span = 128 / ((long)Ho * Wo) + 2;
+    // 32-bit byte offsets are relative to the first image of a tile: a tile (up to 256 rows) may span ceil(256/(Ho*Wo))+1 images
+    const long span = 256 / ((long)Ho * Wo) + 2;
     PD_REQUIRE(span * sN * 4 < 0x7fffffffL, "pd_conv2d: image too large for 32-bit offsets (%ld bytes per image)", sN * 4);
     const bool vec = (C % 4 == 0) && sC == 1 && (sW % 4 == 0) && (sH % 4 == 0) && (sN % 4 == 0) && !affine &&
                      pd::aligned16(x) && pd::aligned16(w);
