@@ -188,3 +188,31 @@ def test_shape_validation_of_the_fused_kernels_needs_no_gpu():
     assert L.pd_disphead_workspace(16) == 1024 * (9 * 16 + 1) * 4
     assert L.pd_conv2d(p, p, None, None, p, None, 1, 8, 8, 16, 1024, 128, 16, 1, 8, 8, 16, 3, 3, 1, 1, 0, 0, 0, 0.0, 1.0,
                        8, None) == -22 and b"row stride" in L.pd_last_error()
+
+
+def test_which_shapes_take_the_bf16_split_kernels(monkeypatch):
+    """pd_conv2d_uses_x3 / pd_conv2d_wgrad_uses_x3 (host logic, no GPU): the routing rule the profiler labels, bench.py's
+    roofline object and the production-size tests rely on.  Arguments: M, Cout, C, KH, KW, stride, pad, mode, act, scale."""
+    lib = _lib.lib
+    monkeypatch.delenv("PD_CONV_X3", raising=False)
+    monkeypatch.delenv("PD_WGRAD_X3C", raising=False)
+    monkeypatch.delenv("PD_CONV_X3_MIN_WG", raising=False)
+    M16 = 16 * 256 * 320
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0) == 2            # encoder 5x5 at batch 16: 256-row tiles
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 2, 0, 0) == 2            # its stride-1 data gradient
+    assert lib.pd_conv2d_uses_x3(256 * 320, 64, 64, 3, 3, 1, 1, 0, 0, 0) == 1      # 320 tiles of 256 rows, 640 of 128
+    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 0, 0) == 0  # 320 tiles of 128 rows: fp32 kernel
+    assert lib.pd_conv2d_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 0, 0) == 0            # 32 output channels
+    assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0) == 0            # C % 16 != 0 (space-to-depth stem)
+    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 0, 0) == 0           # reflection padding
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 2, 0) == 0            # activation in the epilogue
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 0, 1) == 0            # folded BatchNorm scale
+    assert lib.pd_conv2d_uses_x3(4 * M16, 64, 128, 3, 3, 2, 1, 2, 0, 0) == 0       # stride-2 data gradient (parity launches)
+    assert lib.pd_conv2d_uses_x3(M16 // 4, 128, 64, 3, 3, 2, 1, 0, 0, 0) == 2      # stride-2 forward
+    # M, Cout, C, KH, KW, stride, pad, H, W, Ho, Wo
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 256, 320, 256, 320) == 1
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 256, 320, 256, 320) == 0     # 32-wide co tile
+    monkeypatch.setenv("PD_CONV_X3", "0")
+    monkeypatch.setenv("PD_WGRAD_X3C", "0")
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0) == 0
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 256, 320, 256, 320) == 0
