@@ -895,7 +895,11 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
 
     // ---- scalar state: the activation pieces run one chunk ahead, the weight pieces two
     const int dW4 = (MODE == MODE_ZERO ? (int)a.sW : -(int)a.sW) * 4, dH4 = (MODE == MODE_ZERO ? (int)a.sH : -(int)a.sH) * 4;
-    const int nchunks = a.K / CK;
+    // (a channel count that is no multiple of 16 -- the space-to-depth stems: 8, 12, 36 -- gets a last, partly empty channel
+    //  group: the lanes whose 16-byte slot lies beyond C fetch nothing)
+    const int ngroups = (a.C + CK - 1) / CK;
+    const int nchunks = ngroups * a.KH * a.KW;
+    const int c_lim = a.C - 4 * ((lane & 3) ^ ((lane >> 4) & 3));      // this lane's slot is valid while s_c < c_lim
     // Chunk order: the 16-channel group is the OUTER loop, the taps the inner one.  With the taps outside (the order of
     // the fp32 kernels) every input row is fetched once per filter row: the workgroups resident on an XCD hold ~25 000
     // pixels x 256 B = 6.3 MB of input in flight, more than its 4 MB L2, and the row a tile reads at tap row kh is read by
@@ -913,7 +917,7 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     auto load_a = [&](auto dst_tag, auto piece_tag) {
         constexpr unsigned DST = decltype(dst_tag)::value;
         constexpr int P = decltype(piece_tag)::value;
-        const unsigned bad = __builtin_amdgcn_ubfe(inv[P], (unsigned)s_tap, 1u);
+        const unsigned bad = __builtin_amdgcn_ubfe(inv[P], (unsigned)s_tap, 1u) | ((unsigned)(c_lim - 1 - s_c) >> 31);
         dma16s(rx, m0_a + DST * A_BYTES + 1024u * P, (bad << 31) + va[P], s_aoff);
     };
     auto advance_a = [&]() {
@@ -923,6 +927,8 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         if (s_tap == ntaps) { s_tap = 0; s_c += CK; s_aoff = aoff0 + (unsigned)s_c * 4u; }
         if (s_q >= nchunks) { s_tap = 31; s_aoff = 0; }          // run-out: every mask drops tap 31
     };
+    // (in a partly empty channel group the staged weight columns beyond C are the next tap's -- finite values that meet
+    //  zero activations)
     auto load_b = [&](auto dst_tag) {                             // chunk s_qb (past the end: chunk 0 again, never used)
         constexpr unsigned DST = decltype(dst_tag)::value;
         dma16s(rw_, m0_b + DST * BS_BYTES, vb, s_qb < nchunks ? s_boff : 0u);
@@ -1164,7 +1170,8 @@ static long x3_min_wg() {      // fewest workgroups that take the bf16-split ker
 static int x3_eligible(const ConvArgs& a, bool vec) {
     const char* e = getenv("PD_CONV_X3");          // read per call: the tests compare both kernels in one process
     const bool on = !(e && e[0] == '0');
-    if (!(on && vec && a.C % x3::CK == 0 && a.Co % x3::BN == 0 && a.M % 128 == 0 && a.KH * a.KW <= 31 &&
+    // (C % 4 == 0 is part of `vec`; a partly empty last channel group may at most double the contraction: C >= 8)
+    if (!(on && vec && (a.C + x3::CK - 1) / x3::CK * x3::CK <= 2 * a.C && a.Co % x3::BN == 0 && a.M % 128 == 0 && a.KH * a.KW <= 31 &&
           a.pad < a.KH && a.pad_w < a.KW && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) &&
           !a.oscale && a.act == ACT_NONE && (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
           (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0)) && (long)a.Co * a.K * 4 < 0x7fffffffL))

@@ -427,6 +427,8 @@ X3_CASES = [
     (4, 64, 64, 80, 512, 3, 1, 1),
     (1, 64, 256, 320, 64, 3, 1, 1),        # 320 tiles of 256 rows: the 128-row tiles (one row block per wave), bias
     (4, 64, 64, 80, 256, 3, 1, 1),         # ... with 64-row statistics tiles (M = 20480)
+    (2, 36, 256, 320, 64, 3, 1, 1),        # 36 channels (the space-to-depth normals stem): a partly empty third channel group
+    (2, 8, 256, 320, 64, 3, 1, 1),         # 8 channels (XOLP stem): one half-empty group
 ]
 
 
