@@ -1974,7 +1974,9 @@ constexpr unsigned P_BYTES = 3 * 4 * 64 * 16;                                 //
 constexpr unsigned LDS_BYTES = P_BASE + 2 * P_BYTES;                          // 72 KB
 }
 
-template <bool BIAS>
+// ROW8: the host guarantees Wo % 8 == 0 and slices of whole 8-pixel groups, so the eight pixels a wave stages per chunk
+// never straddle an output row: one row class and one 32-pixel advance per chunk instead of a state update per pixel pair.
+template <bool BIAS, bool ROW8>
 __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArgs ua) {
     using namespace x3c;
     const WgradArgs& a = ua.g;
@@ -2078,6 +2080,35 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
         }
     };
 
+    // the four pairs of a chunk (ROW8: they share an output row)
+    auto load_x_all = [&](auto dst_tag) {
+        if constexpr (ROW8) {
+            constexpr unsigned DST = decltype(dst_tag)::value;
+            const int ch = min(s_oh, ua.nb) + max(s_oh - (a.Ho - ua.nb) + 1, 0);
+            const unsigned dead = s_p < nrows ? 0u : 31u;                    // (slices end on 8-pixel boundaries)
+            const int pw0 = s_ow >> 1, pwe = (a.Wo >> 1) - ua.nbw;
+#pragma unroll
+            for (int J = 0; J < 4; ++J) {
+                const int cw = min(pw0 + J, ua.nbw) + max(pw0 + J - pwe + 1, 0);
+                const unsigned bad = __builtin_amdgcn_ubfe(xmask, (unsigned)(ch * ncw + cw) | dead, 1u);
+                dma16s(rx, m0_x + DST * X_BYTES + J * 2 * X_ROW, (bad << 31) + vx, (unsigned)(s_soff + J * 2 * st_w4));
+            }
+            s_p += WG_MC; s_ow += WG_MC; s_soff += WG_MC * st_w4;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {              // Wo >= 14 (host check): 32 columns wrap at most three times
+                const int ow0 = s_ow;
+                s_ow = ow0 >= a.Wo ? ow0 - a.Wo : ow0;
+                s_soff += ow0 >= a.Wo ? d_row4 : 0;
+                const int oh1 = ow0 >= a.Wo ? s_oh + 1 : s_oh;
+                s_soff += oh1 == a.Ho ? d_img4 : 0;
+                s_oh = oh1 == a.Ho ? 0 : oh1;
+            }
+        } else {
+            load_x(dst_tag, std::integral_constant<int, 0>{}); load_x(dst_tag, std::integral_constant<int, 1>{});
+            load_x(dst_tag, std::integral_constant<int, 2>{}); load_x(dst_tag, std::integral_constant<int, 3>{});
+        }
+    };
+
     // ---- fragment / split addresses: lane -> (index inside a 32-wide block = lane % 32, pixel half = lane / 32); the eight
     // pixels of (k-step g, half h) are 16 g + 2 e + h, e = 0..7 (even | odd pixels: the staging tiles keep odd pixels
     // XOR 32 floats, so the two half-waves of a ds_read_b32 sit on different banks).
@@ -2124,11 +2155,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
     auto chunk = [&](auto buf_tag) {
         constexpr unsigned BUF = decltype(buf_tag)::value, NXT = BUF ^ 1;
         const std::integral_constant<unsigned, NXT> nxt{};
-        load_x(nxt, std::integral_constant<int, 0>{});
-        load_x(nxt, std::integral_constant<int, 1>{});
+        load_x_all(nxt);
         load_d(buf_tag);                                   // chunk q + 2 into the slot whose chunk q was split during chunk q - 1
-        load_x(nxt, std::integral_constant<int, 2>{});
-        load_x(nxt, std::integral_constant<int, 3>{});
         if (!active) {                                     // (wave-uniform) no valid k column: only its share of the dY split
             split_d(nxt);
             dma_wait();
@@ -2200,8 +2228,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
     {
         const std::integral_constant<unsigned, 0> d0{};
         const std::integral_constant<unsigned, 1> d1{};
-        load_x(d0, std::integral_constant<int, 0>{}); load_x(d0, std::integral_constant<int, 1>{});
-        load_x(d0, std::integral_constant<int, 2>{}); load_x(d0, std::integral_constant<int, 3>{});
+        load_x_all(d0);
         load_d(d0);
         load_d(d1);
         dma_wait();
@@ -2398,13 +2425,29 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
             if (mode == MODE_ZERO) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 32>), grid, block, 0, st, ua);
             else hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, true, 32>), grid, block, 0, st, ua);
         } else if (mode == MODE_ZERO && wgrad_x3c_on()) {   // bf16-split products, every element split once
-            static const hipError_t lds_b = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<true>),
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, x3c::LDS_BYTES);
-            static const hipError_t lds_n = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<false>),
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, x3c::LDS_BYTES);
-            PD_REQUIRE(lds_b == hipSuccess && lds_n == hipSuccess, "pd_conv2d_wgrad: cannot reserve %u bytes of LDS", x3c::LDS_BYTES);
-            if (dbias) hipLaunchKernelGGL((conv_wgrad_x3c_kernel<true>), grid, block, x3c::LDS_BYTES, st, ua);
-            else hipLaunchKernelGGL((conv_wgrad_x3c_kernel<false>), grid, block, x3c::LDS_BYTES, st, ua);
+            static const hipError_t lds_ok = [] {
+                hipError_t e = hipSuccess;
+                for (const void* f : {reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<true, true>), reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<false, true>),
+                                      reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<true, false>), reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<false, false>)}) {
+                    const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, x3c::LDS_BYTES);
+                    if (r != hipSuccess) e = r;
+                }
+                return e;
+            }();
+            PD_REQUIRE(lds_ok == hipSuccess, "pd_conv2d_wgrad: cannot reserve %u bytes of LDS", x3c::LDS_BYTES);
+            // The lean walker pays on the small planes (3x3x256 @32x40: 133 -> 145 TF, 5x5 128 -> 256 @64x80: 159 -> 171) and
+            // loses on the large ones (5x5x64 @256x320: 148 -> 134; its four loads leave back to back instead of ~40 scalar
+            // instructions apart): planes of up to 8192 pixels take it.  PD_X3C_ROW8 = 0 never, 2 whenever the shape allows.
+            static const int row8_mode = getenv("PD_X3C_ROW8") ? atoi(getenv("PD_X3C_ROW8")) : 1;
+            const bool row8 = row8_mode != 0 && Wo % 8 == 0 && a.mper % 8 == 0 && a.M % 8 == 0 &&
+                              (row8_mode == 2 || (long)Ho * Wo <= 8192);
+            if (row8) {
+                if (dbias) hipLaunchKernelGGL((conv_wgrad_x3c_kernel<true, true>), grid, block, x3c::LDS_BYTES, st, ua);
+                else hipLaunchKernelGGL((conv_wgrad_x3c_kernel<false, true>), grid, block, x3c::LDS_BYTES, st, ua);
+            } else {
+                if (dbias) hipLaunchKernelGGL((conv_wgrad_x3c_kernel<true, false>), grid, block, x3c::LDS_BYTES, st, ua);
+                else hipLaunchKernelGGL((conv_wgrad_x3c_kernel<false, false>), grid, block, x3c::LDS_BYTES, st, ua);
+            }
         } else if (wgrad_x3_on()) {     // products on the bf16 matrix cores (three-way split, fp32 accuracy)
             if (mode == MODE_ZERO) {
                 if (dbias) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 64, true>), grid, block, 0, st, ua);
