@@ -192,10 +192,10 @@ int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* 
                     int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                     int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode,
                     int affine, float sub, float div, long ldd, int accumulate, void* stream);
-/* 1 when pd_conv2d_wgrad sends this zero-padded shape (16-byte aligned NHWC operands assumed) to the kernel that forms the
+/* 1 when pd_conv2d_wgrad sends this shape (zero or reflection padding; 16-byte aligned NHWC operands assumed) to the kernel that forms the
  * fp32 products on the bf16 matrix cores, every element split once (conv_wgrad_x3c_kernel; PD_WGRAD_X3C=0: fp32 MFMA) --
  * the profiler label of a launch and bench.py's roofline object use it. */
-int pd_conv2d_wgrad_uses_x3(long M, int Cout, int C, int KH, int KW, int stride, int pad, int H, int W, int Ho, int Wo);
+int pd_conv2d_wgrad_uses_x3(long M, int Cout, int C, int KH, int KW, int stride, int pad, int mode, int H, int W, int Ho, int Wo);
 
 /* 7x7 / stride-2 / pad-3 stems (pre_encoders.py:54 ShallowEncoder.Conv1, torchvision resnet conv1) executed as a
  * 4x4 / stride-1 / pad-2 convolution over the space-to-depth input [N][H/2][W/2][4C] (4C is a multiple of 4 ->

@@ -1976,8 +1976,11 @@ constexpr unsigned LDS_BYTES = P_BASE + 2 * P_BYTES;                          //
 
 // ROW8: the host guarantees Wo % 8 == 0 and slices of whole 8-pixel groups, so the eight pixels a wave stages per chunk
 // never straddle an output row: one row class and one 32-pixel advance per chunk instead of a state update per pixel pair.
-template <bool BIAS, bool ROW8>
+// REFLECT (ReflectionPad2d(1) + Conv3x3, the decoder): no tap is invalid; a lane whose tap leaves the image for the pair's
+// row / column gets +-2 rows / columns added, as in conv_wgrad_uni_kernel.
+template <bool BIAS, bool ROW8, bool REFLECT = false>
 __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArgs ua) {
+    static_assert(!(ROW8 && REFLECT), "the lean walker has no reflect variant");
     using namespace x3c;
     const WgradArgs& a = ua.g;
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
@@ -2006,13 +2009,20 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
 
     // ---- per-lane invariants of the staging (see conv_wgrad_uni_kernel)
     const int xh = lane >> 5;
-    const int kx = k0 + 4 * ((lane & 31) ^ (8 * xh));
+    const int kx0 = k0 + 4 * ((lane & 31) ^ (8 * xh));
+    const int kx = REFLECT ? min(kx0, a.K - 4) : kx0;   // reflect: lanes past K re-read the last columns (never stored)
     const int tap = kx / a.C;
     const int xc = kx - tap * a.C, xkh = tap / a.KW, xkw = tap - xkh * a.KW;
     const unsigned vx = (unsigned)(xkh * (int)a.sH + (xkw + xh * a.stride) * (int)a.sW + xc) * 4u;
     const int ncw = 2 * ua.nbw + 1;
+    const unsigned c_top = REFLECT && xkh == 0 ? (unsigned)(2 * (int)a.sH * 4) : 0u;
+    const unsigned c_bot = REFLECT && xkh == 2 ? (unsigned)(-2 * (int)a.sH * 4) : 0u;
+    const unsigned c_left = REFLECT && xkw == 0 && xh == 0 ? (unsigned)(2 * (int)a.sW * 4) : 0u;
+    const unsigned c_right = REFLECT && xkw == 2 && xh == 1 ? (unsigned)(-2 * (int)a.sW * 4) : 0u;
     unsigned xmask = 0x80000000u;
-    if (kx < a.K) {
+    if (REFLECT) {
+        xmask = 0;
+    } else if (kx < a.K) {
         for (int ch = 0; ch <= 2 * ua.nb; ++ch) {
             const int oh = ch <= ua.nb ? ch : a.Ho - ua.nb + (ch - ua.nb - 1);
             const bool bad_h = (unsigned)(oh * a.stride - a.pad + xkh) >= (unsigned)a.H;
@@ -2064,9 +2074,19 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
         const int ch = min(s_oh, ua.nb) + max(s_oh - (a.Ho - ua.nb) + 1, 0);
         const int pw = s_ow >> 1;
         const int cw = min(pw, ua.nbw) + max(pw - ((a.Wo >> 1) - ua.nbw) + 1, 0);
+        if constexpr (REFLECT) {
+            // pairs past the slice read an interior pair instead (their dY rows are zero): nothing leaves the tensor
+            const bool live = s_p < nrows;
+            const unsigned f_t = live && s_oh == 0 ? ~0u : 0u, f_b = live && s_oh == a.Ho - 1 ? ~0u : 0u;
+            const unsigned f_l = live && s_ow == 0 ? ~0u : 0u, f_r = live && s_ow == a.Wo - 2 ? ~0u : 0u;
+            const unsigned voff = vx + (f_t & c_top) + (f_b & c_bot) + ((f_l & c_left) + (f_r & c_right));
+            dma16s(rx, m0_x + DST * X_BYTES + J * 2 * X_ROW, voff,
+                   live ? (unsigned)s_soff : (unsigned)((int)a.sH + 2 * (int)a.sW) * 4u);
+        } else {
         const unsigned cls = (unsigned)(ch * ncw + cw) | (s_p < nrows ? 0u : 31u);
         const unsigned bad = __builtin_amdgcn_ubfe(xmask, cls, 1u);
         dma16s(rx, m0_x + DST * X_BYTES + J * 2 * X_ROW, (bad << 31) + vx, (unsigned)s_soff);
+        }
         constexpr int STEP = J < 3 ? 2 : WG_MC - 6;
         s_p += STEP; s_ow += STEP; s_soff += STEP * st_w4;
 #pragma unroll
@@ -2372,7 +2392,10 @@ static bool wgrad_x3c_on() {                  // read per call (PD_WGRAD_X3C=0: 
 }
 
 // 1 when pd_conv2d_wgrad sends this zero-padded shape (16-byte aligned NHWC operands assumed) to conv_wgrad_x3c_kernel
-extern "C" int pd_conv2d_wgrad_uses_x3(long M, int Co, int C, int KH, int KW, int stride, int pad, int H, int W, int Ho, int Wo) {
+extern "C" int pd_conv2d_wgrad_uses_x3(long M, int Co, int C, int KH, int KW, int stride, int pad, int mode, int H, int W, int Ho,
+                                       int Wo) {
+    const bool refl_ok = mode == MODE_REFLECT && pad == 1 && KH == 3 && KW == 3 && stride == 1 && Ho == H && Wo == W && H >= 3;
+    if (!(mode == MODE_ZERO || refl_ok)) return 0;
     static const bool uni_on = !(getenv("PD_WGRAD_UNI") && getenv("PD_WGRAD_UNI")[0] == '0');
     int S = 0; long mper = 0;
     wgrad_plan(M, Co, KH * KW * C, &S, &mper);
@@ -2424,11 +2447,13 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
         if (tco == 32) {              // 17..32 output channels (decoder 96->32, 64->32): reflect + bias in this network
             if (mode == MODE_ZERO) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 32>), grid, block, 0, st, ua);
             else hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, true, 32>), grid, block, 0, st, ua);
-        } else if (mode == MODE_ZERO && wgrad_x3c_on()) {   // bf16-split products, every element split once
+        } else if (wgrad_x3c_on()) {   // bf16-split products, every element split once (zero or reflection padding)
             static const hipError_t lds_ok = [] {
                 hipError_t e = hipSuccess;
                 for (const void* f : {reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<true, true>), reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<false, true>),
-                                      reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<true, false>), reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<false, false>)}) {
+                                      reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<true, false>), reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<false, false>),
+                                      reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<true, false, true>),
+                                      reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<false, false, true>)}) {
                     const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, x3c::LDS_BYTES);
                     if (r != hipSuccess) e = r;
                 }
@@ -2441,7 +2466,10 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
             static const int row8_mode = getenv("PD_X3C_ROW8") ? atoi(getenv("PD_X3C_ROW8")) : 1;
             const bool row8 = row8_mode != 0 && Wo % 8 == 0 && a.mper % 8 == 0 && a.M % 8 == 0 &&
                               (row8_mode == 2 || (long)Ho * Wo <= 8192);
-            if (row8) {
+            if (mode == MODE_REFLECT) {
+                if (dbias) hipLaunchKernelGGL((conv_wgrad_x3c_kernel<true, false, true>), grid, block, x3c::LDS_BYTES, st, ua);
+                else hipLaunchKernelGGL((conv_wgrad_x3c_kernel<false, false, true>), grid, block, x3c::LDS_BYTES, st, ua);
+            } else if (row8) {
                 if (dbias) hipLaunchKernelGGL((conv_wgrad_x3c_kernel<true, true>), grid, block, x3c::LDS_BYTES, st, ua);
                 else hipLaunchKernelGGL((conv_wgrad_x3c_kernel<false, true>), grid, block, x3c::LDS_BYTES, st, ua);
             } else {

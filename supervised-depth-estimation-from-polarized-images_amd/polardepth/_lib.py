@@ -35,7 +35,7 @@ SIGNATURES = {
     "pd_conv2d_tile_m": (_i, [_l, _i]),
     "pd_conv2d_stats_rows": (_l, [_l, _i]),
     "pd_conv2d_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "pd_conv2d_wgrad_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "pd_conv2d_wgrad_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "pd_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                        _i, _f, _f, _l, _vp]),
     "pd_conv16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _i, _i, _i, _l, _i, _i, _vp]),

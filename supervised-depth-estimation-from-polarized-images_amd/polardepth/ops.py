@@ -251,8 +251,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
     ws = _workspace(nbytes, x.device)
     sub, div = (affine if affine is not None else (0.0, 1.0))
     sN, sC, sH, sW = x.stride()
-    x3c = (mode == MODE_ZERO and affine is None and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0 and dy.stride(3) % 4 == 0
-           and lib.pd_conv2d_wgrad_uses_x3(M, Co, C, KH, KW, stride, pad, H, W, Ho, Wo))
+    x3c = (affine is None and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0 and dy.stride(3) % 4 == 0
+           and lib.pd_conv2d_wgrad_uses_x3(M, Co, C, KH, KW, stride, pad, mode, H, W, Ho, Wo))
     _profiled("conv_wgrad_x3c_kernel" if x3c else "conv_wgrad_kernel", 2.0 * M * Co * (alg_k if alg_k is not None else K),
               lambda: check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), N, H, W, C,
                                                 sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride, pad, mode,

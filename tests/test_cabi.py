@@ -210,10 +210,12 @@ def test_which_shapes_take_the_bf16_split_kernels(monkeypatch):
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 0, 1) == 0            # folded BatchNorm scale
     assert lib.pd_conv2d_uses_x3(4 * M16, 64, 128, 3, 3, 2, 1, 2, 0, 0) == 0       # stride-2 data gradient (parity launches)
     assert lib.pd_conv2d_uses_x3(M16 // 4, 128, 64, 3, 3, 2, 1, 0, 0, 0) == 2      # stride-2 forward
-    # M, Cout, C, KH, KW, stride, pad, H, W, Ho, Wo
-    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 256, 320, 256, 320) == 1
-    assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 256, 320, 256, 320) == 0     # 32-wide co tile
+    # M, Cout, C, KH, KW, stride, pad, mode, H, W, Ho, Wo
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320) == 1
+    assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160) == 1   # decoder: ReflectionPad2d(1) + Conv3x3
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 5, 5, 1, 2, 1, 256, 320, 256, 320) == 0       # reflect 5x5: general kernel
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 256, 320, 256, 320) == 0       # 32-wide co tile
     monkeypatch.setenv("PD_CONV_X3", "0")
     monkeypatch.setenv("PD_WGRAD_X3C", "0")
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0) == 0
-    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 256, 320, 256, 320) == 0
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320) == 0

@@ -124,10 +124,13 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
         _close(ops.conv2d_dgrad(dyd, wd, (H, W), stride=s, pad=p, addend=addd).cpu(), xr.grad + add, what="dgrad + addend")
 
 
+@pytest.mark.parametrize("x3", ["0", "1"])
 @pytest.mark.parametrize("case", [(4, 192, 128, 160, 64), (1, 96, 256, 320, 64), (3, 128, 150, 158, 64)])
-def test_production_tile_reflection_padded_conv(case):
+def test_production_tile_reflection_padded_conv(case, x3, monkeypatch):
     """Decoder upconvs (ReflectionPad2d(1) + Conv3x3 + ELU) on the 128x64 REFLECT instantiation + the reflect weight /
     bias gradient in its many-slice regime + the data gradient (pad-1 dgrad + border strips) through the autograd node."""
+    monkeypatch.setenv("PD_CONV_X3", x3)
+    monkeypatch.setenv("PD_WGRAD_X3C", x3)      # reflect weight gradient: bf16-split | fp32 MFMA kernel
     from polardepth import functional as PF
     N, C, H, W, Co = case
     g = torch.Generator().manual_seed(sum(case) + 3)
@@ -150,7 +153,7 @@ def test_production_tile_reflection_padded_conv(case):
         return y
     y, lab = _labels(run)
     # (forward on the REFLECT instantiation; the pad-1 data gradient is a zero-padding launch: fp32 or bf16-split kernel)
-    assert sum(l.startswith(("conv_igemm_uni_kernel<128,64>", "conv_igemm_x3_kernel")) for l in lab) == 2 and "conv_wgrad_kernel" in lab, lab
+    assert sum(l.startswith(("conv_igemm_uni_kernel<128,64>", "conv_igemm_x3_kernel")) for l in lab) == 2 and ("conv_wgrad_x3c_kernel" if x3 == "1" else "conv_wgrad_kernel") in lab, lab
     _close(y.detach().cpu(), ref.detach(), 3e-5, "fwd")
     _close(xc.grad.cpu(), xr.grad, 3e-5, "dgrad")
     _close(conv.weight.grad.cpu(), wr.grad, 3e-5, "wgrad")
