@@ -852,8 +852,11 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     const int hw = a.Ho * a.Wo;
 
     const int img0 = (int)(m0 / hw);
-    const long shift = MODE == MODE_ZERO ? (long)a.pad * a.sH + (long)a.pad_w * a.sW
-                                         : (long)(a.KH - 1 - a.pad) * a.sH + (long)(a.KW - 1 - a.pad_w) * a.sW;
+    // MODE_REFLECT (the decoder's ReflectionPad2d(1) + Conv3x3, same-size output): offsets as with zero padding; a tap that
+    // leaves the image is moved two rows / columns inwards -- a per-row correction (hcor, wcor: +2 rows at the top row, -2
+    // at the bottom one, 0 elsewhere; same for columns) that applies when the tap is the first / last of its dimension.
+    const long shift = MODE != MODE_TRANSPOSED ? (long)a.pad * a.sH + (long)a.pad_w * a.sW
+                                               : (long)(a.KH - 1 - a.pad) * a.sH + (long)(a.KW - 1 - a.pad_w) * a.sW;
     const long rest = (((long)a.N - img0) * a.sN + shift) * 4;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img0 * a.sN - shift, rest > 0x7fffffffL ? 0x7fffffffu : (unsigned)rest);
     const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, a.w_bytes);
@@ -864,6 +867,7 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     const unsigned col4 = 16u * ((lane & 3) ^ ((lane >> 4) & 3));
     const unsigned ones_kw = (1u << a.KW) - 1u;
     unsigned va[2 * RB], inv[2 * RB];
+    int hcor[MODE == MODE_REFLECT ? 2 * RB : 1], wcor[MODE == MODE_REFLECT ? 2 * RB : 1];
 #pragma unroll
     for (int i = 0; i < 2 * RB; ++i) {
         const long m = m0 + 32 * RB * wave + 16 * i + prow;
@@ -873,6 +877,12 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         const int oh = (int)magic_div(rem, a.mg_wo, a.sh_wo);
         const int ow = (int)rem - oh * a.Wo;
         va[i] = (unsigned)((int)dn * (int)a.sN + oh * a.stride * (int)a.sH + ow * a.stride * (int)a.sW) * 4u + col4;
+        if constexpr (MODE == MODE_REFLECT) {
+            hcor[i] = oh == 0 ? 2 * (int)a.sH * 4 : oh == a.H - 1 ? -2 * (int)a.sH * 4 : 0;
+            wcor[i] = ow == 0 ? 2 * (int)a.sW * 4 : ow == a.W - 1 ? -2 * (int)a.sW * 4 : 0;
+            inv[i] = 0;
+            continue;
+        }
         int lo_h, hi_h, lo_w, hi_w;       // taps outside the image: a prefix [0, lo) and a suffix [hi, K) per dimension
         if (MODE == MODE_ZERO) {
             lo_h = a.pad - oh * a.stride; hi_h = a.H + lo_h;
@@ -894,7 +904,7 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     const unsigned vb = (unsigned)((n0 + 16 * wave + prow) * a.K) * 4u + col4;
 
     // ---- scalar state: the activation pieces run one chunk ahead, the weight pieces two
-    const int dW4 = (MODE == MODE_ZERO ? (int)a.sW : -(int)a.sW) * 4, dH4 = (MODE == MODE_ZERO ? (int)a.sH : -(int)a.sH) * 4;
+    const int dW4 = (MODE != MODE_TRANSPOSED ? (int)a.sW : -(int)a.sW) * 4, dH4 = (MODE != MODE_TRANSPOSED ? (int)a.sH : -(int)a.sH) * 4;
     // (a channel count that is no multiple of 16 -- the space-to-depth stems: 8, 12, 36 -- gets a last, partly empty channel
     //  group: the lanes whose 16-byte slot lies beyond C fetch nothing)
     const int ngroups = (a.C + CK - 1) / CK;
@@ -907,7 +917,7 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     // group outside, all KH*KW taps of a 64-byte segment follow each other and the footprint between reuses is a quarter.
     const int ntaps = a.KH * a.KW;
     const unsigned aoff0 = MODE != MODE_TRANSPOSED ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
-    int s_q = 0, s_tap = 0, s_kw = 0, s_c = 0;
+    int s_q = 0, s_tap = 0, s_kw = 0, s_kh = 0, s_c = 0;
     unsigned s_aoff = aoff0;
     int s_qb = 0, sb_tap = 0;
     unsigned s_boff = 0, sb_c4 = 0;
@@ -917,14 +927,21 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     auto load_a = [&](auto dst_tag, auto piece_tag) {
         constexpr unsigned DST = decltype(dst_tag)::value;
         constexpr int P = decltype(piece_tag)::value;
+        if constexpr (MODE == MODE_REFLECT) {
+            const int hs = s_kh == 0 ? max(hcor[P], 0) : s_kh == 2 ? min(hcor[P], 0) : 0;       // (uniform selects)
+            const int ws = s_kw == 0 ? max(wcor[P], 0) : s_kw == 2 ? min(wcor[P], 0) : 0;
+            const unsigned bad = (s_tap == 31 ? 1u : 0u) | ((unsigned)(c_lim - 1 - s_c) >> 31);
+            dma16s(rx, m0_a + DST * A_BYTES + 1024u * P, (bad << 31) + (va[P] + (unsigned)(hs + ws)), s_aoff);
+        } else {
         const unsigned bad = __builtin_amdgcn_ubfe(inv[P], (unsigned)s_tap, 1u) | ((unsigned)(c_lim - 1 - s_c) >> 31);
         dma16s(rx, m0_a + DST * A_BYTES + 1024u * P, (bad << 31) + va[P], s_aoff);
+        }
     };
     auto advance_a = [&]() {
         ++s_q;
         ++s_tap; s_aoff += (unsigned)dW4;
-        if (++s_kw == a.KW) { s_kw = 0; s_aoff += (unsigned)(dH4 - a.KW * dW4); }
-        if (s_tap == ntaps) { s_tap = 0; s_c += CK; s_aoff = aoff0 + (unsigned)s_c * 4u; }
+        if (++s_kw == a.KW) { s_kw = 0; ++s_kh; s_aoff += (unsigned)(dH4 - a.KW * dW4); }
+        if (s_tap == ntaps) { s_tap = 0; s_kh = 0; s_c += CK; s_aoff = aoff0 + (unsigned)s_c * 4u; }
         if (s_q >= nchunks) { s_tap = 31; s_aoff = 0; }          // run-out: every mask drops tap 31
     };
     // (in a partly empty channel group the staged weight columns beyond C are the next tap's -- finite values that meet
@@ -1092,7 +1109,7 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
     }
 
-    // ---- epilogue (full tiles, no scale / activation: the host routes nothing else here): per column block the
+    // ---- epilogue (full tiles, no scale, activation none | ELU: the host routes nothing else here): per column block the
     // wave transposes its 64 x 32 block through LDS and leaves with full 128-byte lines; BatchNorm partial sums per
     // 128-row half of the tile
     {
@@ -1100,6 +1117,7 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         float* T = smem_all + wave * (RW * 32);                        // 4 | 8 KB per wave; the ring is dead
         float (*red)[BN][2] = reinterpret_cast<float (*)[BN][2]>(smem_all + 4 * RW * 32);
         const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+        const bool elu = a.act == ACT_ELU;
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)BM * a.ldy * 4));
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.add ? a.add + m0 * a.ld_add : a.y, a.add ? (unsigned)((long)BM * a.ld_add * 4) : 0u);
 #pragma unroll
@@ -1117,7 +1135,9 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[i][j][r] + bv;
-                    T[(32 * i + (r & 3) + 8 * (r >> 2) + rbase) * 32 + col_l] = v;
+                    // (ELU as torch evaluates it, exp(x) - 1, on the hardware exp2: see conv_epilogue)
+                    T[(32 * i + (r & 3) + 8 * (r >> 2) + rbase) * 32 + col_l] =
+                        elu ? (v > 0.f ? v : __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f) : v;
                     s1 += v;
                     s2 = __builtin_fmaf(v, v, s2);
                 }
@@ -1172,8 +1192,11 @@ static int x3_eligible(const ConvArgs& a, bool vec) {
     const bool on = !(e && e[0] == '0');
     // (C % 4 == 0 is part of `vec`; a partly empty last channel group may at most double the contraction: C >= 8)
     if (!(on && vec && (a.C + x3::CK - 1) / x3::CK * x3::CK <= 2 * a.C && a.Co % x3::BN == 0 && a.M % 128 == 0 && a.KH * a.KW <= 31 &&
-          a.pad < a.KH && a.pad_w < a.KW && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) &&
-          !a.oscale && a.act == ACT_NONE && (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
+          a.pad < a.KH && a.pad_w < a.KW &&
+          (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0) ||
+           (a.mode == MODE_REFLECT && a.KH == 3 && a.KW == 3 && a.pad == 1 && a.pad_w == 1 && a.stride == 1 && a.Ho == a.H &&
+            a.Wo == a.W && a.H >= 3 && a.W >= 3)) &&
+          !a.oscale && (a.act == ACT_NONE || a.act == ACT_ELU) && (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
           (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0)) && (long)a.Co * a.K * 4 < 0x7fffffffL))
         return 0;
     const long ct = a.Co / x3::BN;
@@ -1189,9 +1212,11 @@ static int launch_conv_x3(ConvArgs& a, int rb, hipStream_t st) {
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
     if (rb == 2) {
         if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_ZERO, 2>), grid, block, 0, st, a);
+        else if (a.mode == MODE_REFLECT) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_REFLECT, 2>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_TRANSPOSED, 2>), grid, block, 0, st, a);
     } else {
         if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_ZERO, 1>), grid, block, 0, st, a);
+        else if (a.mode == MODE_REFLECT) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_REFLECT, 1>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_TRANSPOSED, 1>), grid, block, 0, st, a);
     }
     return pd::check_launch("pd_conv2d");
@@ -1255,6 +1280,7 @@ extern "C" int pd_conv2d_uses_x3(long M, int Co, int C, int KH, int KW, int stri
     ConvArgs a{};
     a.M = M; a.Co = Co; a.C = C; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = a.pad_w = pad; a.mode = mode; a.act = act;
     a.K = KH * KW * C; a.ldy = Co;
+    a.H = a.Ho = a.W = a.Wo = 16;             // (reflection padding: a same-size 3x3 layer is assumed)
     a.oscale = has_out_scale ? reinterpret_cast<const float*>(16) : nullptr;
     while ((1 << a.sshift) < stride) ++a.sshift;
     return x3_eligible(a, true);

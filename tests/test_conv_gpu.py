@@ -490,3 +490,24 @@ def test_bf16x3_kernel_keeps_fp32_accuracy(case, monkeypatch):
     # the weight gradient sums 65536+ products per element: slices of <= 4096 pixels in fp32, partial tiles added in order
     assert dwe["1"] <= 2e-5 and dwe["1"] <= 1.5 * dwe["0"] + 1e-7 and dwe["r"] <= 1.5 * dwe["0"] + 1e-7, dwe
     assert dbe["1"] <= 2e-5 and dbe["0"] <= 2e-5, dbe
+
+
+@pytest.mark.parametrize("case", [(8, 128, 128, 160, 64), (16, 256, 64, 80, 128), (16, 512, 32, 40, 256), (4, 48, 128, 160, 64)])
+def test_bf16x3_kernel_reflection_padding_bias_elu(case, monkeypatch):
+    """The decoder's ConvBlock (ReflectionPad2d(1) + Conv3x3 + bias + ELU) on the bf16-split kernel (256- and 128-row tiles, a
+    partly empty channel group) vs an fp64 reference, next to the fp32-MFMA kernel."""
+    N, C, H, W, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.3
+    ref = F.elu(F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w.double(), b.double()))
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    errs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("PD_CONV_X3", knob)
+        assert bool(ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, 3, 3, 1, 1, ops.MODE_REFLECT, ops.ACT_ELU, 0)) == (knob == "1")
+        y = ops.conv2d_fwd(xd, wd, b.cuda(), stride=1, pad=1, mode=ops.MODE_REFLECT, act=ops.ACT_ELU)
+        errs[knob] = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert errs["1"] <= 5e-6 and errs["1"] <= 1.5 * errs["0"] + 1e-7, errs
