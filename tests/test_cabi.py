@@ -205,8 +205,10 @@ def test_which_shapes_take_the_bf16_split_kernels(monkeypatch):
     assert lib.pd_conv2d_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 0, 0) == 0            # 32 output channels
     assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0) == 2            # space-to-depth stem: 36 = 2 channel groups + 4
     assert lib.pd_conv2d_uses_x3(M16, 64, 4, 4, 4, 1, 2, 0, 0, 0) == 0             # a group of 16 with 4 valid channels: no
-    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 0, 0) == 0           # reflection padding
-    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 2, 0) == 0            # activation in the epilogue
+    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 2, 0) == 2           # decoder ConvBlock: 3x3 reflection padding + ELU
+    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 5, 5, 1, 2, 1, 0, 0) == 0           # 5x5 reflection padding
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 1, 0) == 0            # ReLU in the epilogue
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 3, 0) == 0            # sigmoid in the epilogue
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 0, 1) == 0            # folded BatchNorm scale
     assert lib.pd_conv2d_uses_x3(4 * M16, 64, 128, 3, 3, 2, 1, 2, 0, 0) == 0       # stride-2 data gradient (parity launches)
     assert lib.pd_conv2d_uses_x3(M16 // 4, 128, 64, 3, 3, 2, 1, 0, 0, 0) == 2      # stride-2 forward
