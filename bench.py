@@ -511,8 +511,8 @@ def main():
         "eager": eager, "graph": graph_info,
         "roofline": roofline, "xolp_kernel": xolp_kernel,
         "precision": {"accumulate": "f32",
-                      "conv_products": "fp32 MFMA; the 64-column layers with >= 512 tiles (forward and stride-1 data gradient) and the "
-                                       "zero-padded weight gradients with >= 33 output channels form each fp32 product from a "
+                      "conv_products": "fp32 MFMA; the 64-column layers with >= 512 tiles (forward with zero or 3x3 reflection padding, "
+                                       "stride-1 data gradient) and the weight gradients with >= 33 output channels form each fp32 product from a "
                                        "three-way bf16 split of both operands (six bf16 MFMAs, dropped terms <= 2^-23 of the "
                                        "product)" if os.environ.get("PD_CONV_X3", "1") != "0" else "fp32 MFMA",
                       "evidence": "tests/test_conv_gpu.py::test_bf16x3_kernel_keeps_fp32_accuracy: error vs an fp64 convolution "
