@@ -133,7 +133,7 @@ long pd_conv2d_stats_rows(long M, int Cout);
 /* Non-zero (2 | 1: 256- | 128-row tiles) when pd_conv2d / pd_conv2d_add send this shape (16-byte aligned NHWC operands assumed) to the kernel that forms the fp32
  * products on the bf16 matrix cores (conv_igemm_x3_kernel: x = hi + mid + lo in bf16, six MFMAs per 32x32x16 block, fp32
  * accumulation; PD_CONV_X3=0 keeps every layer on the fp32 MFMA): zero padding, the stride-1 data gradient or 3x3 reflection padding (a same-size layer is assumed), C % 4 == 0 and >= 8 (16-channel groups, the last may be partly empty),
- * Cout % 64 == 0, at least 512 tiles of 256 x 64 (M % 256 == 0) or of 128 x 64 (M % 128 == 0), no out_scale, activation none or ELU.  The profiler label of a launch
+ * Cout % 64 == 0, at least 512 tiles of 256 x 64 (M % 256 == 0) or 320 of 128 x 64 (M % 128 == 0), no out_scale, activation none or ELU.  The profiler label of a launch
  * (ops._igemm_label) and bench.py's roofline object use it. */
 int pd_conv2d_uses_x3(long M, int Cout, int C, int KH, int KW, int stride, int pad, int mode, int act, int has_out_scale);
 int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,

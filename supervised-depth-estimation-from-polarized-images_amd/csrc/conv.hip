@@ -1201,8 +1201,11 @@ static int x3_eligible(const ConvArgs& a, bool vec) {
         return 0;
     const long ct = a.Co / x3::BN;
     if (a.M % 256 == 0 && (a.M / 256) * ct >= x3_min_wg()) return 2;
+    // 128-row tiles (four workgroups per CU): worth it from 320 tiles on (3x3x512 @16x20: 117 -> 134 TF); a layer with 320
+    // tiles of 256 rows is better off with its 640 tiles of 128 (64 -> 64 @64x80: 113 vs 102 TF, 3x3x256 @32x40: 161 vs 145)
     static const bool rb1 = !(getenv("PD_CONV_X3_RB1") && getenv("PD_CONV_X3_RB1")[0] == '0');
-    return rb1 && (a.M / 128) * ct >= x3_min_wg() ? 1 : 0;
+    static const long min_wg1 = getenv("PD_CONV_X3_MIN_WG1") ? atol(getenv("PD_CONV_X3_MIN_WG1")) : 320;
+    return rb1 && (a.M / 128) * ct >= min_wg1 ? 1 : 0;
 }
 
 static int launch_conv_x3(ConvArgs& a, int rb, hipStream_t st) {

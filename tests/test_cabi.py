@@ -201,7 +201,8 @@ def test_which_shapes_take_the_bf16_split_kernels(monkeypatch):
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0) == 2            # encoder 5x5 at batch 16: 256-row tiles
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 2, 0, 0) == 2            # its stride-1 data gradient
     assert lib.pd_conv2d_uses_x3(256 * 320, 64, 64, 3, 3, 1, 1, 0, 0, 0) == 1      # 320 tiles of 256 rows, 640 of 128
-    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 0, 0) == 0  # 320 tiles of 128 rows: fp32 kernel
+    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 0, 0) == 1  # 320 tiles of 128 rows
+    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 256, 512, 3, 3, 1, 1, 0, 0, 0) == 0  # 160 tiles of 128 rows: fp32 kernel
     assert lib.pd_conv2d_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 0, 0) == 0            # 32 output channels
     assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0) == 2            # space-to-depth stem: 36 = 2 channel groups + 4
     assert lib.pd_conv2d_uses_x3(M16, 64, 4, 4, 4, 1, 2, 0, 0, 0) == 0             # a group of 16 with 4 valid channels: no

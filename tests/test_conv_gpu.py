@@ -415,7 +415,7 @@ def test_disparity_head_direct_kernels(case, fused, monkeypatch):
 
 
 X3_CASES = [
-    # N, C, H, W, Co, k, s, p -- shapes of the bf16x3 kernel (>= 512 tiles of 256 x 64 or 128 x 64, C % 16 == 0,
+    # N, C, H, W, Co, k, s, p -- shapes of the bf16x3 kernel (>= 512 tiles of 256 x 64 or >= 320 of 128 x 64, C % 4 == 0,
     # Co % 64 == 0): the 64-channel 3x3 / 5x5 layers of the shallow encoders, a stride-2 layer, 16 | C only, two column
     # tiles, a tile spanning two images, a small-M layer with 64-row statistics tiles (M < 65536)
     (2, 64, 256, 320, 64, 3, 1, 1),

@@ -80,7 +80,7 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
         rb = ops.lib.pd_conv2d_uses_x3(Mx, Cox, Cx, k, k, sx, p, mode, 0, 0)
         want = 0
         if x3 == "1" and Cox % 64 == 0 and Cx % 4 == 0 and -(-Cx // 16) * 16 <= 2 * Cx:
-            want = 2 if (Mx % 256 == 0 and (Mx // 256) * (Cox // 64) >= 512) else 1 if (Mx % 128 == 0 and (Mx // 128) * (Cox // 64) >= 512) else 0
+            want = 2 if (Mx % 256 == 0 and (Mx // 256) * (Cox // 64) >= 512) else 1 if (Mx % 128 == 0 and (Mx // 128) * (Cox // 64) >= 320) else 0
         assert rb == want, (rb, want)
         return [f"conv_igemm_x3_kernel<{128 * rb},64>" if rb else "conv_igemm_uni_kernel<128,64>"]
 
