@@ -760,8 +760,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
 // bits each -- hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest, both subtractions exact,
 // |x - hi - mid - lo| <= 2^-27 |x| -- and a product a*b is
 //     hi*hi + (hi*mid + mid*hi) + (mid*mid + hi*lo + lo*hi)   + terms <= 2^-24 |a*b| (mid*lo, lo*mid, lo*lo: dropped),
-// every partial product exact in the fp32 accumulator's input (8 x 8 bits).  Six bf16 MFMAs per 32x32x16 block, summed
-// small terms first, instead of eight fp32 MFMAs of four times the duration: the contraction keeps fp32 accuracy (the
+// every partial product exact in the fp32 accumulator's input (8 x 8 bits).  Six bf16 MFMAs per 32x32x16 block (issued
+// largest term first, in the order the split yields the terms) instead of eight fp32 MFMAs of twice the duration each: the contraction keeps fp32 accuracy (the
 // dropped terms are of the size of ONE fp32 rounding of the product; tests/test_conv_gpu.py measures the kernel's error
 // against an fp64 convolution next to the fp32 kernel's) at 2.7x the matrix rate.  What it costs is the split: ~4.5
 // vector instructions per operand element (tools/bf16x3_peak.hip: the probe that sized this kernel).  So
@@ -769,10 +769,12 @@ __global__ __launch_bounds__(NT) void conv_igemm_uni_kernel(const ConvArgs a) {
 //     stages, splits and multiplies its own 64 rows), 3 vector instructions per MFMA;
 //   * the weights of a chunk (64 x 16) are split ONCE per workgroup, by all 256 threads, one chunk ahead, from an fp32
 //     staging tile into three bf16 planes in LDS: no pre-split copies in memory that could go stale, no extra launch;
-//   * chunks are 16 deep (one MFMA k-step; C % 16 == 0), so that three workgroups fit a CU (52 KB each) and the split of
-//     one wave runs under the MFMAs of the two others.
-// Gather, masks and scalar tap state are those of conv_igemm_uni_kernel.  Output tile 256 x 64; the BatchNorm partial
-// sums keep their 128-row granularity (two rows of `stats` per workgroup), so pd_conv2d_stats_rows() does not change.
+//   * chunks are 16 deep (one MFMA k-step: a 16-channel group of one tap; the channel group is the OUTER loop), so that
+//     three workgroups fit a CU (52 KB each) and the split of one wave runs under the MFMAs of the two others;
+//   * the vector work is threaded between the MFMAs in program order (see chunk()).
+// Gather, masks and scalar tap state are those of conv_igemm_uni_kernel.  Output tile 256 x 64 (128 x 64 with one row
+// block per wave); the BatchNorm partial sums keep their 128- / 64-row granularity, so pd_conv2d_stats_rows() does not
+// change.  (The constants below are those of the 256-row tile; the kernel derives its own from RB.)
 namespace x3 {
 constexpr int BM = 256, BN = 64, CK = 16;
 constexpr unsigned A_BYTES = BM * CK * 4;          // 16 KB per ring slot
