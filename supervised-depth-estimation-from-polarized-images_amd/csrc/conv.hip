@@ -2384,6 +2384,11 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const flo
 
 inline int wgrad_tco(int Co) { return Co > 32 ? 64 : (Co > 16 ? 32 : 16); }
 
+bool wgrad_x3c_enabled() {                    // read per call (PD_WGRAD_X3C=0: weight gradients on the fp32 MFMA)
+    const char* e = getenv("PD_WGRAD_X3C");
+    return !(e && e[0] == '0');
+}
+
 void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
     const int tco = wgrad_tco(Co);
     const long tiles = (long)((Co + tco - 1) / tco) * ((K + WG_K - 1) / WG_K);
@@ -2391,8 +2396,13 @@ void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
     // be small (many tiles: 512-channel layers, S = 2 leaves a quarter of the slots empty); ONE round -- longer slices,
     // half the partial tiles to write and reduce -- when the tiles are few (measured +5 % on the 128x160 / 64x80 layers,
     // -7..-14 % on the many-tile layers, equal on the 256x320 ones)
+    // The bf16-split kernel (64-wide co tile; 72 KB of LDS) has 512 resident workgroups, not 768: one round of those when
+    // the tiles are few (3x3x128 @64x80: 144 -> 162 TF, 3x3x256 @32x40: 150 -> 163, 3x3x64 @128x160: 132 -> 137 against the
+    // 768-workgroup plan), two for the million-pixel layers (5x5x64 @256x320: 153 -> 159), three when one round would leave
+    // fewer than four slices per tile (3x3x512 @16x20, 288 tiles: 134 TF with 1536 workgroups, 92 with 512).
     static const long forced = getenv("PD_WGRAD_WGS") ? atol(getenv("PD_WGRAD_WGS")) : 0;
-    const long total = forced ? forced : (tiles <= 32 ? 768 : 1536);
+    const bool x3c = tco == 64 && wgrad_x3c_enabled();
+    const long total = forced ? forced : x3c ? (512 / tiles < 4 ? 1536 : M >= (1L << 20) ? 1024 : 512) : (tiles <= 32 ? 768 : 1536);
     long s = total / tiles;
     const long smax = (M + 511) / 512;
     if (s > smax) s = smax;
@@ -2417,10 +2427,7 @@ static bool wgrad_x3_on() {                   // read per call: the tests compar
     return e && e[0] == '1';
 }
 
-static bool wgrad_x3c_on() {                  // read per call (PD_WGRAD_X3C=0: weight gradients on the fp32 MFMA)
-    const char* e = getenv("PD_WGRAD_X3C");
-    return !(e && e[0] == '0');
-}
+static bool wgrad_x3c_on() { return wgrad_x3c_enabled(); }
 
 // 1 when pd_conv2d_wgrad sends this zero-padded shape (16-byte aligned NHWC operands assumed) to conv_wgrad_x3c_kernel
 extern "C" int pd_conv2d_wgrad_uses_x3(long M, int Co, int C, int KH, int KW, int stride, int pad, int mode, int H, int W, int Ho,
