@@ -107,7 +107,8 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
 
     dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
     S = ops.lib.pd_conv2d_wgrad_workspace(M, Co, k * k * C) // (4 * (Co * k * k * C + Co))
-    assert S >= 15, f"weight gradient not in the many-slice regime (S = {S})"
+    # (the bf16-split kernel plans for its 512 resident workgroups: one round when that leaves >= 4 slices per tile)
+    assert S >= (4 if x3 == "1" else 15), f"weight gradient not in the many-slice regime (S = {S})"
     dw, lab = _labels(lambda: ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p))
     assert lab == (["conv_wgrad_x3c_kernel"] if x3 == "1" else ["conv_wgrad_kernel"]), lab
     _close(dw.cpu(), wr.grad, what="wgrad")
