@@ -16,7 +16,9 @@
  *     synchronises the device;
  *   - return 0 on success, a negative PD_E* code on failure; the message is
  *     available from pd_last_error() (thread-local);
- *   - re-entrant: no global mutable state.
+ *   - re-entrant: no global mutable state (the only process-wide data are read-only lookup tables and idempotent
+ *     hipFuncSetAttribute bookkeeping); the library reads NO environment variable -- every choice a caller can make
+ *     (kernel family / arithmetic, measurement variants) is an argument of the entry point it concerns.
  */
 #ifndef POLARDEPTH_H
 #define POLARDEPTH_H
@@ -61,6 +63,10 @@ int pd_version(void);
  * Newton-refined hardware seeds with a rounding test (same bits, ~1.3x the arithmetic); the exhaustive test
  * compares the two over all 2^32 uint8 quadruples. */
 #define PD_POLAR_IEEE_RHO 2
+/* measurement only (tools/bench_polar.py): force the nontemporal hint on / off the plane loads of the training step's
+ * instantiation; by default launches of up to 32 frames' worth of 512x640 output carry it. */
+#define PD_POLAR_NT_LOADS 4
+#define PD_POLAR_PLAIN_LOADS 8
 
 /* bytes needed for the table blob with n_d / n_s1 / n_s2 table nodes */
 size_t pd_polar_tables_bytes(int n_d, int n_s1, int n_s2);
@@ -127,19 +133,36 @@ int pd_polar_theta(const void* rho, void* theta_d, void* theta_s1, void* theta_s
  *       (ShallowEncoder.normalizeInput pre_encoders.py:76-83, resnet_encoder.py:812), scalar path only.
  * stats  NULL or fp32 [pd_conv2d_stats_rows(M,Cout)][Cout][2]: per-workgroup column sums and sums
  *       of squares of (conv + bias) -- training-mode BatchNorm statistics (reduced by pd_bn_finalize).
+ * flags  kernel family / arithmetic of the products, the same word for pd_conv2d, pd_conv2d_add, pd_conv2d_rect,
+ *       pd_conv2d_wgrad and their query functions (a query answers for the flags it is given):
+ *         PD_CONV_AUTO       the library's choice (bf16-split products where they are faster, fp32 MFMA elsewhere);
+ *         PD_CONV_FP32_MFMA  every product on v_mfma_f32_32x32x2_f32 / 16x16x4 (the reference's own arithmetic:
+ *                            plain fp32 nn.Conv2d, pre_encoders.py:8-34);
+ *         PD_CONV_BF16X3     bf16-split products whenever the shape fits those kernels, whatever the tile count (tests);
+ *         PD_CONV_WGRAD_SPLIT_IN_REGS  weight gradient: conv_wgrad_uni_kernel's in-register split instead of
+ *                            conv_wgrad_x3c_kernel (kept for its test; slower than either);
+ *         PD_CONV_GENERAL_KERNELS      the general gather kernels instead of the uniform-tap / scalar-pixel ones (tests).
+ *       PD_CONV_FP32_MFMA and PD_CONV_BF16X3 exclude each other; unknown bits are an error.
  */
+#define PD_CONV_AUTO 0u
+#define PD_CONV_FP32_MFMA 1u
+#define PD_CONV_BF16X3 2u
+#define PD_CONV_WGRAD_SPLIT_IN_REGS 4u
+#define PD_CONV_GENERAL_KERNELS 8u
+#define PD_CONV_FLAGS_ALL 15u
 int pd_conv2d_tile_m(long M, int Cout);
 long pd_conv2d_stats_rows(long M, int Cout);
 /* Non-zero (2 | 1: 256- | 128-row tiles) when pd_conv2d / pd_conv2d_add send this shape (16-byte aligned NHWC operands assumed) to the kernel that forms the fp32
  * products on the bf16 matrix cores (conv_igemm_x3_kernel: x = hi + mid + lo in bf16, six MFMAs per 32x32x16 block, fp32
- * accumulation; PD_CONV_X3=0 keeps every layer on the fp32 MFMA): zero padding, the stride-1 data gradient or 3x3 reflection padding (a same-size layer is assumed), C % 4 == 0 and >= 8 (16-channel groups, the last may be partly empty),
+ * accumulation; PD_CONV_FP32_MFMA in `flags` keeps every layer on the fp32 MFMA): zero padding, the stride-1 data gradient or 3x3 reflection padding (a same-size layer is assumed), C % 4 == 0 and >= 8 (16-channel groups, the last may be partly empty),
  * Cout % 64 == 0, at least 512 tiles of 256 x 64 (M % 256 == 0) or 320 of 128 x 64 (M % 128 == 0), no out_scale, activation none or ELU.  The profiler label of a launch
  * (ops._igemm_label) and bench.py's roofline object use it. */
-int pd_conv2d_uses_x3(long M, int Cout, int C, int KH, int KW, int stride, int pad, int mode, int act, int has_out_scale);
+int pd_conv2d_uses_x3(long M, int Cout, int C, int KH, int KW, int stride, int pad, int mode, int act, int has_out_scale,
+                      unsigned flags);
 int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
               int N, int H, int W, int C, long sN, long sH, long sW, long sC,
               int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode, int act,
-              int affine, float sub, float div, long ldy, void* stream);
+              int affine, float sub, float div, long ldy, unsigned flags, void* stream);
 
 /* The 16-channel decoder tail (depth_decoder.py upconv(0,0) 32->16, upconv(0,1) 16->16; layers.py:329-380): 3x3
  * convolutions with 16 output channels from an input halo tile staged once in LDS (the implicit GEMM above re-stages
@@ -172,7 +195,8 @@ int pd_conv16_wgrad(const void* x, const void* dz, void* dw, void* dbias, void* 
  * column padding, no bias / activation; needs C % 32 == 0 and 16-byte aligned NHWC operands (uniform-tap kernel). */
 int pd_dgrad_s2_filters(const void* wt, void* wsub, int Cin, int Cout, void* stream);
 int pd_conv2d_rect(const void* x, const void* w, void* y, int N, int H, int W, int C, long sN, long sH, long sW, long sC,
-                   int Ho, int Wo, int Cout, int KH, int KW, int pad_h, int pad_w, int mode, long ldy, void* stream);
+                   int Ho, int Wo, int Cout, int KH, int KW, int pad_h, int pad_w, int mode, long ldy, unsigned flags,
+                   void* stream);
 int pd_interleave4(const void* sub, void* dx, int N, int Ho, int Wo, int C, void* stream);
 
 /* y = conv(x, w) + addend: the same convolution (no bias / scale / activation / statistics) with an NHWC tensor of the
@@ -181,21 +205,23 @@ int pd_interleave4(const void* sub, void* dx, int N, int Ho, int Wo, int C, void
  * separate pass (the reference: torch's `out += identity` backward, pre_encoders.py:46, torchvision BasicBlock). */
 int pd_conv2d_add(const void* x, const void* w, const void* addend, long ld_add, void* y,
                   int N, int H, int W, int C, long sN, long sH, long sW, long sC,
-                  int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode, long ldy, void* stream);
+                  int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode, long ldy, unsigned flags,
+                  void* stream);
 
 /* Weight gradient dW[Cout][KH][KW][Cin] (+ optional dbias[Cout]) of the convolution above
  * (modes 0 and 1).  dy is NHWC on the output grid with row stride ldd.  Partial tiles go to
  * `workspace` (pd_conv2d_wgrad_workspace bytes) and are summed deterministically; accumulate != 0
  * adds to dw/dbias instead of overwriting.  Replaces autograd's conv weight/bias gradient. */
-size_t pd_conv2d_wgrad_workspace(long M, int Cout, int K);
+size_t pd_conv2d_wgrad_workspace(long M, int Cout, int K, unsigned flags);
 int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* workspace, size_t ws_bytes,
                     int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                     int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode,
-                    int affine, float sub, float div, long ldd, int accumulate, void* stream);
+                    int affine, float sub, float div, long ldd, int accumulate, unsigned flags, void* stream);
 /* 1 when pd_conv2d_wgrad sends this shape (zero or reflection padding; 16-byte aligned NHWC operands assumed) to the kernel that forms the
- * fp32 products on the bf16 matrix cores, every element split once (conv_wgrad_x3c_kernel; PD_WGRAD_X3C=0: fp32 MFMA) --
+ * fp32 products on the bf16 matrix cores, every element split once (conv_wgrad_x3c_kernel; PD_CONV_FP32_MFMA: fp32 MFMA) --
  * the profiler label of a launch and bench.py's roofline object use it. */
-int pd_conv2d_wgrad_uses_x3(long M, int Cout, int C, int KH, int KW, int stride, int pad, int mode, int H, int W, int Ho, int Wo);
+int pd_conv2d_wgrad_uses_x3(long M, int Cout, int C, int KH, int KW, int stride, int pad, int mode, int H, int W, int Ho, int Wo,
+                            unsigned flags);
 
 /* 7x7 / stride-2 / pad-3 stems (pre_encoders.py:54 ShallowEncoder.Conv1, torchvision resnet conv1) executed as a
  * 4x4 / stride-1 / pad-2 convolution over the space-to-depth input [N][H/2][W/2][4C] (4C is a multiple of 4 ->
@@ -288,15 +314,19 @@ int pd_reflect_dgrad_border(const void* dz, long ldd, const void* w, void* dx, i
 /* torch.optim.Adam step (trainer.py:238,442) over one flat fp32 buffer; grads are pre-multiplied
  * by grad_scale (1/world_size after the RCCL sum).  zero_grad != 0 also clears g in the same pass
  * (trainer.py:436 zero_grad of the NEXT iteration, without a separate 85 MB memset).
- * step_state (optional): the step counters below; Adam's t is then read from step_state[1] on the device instead of
- * `step`, so that a hipGraph of the training step can be replayed with frozen arguments.  Bias corrections use beta^t
- * by repeated squaring in double on either side (identical bits). */
+ * step_state (optional): the step words below; Adam's t is then read from step_state[1] and lr / grad_scale from
+ * step_state[2] on the device instead of the `step`, `lr`, `grad_scale` arguments, so that a hipGraph of the training step
+ * can be replayed with frozen arguments and still follow a learning-rate schedule (trainer.py:238-240,467 StepLR).  Bias
+ * corrections use beta^t by repeated squaring in double on either side (identical bits). */
 int pd_adam_step(void* p, void* g, void* m, void* v, long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, long step, const void* step_state, float grad_scale, int zero_grad, void* stream);
-/* Step counters in device memory, int64[4]: [0] training steps begun -- the dropout sites of pd_chain_* add
- * step_state[0] << 12 to their Philox offset (step_state NULL: the offset argument alone) --, [1] optimizer steps.
- * pd_step_tick increments the selected counters (one thread); the only per-step state of a captured training step. */
+/* Step words in device memory, int64[4]: [0] training steps begun -- the dropout sites of pd_chain_* add
+ * step_state[0] << 12 to their Philox offset (step_state NULL: the offset argument alone) --, [1] optimizer steps,
+ * [2] the fp32 bit patterns of lr (low word) and grad_scale (high word).  pd_step_tick increments the selected counters
+ * (one thread); pd_step_set_hyper writes word [2] (call it whenever the scheduler changed lr: it is NOT part of a captured
+ * step).  The only per-step state of a captured training step. */
 int pd_step_tick(void* step_state, int bump_dropout, int bump_adam, void* stream);
+int pd_step_set_hyper(void* step_state, float lr, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------- K5
  * Multi-scale supervised loss (trainer.py:1126-1150,1241-1265,1298-1309; layers.py:62-71,452-465).
@@ -309,7 +339,9 @@ int pd_step_tick(void* step_state, int bump_dropout, int bump_adam, void* stream
 int pd_loss_rows(long n);
 int pd_disp_to_depth(const void* disp, void* depth, void* updisp, int N, int hs, int ws, int H, int W,
                      float min_depth, float max_depth, void* stream);
-int pd_up_gather_bwd(const void* gup, void* gdisp, int N, int hs, int ws, int H, int W, int accumulate, void* stream);
+/* generic != 0: the any-ratio kernel instead of the one specialised for zooms 1 / 2 / 4 / 8 (tests compare the two) */
+int pd_up_gather_bwd(const void* gup, void* gdisp, int N, int hs, int ws, int H, int W, int accumulate, int generic,
+                     void* stream);
 /* gt_normals (optional, NULL = recompute per call): [N,H,W,4] floats written by pd_gt_normals -- the unit normal of the
  * ground-truth depth at every in-range pixel (trainer.py:1298-1309 evaluates it once per scale; it does not depend on
  * the scale, so a step computes it once and its eight consumers read it back). */
@@ -351,12 +383,12 @@ int pd_multiscale_loss_bwd(const void* const* disps, const void* const* colors, 
                            const void* gt, const void* K, const void* gt_normals, const void* wts, const void* sums,
                            void* gup_ws, void* g_ws, void* gd_acc, void* const* gdisps, int N, int H, int W,
                            float min_depth, float max_depth, void* stream);
-/* pd_sup_loss_bwd: ab_ws ([N,H,W,6] floats) is only read by the two-pass form (PD_SUP_BWD_TWO_PASS=1, kept for A/B runs);
+/* pd_sup_loss_bwd: ab_ws ([N,H,W,6] floats) is only read by the two-pass form (two_pass_form != 0, kept for its test);
  * by default one kernel evaluates the per-pixel normal gradients for the halo of an 8 x 64 tile into LDS and gathers
  * from there, so ab_ws may be NULL. */
 int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* gt_normals, const void* wts,
                     const void* sums, void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
-                    int with_normals, int to_disp, void* stream);
+                    int with_normals, int to_disp, int two_pass_form, void* stream);
 /* edge_w (optional, NULL = recompute in the backward pass): [N,h,w,2] floats, the image-only edge weights
  * e^{-|dx I|}, e^{-|dy I|} (layers.py:452-465) written by the forward pass and read by the backward pass. */
 int pd_smooth_fwd(const void* disp, const void* img, void* mean, void* partial, void* edge_w, int N, int h, int w,

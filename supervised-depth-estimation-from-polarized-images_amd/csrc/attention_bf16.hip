@@ -975,8 +975,7 @@ extern "C" int pd_attn_bf16_fwd(const void* q, const void* k, const void* v, voi
         pack_multi(jobs, 2, nblocks, st);
     }
     const dim3 grid((unsigned)((T + 4 * QW - 1) / (4 * QW)), (unsigned)N);
-    static const bool pipe = [] { const char* e = getenv("PD_ATTN_FWD_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
-    if (pipe && T % (4 * KB) == 0 && nblocks / N >= 4)
+    if (T % (4 * KB) == 0 && nblocks / N >= 4)
         hipLaunchKernelGGL(attn_fwd_bf16_pipe_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr,
                            (const char*)vt, (float*)o, (float*)lse, T, scale * kLog2e);
     else
@@ -1031,9 +1030,8 @@ extern "C" int pd_attn_bf16_bwd_parts(const void* q, const void* k, const void* 
     }
     const dim3 grid((unsigned)((T + 4 * QW - 1) / (4 * QW)), (unsigned)N);
     constexpr int kDkvLds = 8 * TILE + 4 * KB * 4, kDkvPipeLds = 16 * TILE + 8 * KB * 4;
-    static const bool pipe_kv = [] { const char* e = getenv("PD_ATTN_BWD_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
     if (!(parts & 2)) {
-    } else if (pipe_kv && T % (4 * KB) == 0 && 2L * N * T * 4 < (1L << 31)) {
+    } else if (T % (4 * KB) == 0 && 2L * N * T * 4 < (1L << 31)) {
         static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bf16_pipe_kernel),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, kDkvPipeLds);
         PD_REQUIRE(lds_ok == hipSuccess, "pd_attn_bf16_bwd: cannot reserve %d bytes of LDS", kDkvPipeLds);
@@ -1048,9 +1046,8 @@ extern "C" int pd_attn_bf16_bwd_parts(const void* q, const void* k, const void* 
                            (const float*)v, (const char*)dr, (const char*)dt, (const float*)lse, (const float*)delta, (float*)dk,
                            (float*)dv, T, scale);
     }
-    static const bool pipe = [] { const char* e = getenv("PD_ATTN_BWD_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
     if (!(parts & 4)) {
-    } else if (pipe && T % (2 * KB) == 0)
+    } else if (T % (2 * KB) == 0)
         hipLaunchKernelGGL(attn_bwd_dq_bf16_pipe_kernel, grid, dim3(ATT_T), 0, st, (const float*)q, (const char*)kr, (const char*)kt,
                            (const char*)vr, (const float*)d_o, (const float*)lse, (const float*)delta, (float*)dq, T, scale);
     else

@@ -60,6 +60,8 @@ struct ConvArgs {
     int sshift;              // log2(stride) (transposed mode: stride is a power of two)
     unsigned w_bytes;
     unsigned mg_hw, sh_hw, mg_wo, sh_wo;   // n / (Ho*Wo) and n / Wo as mulhi + shift (n < 2^31), see magic_div()
+    unsigned flags;          // PD_CONV_* kernel-family selection of the caller (include/polardepth.h)
+    int stats_rows;          // output rows per row of `stats` = pd_conv2d_tile_m(M, Co): the one rule host and kernels share
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -816,14 +818,29 @@ __device__ __forceinline__ Split split8(const float4 a, const float4 b) {
 // split2() on pair P of a value array in three steps -- hi (1 instruction), mid (5), lo (3) -- so that a kernel can
 // thread them between its MFMAs (program order is issue order)
 struct Terms { unsigned h[4], m[4], l[4]; f32x2 tf[4], tr[4]; };
-template <int P> __device__ __forceinline__ void sp_h(const float* x, Terms& t) { t.h[P] = cvt_pk_bf16(x[2 * P], x[2 * P + 1]); }
-template <int P> __device__ __forceinline__ void sp_m(const float* x, Terms& t) {
+// (W marks the split of a weight chunk.  PD_PROBE_NOSPLIT / PD_PROBE_NOSPLIT_W exist for tools/build_probe.sh only: timing
+//  probes -- never defined for libpolardepth.so -- in which the terms are the operand's raw bits, i.e. the instruction mix of
+//  a kernel whose operands arrive pre-split; their results are meaningless.)
+#if defined(PD_PROBE_NOSPLIT)
+#define PD_PROBE_RAW(W) true
+#elif defined(PD_PROBE_NOSPLIT_W)
+#define PD_PROBE_RAW(W) (W)
+#else
+#define PD_PROBE_RAW(W) false
+#endif
+template <int P, bool W = false> __device__ __forceinline__ void sp_h(const float* x, Terms& t) {
+    if constexpr (PD_PROBE_RAW(W)) { t.h[P] = __float_as_uint(x[2 * P]); return; }
+    t.h[P] = cvt_pk_bf16(x[2 * P], x[2 * P + 1]);
+}
+template <int P, bool W = false> __device__ __forceinline__ void sp_m(const float* x, Terms& t) {
+    if constexpr (PD_PROBE_RAW(W)) { t.m[P] = __float_as_uint(x[2 * P + 1]); return; }
     t.tf[P] = f32x2{__uint_as_float(t.h[P] << 16), __uint_as_float(t.h[P] & 0xffff0000u)};
     t.tr[P] = f32x2{x[2 * P], x[2 * P + 1]} - t.tf[P];
     t.m[P] = cvt_pk_bf16(t.tr[P].x, t.tr[P].y);
     t.tf[P].x = __uint_as_float(t.m[P] << 16);
 }
-template <int P> __device__ __forceinline__ void sp_l(Terms& t) {
+template <int P, bool W = false> __device__ __forceinline__ void sp_l(Terms& t) {
+    if constexpr (PD_PROBE_RAW(W)) { t.l[P] = t.h[P]; return; }
     t.tf[P].y = __uint_as_float(t.m[P] & 0xffff0000u);
     const f32x2 r2 = t.tr[P] - t.tf[P];
     t.l[P] = cvt_pk_bf16(r2.x, r2.y);
@@ -1045,11 +1062,11 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
             mm(t0, PD_I(0), PD_I(1)); x3::sp_m<1>(x0, t0); PD_SB
             mm(t0, PD_I(0), PD_I(2)); x3::sp_m<2>(x0, t0); PD_SB
             mm(t0, PD_I(0), PD_I(3)); x3::sp_m<3>(x0, t0); PD_SB
-            mm(t0, PD_I(0), PD_I(4)); x3::sp_h<0>(ws, tw); x3::sp_h<1>(ws, tw); PD_SB
-            mm(t0, PD_I(0), PD_I(5)); x3::sp_m<0>(ws, tw); PD_SB
-            mm(t0, PD_I(0), PD_I(6)); x3::sp_l<0>(t0); x3::sp_l<0>(tw); PD_SB
-            mm(t0, PD_I(0), PD_I(7)); x3::sp_l<1>(t0); x3::sp_m<1>(ws, tw); PD_SB
-            mm(t0, PD_I(0), PD_I(8)); x3::sp_l<2>(t0); x3::sp_l<1>(tw); PD_SB
+            mm(t0, PD_I(0), PD_I(4)); x3::sp_h<0, true>(ws, tw); x3::sp_h<1, true>(ws, tw); PD_SB
+            mm(t0, PD_I(0), PD_I(5)); x3::sp_m<0, true>(ws, tw); PD_SB
+            mm(t0, PD_I(0), PD_I(6)); x3::sp_l<0>(t0); x3::sp_l<0, true>(tw); PD_SB
+            mm(t0, PD_I(0), PD_I(7)); x3::sp_l<1>(t0); x3::sp_m<1, true>(ws, tw); PD_SB
+            mm(t0, PD_I(0), PD_I(8)); x3::sp_l<2>(t0); x3::sp_l<1, true>(tw); PD_SB
             mm(t0, PD_I(0), PD_I(9)); x3::sp_l<3>(t0); PD_SB
             *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
             *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
@@ -1062,20 +1079,20 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         mm(t0, PD_I(0), PD_I(1)); x3::sp_m<1>(x0, t0); PD_SB
         mm(t0, PD_I(0), PD_I(2)); x3::sp_m<2>(x0, t0); PD_SB
         mm(t0, PD_I(0), PD_I(3)); x3::sp_m<3>(x0, t0); PD_SB
-        mm(t0, PD_I(0), PD_I(4)); x3::sp_h<0>(ws, tw); x3::sp_h<1>(ws, tw); PD_SB
-        mm(t0, PD_I(0), PD_I(5)); x3::sp_m<0>(ws, tw); PD_SB
+        mm(t0, PD_I(0), PD_I(4)); x3::sp_h<0, true>(ws, tw); x3::sp_h<1, true>(ws, tw); PD_SB
+        mm(t0, PD_I(0), PD_I(5)); x3::sp_m<0, true>(ws, tw); PD_SB
         mm(t0, PD_I(0), PD_I(6)); x3::sp_l<0>(t0); x3::sp_h<0>(x1, t1); PD_SB
         mm(t0, PD_I(0), PD_I(7)); x3::sp_l<1>(t0); x3::sp_h<1>(x1, t1); PD_SB
         mm(t0, PD_I(0), PD_I(8)); x3::sp_l<2>(t0); x3::sp_h<2>(x1, t1); PD_SB
         mm(t0, PD_I(0), PD_I(9)); x3::sp_l<3>(t0); x3::sp_h<3>(x1, t1); PD_SB
-        mm(t0, PD_I(0), PD_I(10)); x3::sp_m<1>(ws, tw); PD_SB
-        mm(t0, PD_I(0), PD_I(11)); x3::sp_l<0>(tw); PD_SB
+        mm(t0, PD_I(0), PD_I(10)); x3::sp_m<1, true>(ws, tw); PD_SB
+        mm(t0, PD_I(0), PD_I(11)); x3::sp_l<0, true>(tw); PD_SB
         // row block 1
         mm(t1, PD_I(RB - 1), PD_I(0)); x3::sp_m<0>(x1, t1); PD_SB
         mm(t1, PD_I(RB - 1), PD_I(1)); x3::sp_m<1>(x1, t1); PD_SB
         mm(t1, PD_I(RB - 1), PD_I(2)); x3::sp_m<2>(x1, t1); PD_SB
         mm(t1, PD_I(RB - 1), PD_I(3)); x3::sp_m<3>(x1, t1); PD_SB
-        mm(t1, PD_I(RB - 1), PD_I(4)); x3::sp_l<1>(tw); PD_SB
+        mm(t1, PD_I(RB - 1), PD_I(4)); x3::sp_l<1, true>(tw); PD_SB
         mm(t1, PD_I(RB - 1), PD_I(5));
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
@@ -1167,8 +1184,8 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
             }
         }
         if (a.stats) {
-            // one row of `stats` per 128 output pixels (64 when M < 65536, pd_conv2d_tile_m): WPS waves each
-            const int sgr = a.M < 64 * 1024 ? 64 : 128, wps = sgr / RW, nrow = BM / sgr;
+            // one row of `stats` per a.stats_rows output pixels (128, or 64 when M < 65536: pd_conv2d_tile_m): WPS waves each
+            const int sgr = a.stats_rows, wps = sgr / RW, nrow = BM / sgr;
             __syncthreads();
             if (tid < nrow * BN) {
                 const int row_l = tid >> 6, cl = tid & 63;
@@ -1181,17 +1198,15 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     }
 }
 
-static long x3_min_wg() {      // fewest workgroups that take the bf16-split kernel: two per CU (PD_CONV_X3_MIN_WG: tuning aid).
-    // Below that a SIMD holds one wave most of the time and the split is not hidden by another wave's MFMAs: 320
-    // workgroups run at the fp32 kernel's pace (3x3x256 @32x40: 116 vs 114 TF), 640 at 1.3x (5x5 256 -> 512 @32x40: 167 vs 127).
-    const char* e = getenv("PD_CONV_X3_MIN_WG");
-    return e ? atol(e) : 512;
-}
+// Fewest workgroups that take the bf16-split kernel by default: two per CU.  Below that a SIMD holds one wave most of the
+// time and the split is not hidden by another wave's MFMAs: 320 workgroups of 256 rows run at the fp32 kernel's pace
+// (3x3x256 @32x40: 116 vs 114 TF), 640 at 1.3x (5x5 256 -> 512 @32x40: 167 vs 127).  128-row tiles (four workgroups per CU)
+// are worth it from 320 on (3x3x512 @16x20: 117 -> 134 TF).  PD_CONV_BF16X3 in the caller's flags waives both counts.
+constexpr long X3_MIN_WG = 512, X3_MIN_WG1 = 320;
 
 // 0: not for the bf16-split kernel; 2 | 1: its row blocks per wave (256- | 128-row tiles)
 static int x3_eligible(const ConvArgs& a, bool vec) {
-    const char* e = getenv("PD_CONV_X3");          // read per call: the tests compare both kernels in one process
-    const bool on = !(e && e[0] == '0');
+    const bool on = !(a.flags & PD_CONV_FP32_MFMA), force = (a.flags & PD_CONV_BF16X3) != 0;
     // (C % 4 == 0 is part of `vec`; a partly empty last channel group may at most double the contraction: C >= 8)
     if (!(on && vec && (a.C + x3::CK - 1) / x3::CK * x3::CK <= 2 * a.C && a.Co % x3::BN == 0 && a.M % 128 == 0 && a.KH * a.KW <= 31 &&
           a.pad < a.KH && a.pad_w < a.KW &&
@@ -1202,12 +1217,10 @@ static int x3_eligible(const ConvArgs& a, bool vec) {
           (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0)) && (long)a.Co * a.K * 4 < 0x7fffffffL))
         return 0;
     const long ct = a.Co / x3::BN;
-    if (a.M % 256 == 0 && (a.M / 256) * ct >= x3_min_wg()) return 2;
-    // 128-row tiles (four workgroups per CU): worth it from 320 tiles on (3x3x512 @16x20: 117 -> 134 TF); a layer with 320
-    // tiles of 256 rows is better off with its 640 tiles of 128 (64 -> 64 @64x80: 113 vs 102 TF, 3x3x256 @32x40: 161 vs 145)
-    static const bool rb1 = !(getenv("PD_CONV_X3_RB1") && getenv("PD_CONV_X3_RB1")[0] == '0');
-    static const long min_wg1 = getenv("PD_CONV_X3_MIN_WG1") ? atol(getenv("PD_CONV_X3_MIN_WG1")) : 320;
-    return rb1 && (a.M / 128) * ct >= min_wg1 ? 1 : 0;
+    if (a.M % 256 == 0 && (a.M / 256) * ct >= X3_MIN_WG) return 2;
+    // a layer with 320 tiles of 256 rows is better off with its 640 tiles of 128 (64 -> 64 @64x80: 113 vs 102 TF, 3x3x256
+    // @32x40: 161 vs 145)
+    return (force || (a.M / 128) * ct >= X3_MIN_WG1) ? 1 : 0;
 }
 
 static int launch_conv_x3(ConvArgs& a, int rb, hipStream_t st) {
@@ -1235,8 +1248,8 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
 #define PD_LAUNCH(V, MD) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, V, MD>), grid, block, 0, st, a)
 #define PD_LAUNCH_DMA(MD) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, MD, true>), grid, block, 0, st, a)
-    static const bool dma = !(getenv("PD_CONV_DMA") && getenv("PD_CONV_DMA")[0] == '0');   // direct-to-LDS staging (default on)
-    static const bool uni_on = !(getenv("PD_CONV_UNI") && getenv("PD_CONV_UNI")[0] == '0');  // uniform-tap kernel (default on)
+    constexpr bool dma = true;                                    // direct-to-LDS staging (the register-staged path serves the scalar gather)
+    const bool uni_on = !(a.flags & PD_CONV_GENERAL_KERNELS);       // uniform-tap kernel unless the caller asks for the general one
     if constexpr (BN % 32 == 0 && WN == 32) {
         const bool uni = vec && dma && uni_on && a.C % BK == 0 && a.KH * a.KW <= 31 && a.pad < a.KH && a.pad_w < a.KW &&
                          (a.mode == MODE_ZERO || a.mode == MODE_REFLECT || (a.mode == MODE_TRANSPOSED && a.sshift == 0));
@@ -1247,8 +1260,7 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
         if (uni) {
             // ring depth: 2 for the 128-row tiles (3 workgroups per CU); 3 for the 64x64 tile of the small-M layers, whose
             // short chunks (16 MFMAs per wave) leave the loads half the time to land: 118 -> 135 TF on 3x3x256 @32x40
-            static const int ns_env = getenv("PD_CONV_STAGES") ? atoi(getenv("PD_CONV_STAGES")) : 0;
-            const int ns = ns_env ? ns_env : (BM == 64 ? 3 : 2);
+            const int ns = BM == 64 ? 3 : 2;
             if (ns == 2) {
                 if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_ZERO, 2>), grid, block, 0, st, a);
                 else hipLaunchKernelGGL((conv_igemm_uni_kernel<BM, BN, WM, WN, MODE_TRANSPOSED, 2>), grid, block, 0, st, a);
@@ -1281,8 +1293,9 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
 }  // namespace
 
 extern "C" int pd_conv2d_uses_x3(long M, int Co, int C, int KH, int KW, int stride, int pad, int mode, int act,
-                                 int has_out_scale) {
+                                 int has_out_scale, unsigned flags) {
     ConvArgs a{};
+    a.flags = flags;
     a.M = M; a.Co = Co; a.C = C; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = a.pad_w = pad; a.mode = mode; a.act = act;
     a.K = KH * KW * C; a.ldy = Co;
     a.H = a.Ho = a.W = a.Wo = 16;             // (reflection padding: a same-size 3x3 layer is assumed)
@@ -1293,8 +1306,6 @@ extern "C" int pd_conv2d_uses_x3(long M, int Co, int C, int KH, int KW, int stri
 
 extern "C" int pd_conv2d_tile_m(long M, int Co) {
     if (Co <= 32) return 128;   // 128x32 tile: four waves of one 32x32 MFMA tile each
-    static const int forced = getenv("PD_CONV_BM") ? atoi(getenv("PD_CONV_BM")) : 0;   // tuning aid: 64 or 128
-    if (forced == 64 || forced == 128) return forced;
     return M >= 64 * 1024 ? 128 : 64;
 }
 
@@ -1307,40 +1318,43 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
                        const void* addend, long ld_add,
                        int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                        int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
-                       int affine, float sub, float div, long ldy, void* stream, int pad_w = -1);
+                       int affine, float sub, float div, long ldy, unsigned flags, void* stream, int pad_w = -1);
 
 extern "C" int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
                          int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                          int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
-                         int affine, float sub, float div, long ldy, void* stream) {
+                         int affine, float sub, float div, long ldy, unsigned flags, void* stream) {
     return conv2d_impl(x, w, bias, out_scale, y, stats, nullptr, 0, N, H, W, C, sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride,
-                       pad, mode, act, affine, sub, div, ldy, stream);
+                       pad, mode, act, affine, sub, div, ldy, flags, stream);
 }
 
 extern "C" int pd_conv2d_add(const void* x, const void* w, const void* addend, long ld_add, void* y,
                              int N, int H, int W, int C, long sN, long sH, long sW, long sC,
-                             int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, long ldy, void* stream) {
+                             int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, long ldy, unsigned flags,
+                             void* stream) {
     PD_REQUIRE(addend && ld_add >= Co, "pd_conv2d_add: bad addend");
     return conv2d_impl(x, w, nullptr, nullptr, y, nullptr, addend, ld_add, N, H, W, C, sN, sH, sW, sC, Ho, Wo, Co, KH, KW,
-                       stride, pad, mode, ACT_NONE, 0, 0.f, 1.f, ldy, stream);
+                       stride, pad, mode, ACT_NONE, 0, 0.f, 1.f, ldy, flags, stream);
 }
 
 // rows x columns filter with its own column padding: the exact sub-filters (1x1, 1x2, 2x1, 2x2) of a stride-2 data
 // gradient split by output parity (pd_dgrad_s2_filters); stride 1, no bias / activation, uniform-tap kernel only
 extern "C" int pd_conv2d_rect(const void* x, const void* w, void* y, int N, int H, int W, int C, long sN, long sH, long sW,
                               long sC, int Ho, int Wo, int Co, int KH, int KW, int pad_h, int pad_w, int mode, long ldy,
-                              void* stream) {
+                              unsigned flags, void* stream) {
     PD_REQUIRE(pad_w >= 0 && mode != MODE_REFLECT, "pd_conv2d_rect: bad padding / mode");
+    PD_REQUIRE(!(flags & PD_CONV_GENERAL_KERNELS), "pd_conv2d_rect: the general kernel has no separate column padding");
     return conv2d_impl(x, w, nullptr, nullptr, y, nullptr, nullptr, 0, N, H, W, C, sN, sH, sW, sC, Ho, Wo, Co, KH, KW, 1,
-                       pad_h, mode, ACT_NONE, 0, 0.f, 1.f, ldy, stream, pad_w);
+                       pad_h, mode, ACT_NONE, 0, 0.f, 1.f, ldy, flags, stream, pad_w);
 }
 
 static int conv2d_impl(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
                        const void* addend, long ld_add,
                        int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                        int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode, int act,
-                       int affine, float sub, float div, long ldy, void* stream, int pad_w) {
+                       int affine, float sub, float div, long ldy, unsigned flags, void* stream, int pad_w) {
     if (pad_w < 0) pad_w = pad;
+    PD_REQUIRE(pd::conv_flags_ok(flags), "pd_conv2d: bad flags 0x%x", flags);
     PD_REQUIRE(x && w && y, "pd_conv2d: null tensor");
     PD_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && Co > 0, "pd_conv2d: bad dims");
     PD_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "pd_conv2d: bad filter geometry");
@@ -1368,6 +1382,7 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
     a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.pad_w = pad_w;
     a.mode = mode; a.act = act; a.affine = affine; a.sub = sub; a.div = div;
     a.K = KH * KW * C; a.M = (long)N * Ho * Wo; a.ldy = ldy; a.sshift = sshift;
+    a.flags = flags; a.stats_rows = pd_conv2d_tile_m(a.M, Co);
     auto magic = [](long d, unsigned& mg, unsigned& sh) {       // n / d == mulhi(n, mg) >> sh for 0 <= n < 2^31, d >= 2
         if (d <= 1 || d >= (1L << 31)) { mg = 0; sh = 0; return; }
         int l = 0;
@@ -1390,8 +1405,7 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
     // 96 output columns (the data gradient of the decoder's 96 -> 32 layer): three 32-wide column tiles instead of a full and a
     // half-empty 64-wide one (a quarter of the matrix work of that launch was padding)
     if (const int rb = x3_eligible(a, vec)) return launch_conv_x3(a, rb, st);
-    static const bool n96 = [] { const char* e = getenv("PD_CONV_N96"); return !(e && e[0] == '0'); }();
-    if (Co == 96 && n96 && bm == 128) return launch_conv<128, 32, 32, 32>(a, vec, st);
+    if (Co == 96 && bm == 128) return launch_conv<128, 32, 32, 32>(a, vec, st);
     if (Co > 32) return bm == 128 ? launch_conv<128, 64, 64, 32>(a, vec, st) : launch_conv<64, 64, 32, 32>(a, vec, st);
     if (Co > 16) return launch_conv<128, 32, 32, 32>(a, vec, st);
     return launch_conv<128, 16, 32, 16>(a, vec, st);   // 16x16x4 MFMA tiles
@@ -2120,6 +2134,10 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
         }
         constexpr int STEP = J < 3 ? 2 : WG_MC - 6;
         s_p += STEP; s_ow += STEP; s_soff += STEP * st_w4;
+#ifdef PD_PROBE_NOWALK      // tools/build_probe.sh only: the cost of the row / image wrap bookkeeping (results meaningless)
+        s_soff = s_soff >= (a.N - img0 - 1) * sn4 ? 0 : s_soff;      // (stay inside the tensor: the scalar offset is not range-checked)
+        return;
+#endif
 #pragma unroll
         for (int w = 0; w < (J < 3 ? 1 : 2); ++w) {
             const int ow0 = s_ow;
@@ -2384,12 +2402,10 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const flo
 
 inline int wgrad_tco(int Co) { return Co > 32 ? 64 : (Co > 16 ? 32 : 16); }
 
-bool wgrad_x3c_enabled() {                    // read per call (PD_WGRAD_X3C=0: weight gradients on the fp32 MFMA)
-    const char* e = getenv("PD_WGRAD_X3C");
-    return !(e && e[0] == '0');
-}
+// bf16-split weight gradient (conv_wgrad_x3c_kernel) unless the caller asks for the fp32 MFMA or for the in-register split
+inline bool wgrad_x3c_enabled(unsigned flags) { return !(flags & (PD_CONV_FP32_MFMA | PD_CONV_WGRAD_SPLIT_IN_REGS)); }
 
-void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
+void wgrad_plan(long M, int Co, int K, unsigned flags, int* S, long* mper) {
     const int tco = wgrad_tco(Co);
     const long tiles = (long)((Co + tco - 1) / tco) * ((K + WG_K - 1) / WG_K);
     // <= two full rounds of the 768 resident workgroups (floor: no ragged tail) when a slice count of one round would
@@ -2400,9 +2416,8 @@ void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
     // the tiles are few (3x3x128 @64x80: 144 -> 162 TF, 3x3x256 @32x40: 150 -> 163, 3x3x64 @128x160: 132 -> 137 against the
     // 768-workgroup plan), two for the million-pixel layers (5x5x64 @256x320: 153 -> 159), three when one round would leave
     // fewer than four slices per tile (3x3x512 @16x20, 288 tiles: 134 TF with 1536 workgroups, 92 with 512).
-    static const long forced = getenv("PD_WGRAD_WGS") ? atol(getenv("PD_WGRAD_WGS")) : 0;
-    const bool x3c = tco == 64 && wgrad_x3c_enabled();
-    const long total = forced ? forced : x3c ? (512 / tiles < 4 ? 1536 : M >= (1L << 20) ? 1024 : 512) : (tiles <= 32 ? 768 : 1536);
+    const bool x3c = tco == 64 && wgrad_x3c_enabled(flags) && !(flags & PD_CONV_GENERAL_KERNELS);
+    const long total = x3c ? (512 / tiles < 4 ? 1536 : M >= (1L << 20) ? 1024 : 512) : (tiles <= 32 ? 768 : 1536);
     long s = total / tiles;
     const long smax = (M + 511) / 512;
     if (s > smax) s = smax;
@@ -2416,37 +2431,35 @@ void wgrad_plan(long M, int Co, int K, int* S, long* mper) {
 
 }  // namespace
 
-extern "C" size_t pd_conv2d_wgrad_workspace(long M, int Co, int K) {
+extern "C" size_t pd_conv2d_wgrad_workspace(long M, int Co, int K, unsigned flags) {
     int S; long mper;
-    wgrad_plan(M, Co, K, &S, &mper);
+    wgrad_plan(M, Co, K, flags, &S, &mper);
     return ((size_t)S * Co * K + (size_t)S * Co) * sizeof(float);
 }
 
-static bool wgrad_x3_on() {                   // read per call: the tests compare both kernels in one process
-    const char* e = getenv("PD_WGRAD_X3");      // default off: 216 vector instructions per 24 MFMAs -- measured 8 % slower
-    return e && e[0] == '1';
-}
-
-static bool wgrad_x3c_on() { return wgrad_x3c_enabled(); }
+// conv_wgrad_uni_kernel's X3 branch (both operands split in registers by every wave that needs them): 216 vector
+// instructions per 24 MFMAs, measured 8 % slower than the fp32 kernel -- kept for its test, reached by flag only
+static bool wgrad_x3_on(unsigned flags) { return (flags & PD_CONV_WGRAD_SPLIT_IN_REGS) && !(flags & PD_CONV_FP32_MFMA); }
 
 // 1 when pd_conv2d_wgrad sends this zero-padded shape (16-byte aligned NHWC operands assumed) to conv_wgrad_x3c_kernel
 extern "C" int pd_conv2d_wgrad_uses_x3(long M, int Co, int C, int KH, int KW, int stride, int pad, int mode, int H, int W, int Ho,
-                                       int Wo) {
+                                       int Wo, unsigned flags) {
     const bool refl_ok = mode == MODE_REFLECT && pad == 1 && KH == 3 && KW == 3 && stride == 1 && Ho == H && Wo == W && H >= 3;
     if (!(mode == MODE_ZERO || refl_ok)) return 0;
-    static const bool uni_on = !(getenv("PD_WGRAD_UNI") && getenv("PD_WGRAD_UNI")[0] == '0');
+    const bool uni_on = !(flags & PD_CONV_GENERAL_KERNELS);
     int S = 0; long mper = 0;
-    wgrad_plan(M, Co, KH * KW * C, &S, &mper);
+    wgrad_plan(M, Co, KH * KW * C, flags, &S, &mper);
     const int nb = (pad + stride - 1) / stride, nbw = (nb + 1) / 2;
-    return uni_on && wgrad_x3c_on() && wgrad_tco(Co) == 64 && C % 4 == 0 && Co % 4 == 0 && Wo % 2 == 0 && Ho >= 2 * nb &&
+    return uni_on && wgrad_x3c_enabled(flags) && wgrad_tco(Co) == 64 && C % 4 == 0 && Co % 4 == 0 && Wo % 2 == 0 && Ho >= 2 * nb &&
            Wo >= 4 * nbw && Wo >= 14 && (2 * nb + 1) * (2 * nbw + 1) <= 31 && mper % WG_MC == 0 && M % 4 == 0 && KH * KW * C >= 4;
 }
 
 extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* workspace, size_t ws_bytes,
                                int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                                int Ho, int Wo, int Co, int KH, int KW, int stride, int pad, int mode,
-                               int affine, float sub, float div, long ldd, int accumulate, void* stream) {
+                               int affine, float sub, float div, long ldd, int accumulate, unsigned flags, void* stream) {
     PD_REQUIRE(x && dy && dw && workspace, "pd_conv2d_wgrad: null tensor");
+    PD_REQUIRE(pd::conv_flags_ok(flags), "pd_conv2d_wgrad: bad flags 0x%x", flags);
     PD_REQUIRE(mode == MODE_ZERO || mode == MODE_REFLECT, "pd_conv2d_wgrad: mode must be 0 or 1");
     PD_REQUIRE(Ho <= (H + 2 * pad - KH) / stride + 1 && Wo <= (W + 2 * pad - KW) / stride + 1,
                "pd_conv2d_wgrad: output grid does not match input/filter geometry");
@@ -2458,8 +2471,8 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.mode = mode;
     a.affine = affine; a.sub = sub; a.div = div;
     a.K = KH * KW * C; a.M = (long)N * Ho * Wo; a.ldd = ldd;
-    wgrad_plan(a.M, Co, a.K, &a.S, &a.mper);
-    const size_t need = pd_conv2d_wgrad_workspace(a.M, Co, a.K);
+    wgrad_plan(a.M, Co, a.K, flags, &a.S, &a.mper);
+    const size_t need = pd_conv2d_wgrad_workspace(a.M, Co, a.K, flags);
     PD_REQUIRE(ws_bytes >= need, "pd_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
     a.part = (float*)workspace;
     a.bpart = dbias ? a.part + (size_t)a.S * Co * a.K : nullptr;
@@ -2475,7 +2488,7 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
 #define PD_WG(T, V, MD) hipLaunchKernelGGL((conv_wgrad_kernel<T, V, MD>), grid, block, 0, st, a)
     // scalar-pixel variant: 16-byte path, zero padding, 64-wide co tile, even output rows (pixel pairs stay inside a
     // row), border classes that fit the 31-bit mask
-    static const bool uni_on = !(getenv("PD_WGRAD_UNI") && getenv("PD_WGRAD_UNI")[0] == '0');
+    const bool uni_on = !(flags & PD_CONV_GENERAL_KERNELS);
     const int nb = (pad + stride - 1) / stride, nbw = (nb + 1) / 2;
     const bool refl_ok = mode == MODE_REFLECT && pad == 1 && KH == 3 && KW == 3 && stride == 1 && Ho == H && Wo == W && H >= 3;
     if (uni_on && (tco == 64 || tco == 32) && vec && (mode == MODE_ZERO || refl_ok) && Co % 4 == 0 && Wo % 2 == 0 && ldd % 4 == 0 &&
@@ -2485,7 +2498,7 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
         if (tco == 32) {              // 17..32 output channels (decoder 96->32, 64->32): reflect + bias in this network
             if (mode == MODE_ZERO) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 32>), grid, block, 0, st, ua);
             else hipLaunchKernelGGL((conv_wgrad_uni_kernel<true, true, 32>), grid, block, 0, st, ua);
-        } else if (wgrad_x3c_on()) {   // bf16-split products, every element split once (zero or reflection padding)
+        } else if (wgrad_x3c_enabled(flags)) {   // bf16-split products, every element split once (zero or reflection padding)
             static const hipError_t lds_ok = [] {
                 hipError_t e = hipSuccess;
                 for (const void* f : {reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<true, true>), reinterpret_cast<const void*>(conv_wgrad_x3c_kernel<false, true>),
@@ -2500,10 +2513,8 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
             PD_REQUIRE(lds_ok == hipSuccess, "pd_conv2d_wgrad: cannot reserve %u bytes of LDS", x3c::LDS_BYTES);
             // The lean walker pays on the small planes (3x3x256 @32x40: 133 -> 145 TF, 5x5 128 -> 256 @64x80: 159 -> 171) and
             // loses on the large ones (5x5x64 @256x320: 148 -> 134; its four loads leave back to back instead of ~40 scalar
-            // instructions apart): planes of up to 8192 pixels take it.  PD_X3C_ROW8 = 0 never, 2 whenever the shape allows.
-            static const int row8_mode = getenv("PD_X3C_ROW8") ? atoi(getenv("PD_X3C_ROW8")) : 1;
-            const bool row8 = row8_mode != 0 && Wo % 8 == 0 && a.mper % 8 == 0 && a.M % 8 == 0 &&
-                              (row8_mode == 2 || (long)Ho * Wo <= 8192);
+            // instructions apart): planes of up to 8192 pixels take it.
+            const bool row8 = Wo % 8 == 0 && a.mper % 8 == 0 && a.M % 8 == 0 && (long)Ho * Wo <= 8192;
             if (mode == MODE_REFLECT) {
                 if (dbias) hipLaunchKernelGGL((conv_wgrad_x3c_kernel<true, false, true>), grid, block, x3c::LDS_BYTES, st, ua);
                 else hipLaunchKernelGGL((conv_wgrad_x3c_kernel<false, false, true>), grid, block, x3c::LDS_BYTES, st, ua);
@@ -2514,7 +2525,7 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
                 if (dbias) hipLaunchKernelGGL((conv_wgrad_x3c_kernel<true, false>), grid, block, x3c::LDS_BYTES, st, ua);
                 else hipLaunchKernelGGL((conv_wgrad_x3c_kernel<false, false>), grid, block, x3c::LDS_BYTES, st, ua);
             }
-        } else if (wgrad_x3_on()) {     // products on the bf16 matrix cores (three-way split, fp32 accuracy)
+        } else if (wgrad_x3_on(flags)) {     // products on the bf16 matrix cores (three-way split, fp32 accuracy)
             if (mode == MODE_ZERO) {
                 if (dbias) hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, true, 64, true>), grid, block, 0, st, ua);
                 else hipLaunchKernelGGL((conv_wgrad_uni_kernel<false, false, 64, true>), grid, block, 0, st, ua);

@@ -776,10 +776,14 @@ __host__ __device__ inline double ipow(double b, long t) {
     return r;
 }
 
-// step_state = int64[4] in device memory: [0] training steps begun (dropout epoch), [1] optimizer steps (Adam's t)
+// step_state = int64[4] in device memory: [0] training steps begun (dropout epoch), [1] optimizer steps (Adam's t),
+// [2] the fp32 bit patterns of lr (low word) and grad_scale (high word) for a captured optimizer step
 __global__ void step_tick_kernel(long long* __restrict__ st, int bump_dropout, int bump_adam) {
     if (bump_dropout) st[0] += 1;
     if (bump_adam) st[1] += 1;
+}
+__global__ void step_set_hyper_kernel(long long* __restrict__ st, float lr, float grad_scale) {
+    st[2] = (long long)(((unsigned long long)__float_as_uint(grad_scale) << 32) | (unsigned long long)__float_as_uint(lr));
 }
 
 template <bool ZERO_G>
@@ -788,7 +792,11 @@ __global__ __launch_bounds__(EW_T) void adam_kernel(float* __restrict__ p, float
                                                     float beta1, float beta2, float eps, float wd, float bc1,
                                                     float bc2_sqrt, float grad_scale,
                                                     const long long* __restrict__ step_state) {
-    if (step_state) {       // step count in device memory (captured step): the bias corrections of pd_adam_step's host branch
+    if (step_state) {       // step count, lr and grad_scale in device memory (captured step): nothing of a replayed
+        // optimizer step is frozen at capture time -- the bias corrections are those of pd_adam_step's host branch
+        const unsigned long long hy = (unsigned long long)step_state[2];
+        lr = __uint_as_float((unsigned)hy);
+        grad_scale = __uint_as_float((unsigned)(hy >> 32));
         const long t = (long)step_state[1];
         bc1 = (float)(1.0 - ipow((double)beta1, t));
         bc2_sqrt = sqrtf((float)(1.0 - ipow((double)beta2, t)));
@@ -890,7 +898,7 @@ static int chain_check(int N, int H, int W, int C, int pool) {
 extern "C" long pd_chain_bwd_rows(int N, int H, int W, int C) {
     const long items = (long)N * H * W * (C / 4);
     long b = (items + EW_T - 1) / EW_T;
-    static const long cap = getenv("PD_CHAIN_ROWS") ? atol(getenv("PD_CHAIN_ROWS")) : 1024;
+    constexpr long cap = 1024;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     return b;
@@ -1062,6 +1070,12 @@ extern "C" int pd_step_tick(void* step_state, int bump_dropout, int bump_adam, v
     PD_REQUIRE(step_state, "pd_step_tick: null state");
     hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)step_state, bump_dropout, bump_adam);
     return pd::check_launch("pd_step_tick");
+}
+
+extern "C" int pd_step_set_hyper(void* step_state, float lr, float grad_scale, void* stream) {
+    PD_REQUIRE(step_state, "pd_step_set_hyper: null state");
+    hipLaunchKernelGGL(step_set_hyper_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)step_state, lr, grad_scale);
+    return pd::check_launch("pd_step_set_hyper");
 }
 
 extern "C" int pd_adam_step(void* p, void* g, void* m, void* v, long n, float lr, float beta1, float beta2,

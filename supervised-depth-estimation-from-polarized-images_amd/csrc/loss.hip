@@ -915,12 +915,11 @@ extern "C" int pd_disp_to_depth(const void* disp, void* depth, void* updisp, int
 }
 
 extern "C" int pd_up_gather_bwd(const void* gup, void* gdisp, int N, int hs, int ws, int H, int W, int accumulate,
-                                void* stream) {
+                                int generic, void* stream) {
     PD_REQUIRE(gup && gdisp && N >= 0 && hs > 0 && ws > 0, "pd_up_gather_bwd: bad arguments");
     PD_REQUIRE(H % hs == 0 && W % ws == 0, "pd_up_gather_bwd: full size must be an integer multiple of the scale size");
     if (N == 0) return PD_OK;
-    const char* gen = getenv("PD_UP_GATHER_GENERIC");                 // A/B and test switch: the generic kernel
-    const int f = (gen && gen[0] == '1') ? 0 : H / hs;
+    const int f = generic ? 0 : H / hs;                                // generic != 0: the any-ratio kernel (tests compare the two)
     const unsigned grid = lgrid((long)N * hs * ws);
 #define PD_UPG(F) hipLaunchKernelGGL(up_gather_bwd_f_kernel<F>, dim3(grid), dim3(LT), 0, (hipStream_t)stream, \
                                      (const float*)gup, (float*)gdisp, N, hs, ws, H, W, accumulate)
@@ -992,14 +991,13 @@ extern "C" int pd_normals_pred_loss_bwd(const void* pred, long ld, const void* g
 
 extern "C" int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* gt_normals, const void* wts,
                                const void* sums, void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
-                               int with_normals, int to_disp, void* stream) {
+                               int with_normals, int to_disp, int two_pass_form, void* stream) {
     PD_REQUIRE(pred && gt && wts && sums && gout && N > 0 && H > 0 && W > 0 && pd::aligned16(gt_normals),
                "pd_sup_loss_bwd: bad arguments");
     PD_REQUIRE(!with_normals || K, "pd_sup_loss_bwd: the normals term needs K");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = lgrid((long)N * H * W);
-    const char* tp = getenv("PD_SUP_BWD_TWO_PASS");                    // A/B and test switch: the two-pass form
-    const bool two_pass = tp && tp[0] == '1';
+    const bool two_pass = two_pass_form != 0;                          // the form with the [N,H,W,6] intermediate (tests compare the two)
     if (with_normals && !two_pass) {
         const int tiles_h = (H + SB_TR - 1) / SB_TR, tiles_w = (W + SB_TW - 1) / SB_TW;
         const long ntiles = (long)N * tiles_h * tiles_w;

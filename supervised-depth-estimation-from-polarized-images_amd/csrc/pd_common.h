@@ -14,6 +14,10 @@ inline int check_launch(const char* what) {
     return PD_OK;
 }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// PD_CONV_* flags of the convolution entry points: known bits only, and not both arithmetic requests at once
+inline bool conv_flags_ok(unsigned f) {
+    return (f & ~PD_CONV_FLAGS_ALL) == 0 && (f & (PD_CONV_FP32_MFMA | PD_CONV_BF16X3)) != (PD_CONV_FP32_MFMA | PD_CONV_BF16X3);
+}
 }  // namespace pd
 
 #define PD_REQUIRE(cond, ...) \

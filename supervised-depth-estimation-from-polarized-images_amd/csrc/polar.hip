@@ -898,20 +898,9 @@ int set_lds_limit(K kernel, size_t lds) {
     return PD_OK;
 }
 
-// workgroup size of the fast-normals kernel: 1024 = 4 waves per SIMD on one workgroup per CU (tuning knob:
-// PD_POLAR_THREADS = 256 | 512 | 1024)
-int fast_threads() {
-    static const int v = [] {
-        const char* e = getenv("PD_POLAR_THREADS");
-        const int t = e ? atoi(e) : 0;
-        return (t == 256 || t == 512 || t == 1024) ? t : 1024;
-    }();
-    return v;
-}
-bool plain_stores() {
-    static const bool v = [] { const char* e = getenv("PD_POLAR_PLAIN_STORES"); return e && e[0] == '1'; }();
-    return v;
-}
+// workgroup size of the fast-normals kernel: 1024 = 4 waves per SIMD on one workgroup per CU (256 and 512 were measured
+// and dropped: profiles/r02_*, r03_polar_kernel_gbps.log)
+constexpr int fast_threads() { return 1024; }
 
 }  // namespace
 
@@ -990,9 +979,8 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
     const bool pitched = Wout != W;
     const bool need_normals = normals != nullptr || ints != nullptr;
     const bool precise = (flags & PD_POLAR_PRECISE_NORMALS) != 0;
-    const bool nt = !plain_stores();
-    static const bool lut4 = [] { const char* e = getenv("PD_POLAR_LUT4"); return e && e[0] == '1'; }();   // A/B knob: the 4 MB LUT
-    const int nth = need_normals ? (precise ? kThreadsP : (nt ? fast_threads() : 512)) : kThreads;
+    // (every instantiation stores nontemporally: plain stores are -20 % on this access shape, r02_membench2_*)
+    const int nth = need_normals ? (precise ? kThreadsP : fast_threads()) : kThreads;
     // LDS image: 64 KB of bucket records + the keys + 16 (fast) or 32 (precise) bytes per bin, + 1 KiB per wave for the
     // LUT prefetch sink
     const size_t lds = need_normals ? img_bytes_for(nk, precise) + (size_t)(nth / 64) * 1024 : 0;
@@ -1031,26 +1019,20 @@ extern "C" int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void*
             return PD_OK;
         };
         if (mode == PD_POLAR_LS) {
-            if (!need_normals) rc = nt ? go(polar_kernel<PD_POLAR_LS, OUT_XOLP, kThreads, true>) : go(polar_kernel<PD_POLAR_LS, OUT_XOLP, kThreads, false>);
+            if (!need_normals) rc = go(polar_kernel<PD_POLAR_LS, OUT_XOLP, kThreads, true>);
             else if (precise) rc = go(polar_kernel<PD_POLAR_LS, OUT_PRECISE, kThreadsP, true>);
-            else if (!nt) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, false>);
-            else if (nth == 256) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 256, true>);
-            else if (nth == 512) rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 512, true>);
             else if (xolp && normals && !xolp_std && !ints) {
                 // the training step's output set; nontemporal plane loads for launches of up to 32 frames' worth of 512x640
                 // output (see load_words)
-                static const int ntl_env = [] { const char* e = getenv("PD_POLAR_NT_LOADS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-                const bool ntl = ntl_env >= 0 ? ntl_env != 0 : total * 4 <= 32L * 512 * 640;
-                rc = lut4 ? go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, true, true>)
-                          : ntl ? go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, false, true>)
-                                : go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, false, false>);
+                // (PD_POLAR_NT_LOADS / PD_POLAR_PLAIN_LOADS in `flags` override the size rule: measurement)
+                const bool ntl = (flags & PD_POLAR_NT_LOADS) ? true : (flags & PD_POLAR_PLAIN_LOADS) ? false : total * 4 <= 32L * 512 * 640;
+                rc = ntl ? go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, false, true>)
+                         : go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true, true, false, false>);
             }
             else rc = go(polar_kernel<PD_POLAR_LS, OUT_FAST, 1024, true>);
         } else {
             if (!need_normals) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_XOLP, kThreads, true>);
             else if (precise) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_PRECISE, kThreadsP, true>);
-            else if (nth == 256) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_FAST, 256, true>);
-            else if (nth == 512) rc = go(polar_kernel<PD_POLAR_STOKES, OUT_FAST, 512, true>);
             else rc = go(polar_kernel<PD_POLAR_STOKES, OUT_FAST, 1024, true>);
         }
     }

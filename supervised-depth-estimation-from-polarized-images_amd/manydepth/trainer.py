@@ -242,7 +242,7 @@ class Trainer:
             if batch_idx < skip:
                 continue
             before_op_time = time.time()
-            if self.step_graph and not self.distributed:
+            if self.step_graph:
                 # PD_STEP_GRAPH=1: the whole step (zero_grad .. Adam) replayed from a hipGraph captured on the first batch
                 # (polardepth/graph.py; same bits as the eager step, ~2 ms of host time instead of 13-35)
                 dev_inputs = {k: v.to(self.device, non_blocking=True) for k, v in inputs.items()}

@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libpolardepth.so")
+# PD_LIB: another build of the same ABI (the timing-probe libraries of tools/build_probe.sh); read once, at import
+_SO = os.environ.get("PD_LIB") or os.path.join(_HERE, "libpolardepth.so")
 
 
 class LibraryMissing(RuntimeError):
@@ -20,6 +21,7 @@ _dp = _c.POINTER(_c.c_double)
 _l, _f = _c.c_long, _c.c_float
 _u64 = _c.c_uint64
 _ip = _c.POINTER(_c.c_int)
+_u = _c.c_uint
 _vpp = _c.POINTER(_c.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/polardepth.h one to one
@@ -34,20 +36,20 @@ SIGNATURES = {
     "pd_polar_theta": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _l, _vp]),
     "pd_conv2d_tile_m": (_i, [_l, _i]),
     "pd_conv2d_stats_rows": (_l, [_l, _i]),
-    "pd_conv2d_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "pd_conv2d_wgrad_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "pd_conv2d_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u]),
+    "pd_conv2d_wgrad_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u]),
     "pd_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                       _i, _f, _f, _l, _vp]),
+                       _i, _f, _f, _l, _u, _vp]),
     "pd_conv16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _i, _i, _i, _l, _i, _i, _vp]),
     "pd_conv16_wgrad_workspace": (_sz, [_i]),
     "pd_conv16_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _l, _l, _l, _l, _i, _vp]),
     "pd_dgrad_s2_filters": (_i, [_vp, _vp, _i, _i, _vp]),
-    "pd_conv2d_rect": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _l, _vp]),
+    "pd_conv2d_rect": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _l, _u, _vp]),
     "pd_interleave4": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "pd_conv2d_add": (_i, [_vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _l, _vp]),
-    "pd_conv2d_wgrad_workspace": (_sz, [_l, _i, _i]),
+    "pd_conv2d_add": (_i, [_vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _l, _u, _vp]),
+    "pd_conv2d_wgrad_workspace": (_sz, [_l, _i, _i, _u]),
     "pd_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i,
-                             _i, _i, _f, _f, _l, _i, _vp]),
+                             _i, _i, _f, _f, _l, _i, _u, _vp]),
     "pd_weight_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pd_weight_transpose_batched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "pd_stem_s2d_input": (_i, [_vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _f, _f, _vp]),
@@ -73,9 +75,10 @@ SIGNATURES = {
     "pd_reflect_dgrad_border": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pd_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _vp, _f, _i, _vp]),
     "pd_step_tick": (_i, [_vp, _i, _i, _vp]),
+    "pd_step_set_hyper": (_i, [_vp, _f, _f, _vp]),
     "pd_loss_rows": (_i, [_l]),
     "pd_disp_to_depth": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
-    "pd_up_gather_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "pd_up_gather_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pd_gt_normals": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "pd_sup_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "pd_normals_loss_masked": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -85,7 +88,7 @@ SIGNATURES = {
                                     _i, _vp]),
     "pd_multiscale_loss_bwd": (_i, [_vpp, _vpp, _vpp, _vpp, _vpp, _ip, _ip, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vpp,
                                     _i, _i, _i, _f, _f, _vp]),
-    "pd_sup_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp]),
+    "pd_sup_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _i, _vp]),
     "pd_smooth_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pd_smooth_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_loss_finalize": (_i, [_vp, _ip, _vp, _ip, _ip, _ip, _i, _i, _f, _f, _vp, _vp, _vp]),

@@ -141,19 +141,38 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(store.flat)
         self.step_count = 0
         self.grad_scale = 1.0
-        self.device_step = False     # graph mode: Adam's t lives in device memory (functional.DropoutState.state()[1])
+        self.device_step = False     # graph mode: t, lr and grad_scale live in THIS optimizer's device words (dev_state)
+        self.dev_state = None        # int64[4]: [1] Adam's t, [2] lr | grad_scale << 32 (fp32 bit patterns); pd_step_set_hyper
+        self._dev_hyper = None       # (lr, grad_scale) last written to dev_state[2]
 
     def use_device_step(self, on=True):
-        """Keep Adam's step count in device memory (incremented by pd_step_tick in front of the update) so that step() has
-        no per-step kernel argument and can be replayed from a hipGraph.  Same bits as the host-side count."""
-        from . import functional as PF
+        """Keep Adam's step count, learning rate and gradient scale in device memory so that step() has no per-step kernel
+        argument and can be replayed from a hipGraph: t is incremented by pd_step_tick in front of the update, lr and
+        grad_scale are rewritten by sync_hyper() whenever the scheduler (trainer.py:467 StepLR) or the reducer changed
+        them.  Same bits as the host-side arguments.  The words belong to this optimizer (a second optimizer or trainer on
+        the same device has its own); only the dropout stream's step counter is per device (functional.DropoutState)."""
         self.device_step = bool(on)
         if on:
-            PF.DropoutState.state(self.store.flat.device)[1] = self.step_count
+            if self.dev_state is None:
+                self.dev_state = torch.zeros(4, dtype=torch.int64, device=self.store.flat.device)
+            self.dev_state[1] = self.step_count
+            self._dev_hyper = None
+            self.sync_hyper()
+
+    def sync_hyper(self):
+        """Write lr / grad_scale to the device words if they changed since the last write (one tiny launch, outside any
+        capture: GraphedTrainStep.step calls it in front of every replay)."""
+        if not self.device_step:
+            return
+        cur = (float(self.param_groups[0]["lr"]), float(self.grad_scale))
+        if cur != self._dev_hyper:
+            check(lib.pd_step_set_hyper(ptr(self.dev_state), cur[0], cur[1], stream_ptr()), "pd_step_set_hyper")
+            self._dev_hyper = cur
 
     def zero_grad(self, set_to_none=False):
         from . import functional as PF
         PF.sync_wgrad_stream()
+        PF.reset_backward_state()
         self.store.zero_grad()
         if self.store.flat.is_cuda:
             PF.DropoutState.begin_step(self.store.flat.device)       # a training step begins: fresh dropout masks
@@ -172,7 +191,9 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = g["betas"]
         state = None
         if self.device_step:
-            state = PF.DropoutState.state(self.store.flat.device)
+            state = self.dev_state
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_hyper()              # (a capture must not bake the write in: it would pin lr to today's value)
             check(lib.pd_step_tick(ptr(state), 0, 1, stream_ptr()), "pd_step_tick")
         check(lib.pd_adam_step(ptr(self.store.flat), ptr(self.store.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n,
                                float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
@@ -280,6 +301,10 @@ class GradReducer:
         self.comm_stream = torch.cuda.Stream(device=store.grad.device) if self.cuda and self.active else None
         self._events = {}            # (bucket, stream id) -> reusable event: the stream's position behind the bucket's last kernel
         self._t0 = self._t1 = None   # events around finish(): the part of the exchange the step actually waits for
+        # deferred: the backward pass runs inside a hipGraph replay (polardepth/graph.py, segmented mode) -- no Python runs
+        # while the gradients are produced, so nothing is launched from mark_ready(); exchange_now() reduces every bucket
+        # behind the replay, with the same per-bucket calls (hence the same bits) as the overlapped path
+        self.deferred = False
         self.reset()
 
     def reset(self):
@@ -306,7 +331,7 @@ class GradReducer:
         producer stream, an event behind that kernel; the bucket's all-reduce waits for exactly these events -- not for
         whole streams: an encoder stream that is still busy with layers of another bucket does not hold back a decoder
         bucket whose kernels have finished."""
-        if not self.active or id(p) in self.seen:
+        if not self.active or self.deferred or id(p) in self.seen:
             return
         self.seen.add(id(p))
         b = self.bucket_of[id(p)]
@@ -344,12 +369,25 @@ class GradReducer:
         else:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish(self):
+    def exchange_now(self):
+        """All buckets, now: the current stream holds every gradient (a graph replay of forward + backward has been
+        enqueued on it); the all-reduces run on the comm stream behind it, the current stream waits for them."""
         if not self.active:
+            return
+        self.reset()
+        was, self.deferred = self.deferred, False
+        try:
+            self.finish()                        # every bucket has pending > 0: _launch waits for the current stream
+        finally:
+            self.deferred = was
+
+    def finish(self):
+        if not self.active or self.deferred:
             return
         for b in range(len(self.buckets)):       # buckets holding a parameter that got no gradient this step
             self._launch(b)
-        if self.comm_stream is not None:
+        timed = self.comm_stream is not None and not torch.cuda.is_current_stream_capturing()
+        if timed:
             if self._t0 is None:
                 self._t0, self._t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self._t0.record()
@@ -357,6 +395,7 @@ class GradReducer:
             w.wait()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if timed:
             self._t1.record()
         self.works = []
 

@@ -23,7 +23,8 @@ class DropoutState:
     the dropout call sites since the step began (host side, a kernel argument) and ``step`` counts the training steps in
     DEVICE memory (``state(device)[0]``, incremented by pd_step_tick when the optimizer's zero_grad opens a step).  Nothing
     per-step is a kernel argument, so a captured hipGraph of the step draws fresh masks on every replay; the eager path
-    uses the same scheme and therefore the same masks.  state(device)[1] is Adam's step count (FusedAdam, graph mode)."""
+    uses the same scheme and therefore the same masks.  (Adam's device-side words are the optimizer's own:
+    engine.FusedAdam.dev_state.)"""
     seed = 0x5EEDC0DE
     site = 0
     _state = {}
@@ -246,6 +247,20 @@ def _check_deposits_after_backward():
         raise RuntimeError("ActGrad: a convolution handed its input gradient to the disparity head of the same tensor, but "
                            "that head did not run in this backward pass (loss over a subset of the decoder's scales on a "
                            "hand-built graph?); the gradients upstream of it are missing.  Set PD_ACT_FUSION=0.")
+
+
+def reset_backward_state():
+    """A training step begins (FusedAdam.zero_grad): forget what an ABORTED backward pass left behind.  The two end-of-
+    backward callbacks above reset their own flags, but autograd skips final callbacks when a node raises -- the flags would
+    then stay set for the rest of the process (no join, no deposit check ever queued again) and _DEPOSITS would keep
+    gradient tensors alive."""
+    global _join_queued, _deposit_check_queued
+    _join_queued = False
+    _deposit_check_queued = False
+    for m in _DEPOSITS:
+        m.grad = None
+        m.closed = False
+    _DEPOSITS.clear()
 
 
 class JoinHeadsFn(torch.autograd.Function):
@@ -935,6 +950,7 @@ def _parr(tensors):
 
 
 USE_MULTISCALE_LAUNCH = os.environ.get("PD_MULTISCALE_LAUNCH", "1") != "0"   # all scales of the loss per launch
+SUP_BWD_TWO_PASS = os.environ.get("PD_SUP_BWD_TWO_PASS") == "1"   # per-scale backward with the [N,H,W,6] intermediate (its test assigns it)
 
 
 class MultiScaleLossFn(torch.autograd.Function):
@@ -1020,7 +1036,7 @@ class MultiScaleLossFn(torch.autograd.Function):
         wts = _f32(dev, 3 * S)
         check(lib.pd_loss_weights(ptr(gvals), _iarr(cfg.scales), S, cfg.w_normals, cfg.w_smooth, ptr(wts), st),
               "pd_loss_weights")
-        if ctx.multi and os.environ.get("PD_SUP_BWD_TWO_PASS") != "1":
+        if ctx.multi and not SUP_BWD_TWO_PASS:
             grads = [torch.empty_like(d) for d in disps]
             gup = _f32(dev, S, N, H, W)
             gws = _f32(dev, sum(d.numel() for d in disps))
@@ -1031,16 +1047,16 @@ class MultiScaleLossFn(torch.autograd.Function):
                                              _parr(grads), N, H, W, cfg.min_depth, cfg.max_depth, st), "pd_multiscale_loss_bwd")
             return (None, None, None, *grads, *([None] * S))
         # (the [N,H,W,6] intermediate of the two-pass form; the fused kernel keeps it in LDS)
-        ab = _f32(dev, N, H, W, 6) if os.environ.get("PD_SUP_BWD_TWO_PASS") == "1" else None
+        ab = _f32(dev, N, H, W, 6) if SUP_BWD_TWO_PASS else None
         gup = _f32(dev, N, H, W)
         grads = []
         for i in range(S):
             d = disps[i]
             hs, ws = d.shape[2], d.shape[3]
             check(lib.pd_sup_loss_bwd(ptr(depths[i]), ptr(gt), ptr(K), ptr(ctx.gtn), ptr(wts[3 * i:]), ptr(sums[5 * i:]), ptr(ab),
-                                      ptr(gup), N, H, W, cfg.min_depth, cfg.max_depth, 1, 1, st), "pd_sup_loss_bwd")
+                                      ptr(gup), N, H, W, cfg.min_depth, cfg.max_depth, 1, 1, int(SUP_BWD_TWO_PASS), st), "pd_sup_loss_bwd")
             gd = torch.empty_like(d)
-            check(lib.pd_up_gather_bwd(ptr(gup), ptr(gd), N, hs, ws, H, W, 0, st), "pd_up_gather_bwd")
+            check(lib.pd_up_gather_bwd(ptr(gup), ptr(gd), N, hs, ws, H, W, 0, 0, st), "pd_up_gather_bwd")
             gws = _f32(dev, N, hs, ws)
             gacc = torch.empty(N, dtype=torch.float64, device=dev)
             check(lib.pd_smooth_bwd(ptr(d), ptr(colors[i]), ptr(means[i]), ptr(wts[3 * i:]), ptr(ctx.edge_ws[i]), ptr(gws), ptr(gacc),

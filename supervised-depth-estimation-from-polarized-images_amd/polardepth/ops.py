@@ -15,6 +15,35 @@ ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 CL = torch.channels_last
 PROFILE = None      # bench.py sets this to a list: (kernel label, algorithmic flops, start event, end event, shape)
 
+# Kernel family / arithmetic of the convolutions: the `flags` word of pd_conv2d* / pd_conv2d_wgrad (include/polardepth.h).
+# The library reads no environment variable; this module owns the knobs and reads them ONCE, at import:
+#   PD_CONV_X3=0    forward / data gradient on the fp32 MFMA only      PD_WGRAD_X3C=0   weight gradients likewise
+# Tests and bench.py switch families in-process by assigning CONV_FLAGS / WGRAD_FLAGS (or `with conv_flags(...)`).
+CONV_AUTO, CONV_FP32_MFMA, CONV_BF16X3, CONV_WGRAD_SPLIT_IN_REGS, CONV_GENERAL_KERNELS = 0, 1, 2, 4, 8
+CONV_FLAGS = CONV_FP32_MFMA if os.environ.get("PD_CONV_X3", "1") == "0" else CONV_AUTO        # pd_conv2d, _add, _rect
+WGRAD_FLAGS = CONV_FP32_MFMA if os.environ.get("PD_WGRAD_X3C", "1") == "0" else CONV_AUTO     # pd_conv2d_wgrad
+
+
+class conv_flags:
+    """Context manager: run the enclosed convolutions with the given flags (None = leave that entry point's word alone)."""
+
+    def __init__(self, conv=None, wgrad=None):
+        self.new = (conv, wgrad)
+
+    def __enter__(self):
+        global CONV_FLAGS, WGRAD_FLAGS
+        self.old = (CONV_FLAGS, WGRAD_FLAGS)
+        if self.new[0] is not None:
+            CONV_FLAGS = int(self.new[0])
+        if self.new[1] is not None:
+            WGRAD_FLAGS = int(self.new[1])
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_FLAGS, WGRAD_FLAGS
+        CONV_FLAGS, WGRAD_FLAGS = self.old
+        return False
+
 
 def _profiled(label, flops, fn, shape=None):
     if PROFILE is None:
@@ -29,12 +58,12 @@ def _profiled(label, flops, fn, shape=None):
 
 def _igemm_label(M, Co, vec, kind, C=0, KH=1, KW=1, stride=1, pad=0, mode=0, act=ACT_NONE, out_scale=False):
     """Profiler label = the kernel family pd_conv2d launches for this call (same rule as launch_conv in conv.hip)."""
-    rb = lib.pd_conv2d_uses_x3(M, Co, C, KH, KW, stride, pad, mode, act, int(out_scale)) if vec else 0
+    rb = lib.pd_conv2d_uses_x3(M, Co, C, KH, KW, stride, pad, mode, act, int(out_scale), CONV_FLAGS) if vec else 0
     if rb:
         return f"conv_igemm_x3_kernel<{128 * rb},64>"
     bm = lib.pd_conv2d_tile_m(M, Co)
     bn = 64 if Co > 32 else (32 if Co > 16 else 16)
-    uni = (vec and bn >= 32 and C % 32 == 0 and C > 0 and KH * KW <= 31 and pad < KH and pad < KW and
+    uni = (vec and not (CONV_FLAGS & CONV_GENERAL_KERNELS) and bn >= 32 and C % 32 == 0 and C > 0 and KH * KW <= 31 and pad < KH and pad < KW and
            (mode in (MODE_ZERO, MODE_REFLECT) or (mode == MODE_TRANSPOSED and stride == 1)))
     if uni:
         return f"conv_igemm_uni_kernel<{bm},{bn}>"
@@ -117,7 +146,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
     _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd", C, KH, KW, stride, pad, mode, act, out_scale is not None), 2.0 * N * Ho * Wo * Co * (alg_k if alg_k is not None else C * KH * KW),
               lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out_scale), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
                                           Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub,
-                                          div, ldy, stream_ptr()), "pd_conv2d"),
+                                          div, ldy, CONV_FLAGS, stream_ptr()), "pd_conv2d"),
               shape=("fwd", N, C, H, W, Co, KH, stride, mode))
     return (out, stats) if want_stats else out
 
@@ -161,7 +190,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
         wt = weight_transposed(w)
     dx = empty_nhwc(N, Ci, H, W, dy.device)
     sN, sC, sH, sW = dy.stride()
-    if (USE_S2_PHASES and addend is None and stride == 2 and KH == 3 and KW == 3 and pad == 1 and H == 2 * Hy and W == 2 * Wy
+    if (USE_S2_PHASES and not (CONV_FLAGS & CONV_GENERAL_KERNELS) and addend is None and stride == 2 and KH == 3 and KW == 3 and pad == 1 and H == 2 * Hy and W == 2 * Wy
             and Co % 32 == 0 and Ci % 4 == 0 and Ci > 16 and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0):
         # stride-2 data gradient by output parity: four stride-1 2x2 sub-filter launches + one interleave
         def _phases():
@@ -171,7 +200,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
             for c, off in enumerate((0, 1, 3, 5)):
                 ph, pw = c >> 1, c & 1
                 check(lib.pd_conv2d_rect(ptr(dy), wsub.data_ptr() + 4 * off * Ci * Co, ptr(sub[c]), N, Hy, Wy, Co, sN, sH, sW,
-                                         sC, Hy, Wy, Ci, 1 + ph, 1 + pw, ph, pw, MODE_TRANSPOSED, Ci, stream_ptr()),
+                                         sC, Hy, Wy, Ci, 1 + ph, 1 + pw, ph, pw, MODE_TRANSPOSED, Ci, CONV_FLAGS, stream_ptr()),
                       "pd_conv2d_rect(dgrad s2 phase)")
             check(lib.pd_interleave4(ptr(sub), ptr(dx), N, Hy, Wy, Ci, stream_ptr()), "pd_interleave4")
         _profiled("conv_dgrad_s2_phases", 2.0 * N * Hy * Wy * Co * Ci * KH * KW, _phases,
@@ -193,7 +222,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
         _profiled(_igemm_label(N * H * W, Ci, True, "dgrad", Co, KH, KW, stride, pad, MODE_TRANSPOSED),
                   2.0 * N * Hy * Wy * Co * Ci * KH * KW,
                   lambda: check(lib.pd_conv2d_add(ptr(dy), ptr(wt), ptr(addend), ld_add, ptr(dx), N, Hy, Wy, Co, sN, sH, sW,
-                                                  sC, H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, Ci, stream_ptr()),
+                                                  sC, H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, Ci, CONV_FLAGS, stream_ptr()),
                                 "pd_conv2d_add(dgrad)"),
                   shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))
         return dx
@@ -201,7 +230,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
     _profiled(_igemm_label(N * H * W, Ci, True, "dgrad", Co, KH, KW, stride, pad, MODE_TRANSPOSED), 2.0 * N * Hy * Wy * Co * Ci * KH * KW,
               lambda: check(lib.pd_conv2d(ptr(dy), ptr(wt), None, None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,
                                           H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci,
-                                          stream_ptr()), "pd_conv2d(dgrad)"),
+                                          CONV_FLAGS, stream_ptr()), "pd_conv2d(dgrad)"),
               shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))
     return dx
 
@@ -247,17 +276,17 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
                                 "pd_conv16_wgrad"),
                   shape=("wgrad", N, C, H, W, Co, KH, stride, mode))
         return (dw, dbias) if (want_bias or dbias is not None) else dw
-    nbytes = lib.pd_conv2d_wgrad_workspace(M, Co, K)
+    nbytes = lib.pd_conv2d_wgrad_workspace(M, Co, K, WGRAD_FLAGS)
     ws = _workspace(nbytes, x.device)
     sub, div = (affine if affine is not None else (0.0, 1.0))
     sN, sC, sH, sW = x.stride()
     x3c = (affine is None and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0 and dy.stride(3) % 4 == 0
-           and lib.pd_conv2d_wgrad_uses_x3(M, Co, C, KH, KW, stride, pad, mode, H, W, Ho, Wo))
+           and lib.pd_conv2d_wgrad_uses_x3(M, Co, C, KH, KW, stride, pad, mode, H, W, Ho, Wo, WGRAD_FLAGS))
     _profiled("conv_wgrad_x3c_kernel" if x3c else "conv_wgrad_kernel", 2.0 * M * Co * (alg_k if alg_k is not None else K),
               lambda: check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), N, H, W, C,
                                                 sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride, pad, mode,
                                                 int(affine is not None), sub, div, dy.stride(3), int(accumulate),
-                                                stream_ptr()), "pd_conv2d_wgrad"),
+                                                WGRAD_FLAGS, stream_ptr()), "pd_conv2d_wgrad"),
               shape=("wgrad", N, C, H, W, Co, KH, stride, mode))
     return (dw, dbias) if (want_bias or dbias is not None) else dw
 
@@ -361,7 +390,7 @@ def gemm_nt(a, b, out=None):
     _profiled(_igemm_label(M, Nn, K % 4 == 0, "gemm", K), 2.0 * M * Nn * K,
               lambda: check(lib.pd_conv2d(ptr(a), ptr(b), None, None, ptr(out), None, 1, M, 1, K, M * K, K, K, 1,
                                           M, 1, Nn, 1, 1, 1, 0, MODE_ZERO, ACT_NONE, 0, 0.0, 1.0, out.stride(0),
-                                          stream_ptr()), "pd_conv2d(gemm_nt)"))
+                                          CONV_FLAGS, stream_ptr()), "pd_conv2d(gemm_nt)"))
     return out
 
 
@@ -372,12 +401,12 @@ def gemm_tn(dy, x):
     Mx, K = x.shape
     assert M == Mx and dy.is_contiguous() and x.is_contiguous()
     out = torch.empty((Nn, K), dtype=torch.float32, device=x.device)
-    nbytes = lib.pd_conv2d_wgrad_workspace(M, Nn, K)
+    nbytes = lib.pd_conv2d_wgrad_workspace(M, Nn, K, WGRAD_FLAGS)
     ws = _workspace(nbytes, x.device)
     _profiled("conv_wgrad_kernel", 2.0 * M * Nn * K,
               lambda: check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(out), None, ptr(ws), ws.numel(), 1, M, 1, K,
                                                 M * K, K, K, 1, M, 1, Nn, 1, 1, 1, 0, MODE_ZERO, 0, 0.0, 1.0, Nn, 0,
-                                                stream_ptr()), "pd_conv2d_wgrad(gemm_tn)"))
+                                                WGRAD_FLAGS, stream_ptr()), "pd_conv2d_wgrad(gemm_tn)"))
     return out
 
 

@@ -66,7 +66,7 @@ def _device_tables(n, device_index):
 
 
 def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=None, out_width=None, out=None,
-                  precise=False, ieee_rho=False):
+                  precise=False, ieee_rho=False, nt_loads=None):
     """Run K1 on ``pol`` [B,4,H,W] uint8 (planes 0/45/90/135 deg) on the GPU.
 
     want: any of "xolp", "xolp_std", "normals", "ints".  Returns a dict of fp32 NCHW tensors
@@ -74,6 +74,8 @@ def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=No
     output [.., H, out_width] with the extra right columns zero (612 -> 640 padding for the network).
     precise=True selects PD_POLAR_PRECISE_NORMALS (fp64 theta trig; the default fp32 path is within ~3e-7 of it);
     ieee_rho=True selects PD_POLAR_IEEE_RHO (the literal fp64 sqrt/div sequence for every pixel: same bits, slower).
+    nt_loads=True / False forces the nontemporal hint on / off the plane loads (PD_POLAR_NT_LOADS / PD_POLAR_PLAIN_LOADS:
+    measurement; None = the library's size rule).
     """
     if not (isinstance(pol, torch.Tensor) and pol.is_cuda):
         raise RuntimeError("polar_forward needs a CUDA(HIP) uint8 tensor; there is no CPU fallback")
@@ -95,7 +97,8 @@ def polar_forward(pol, n=1.5, mode=MODE_LS, mask=None, want=("xolp",), tables=No
     with torch.cuda.device(pol.device):
         check(lib.pd_polar_fwd(ptr(pol), ptr(mask), ptr(out.get("xolp")), ptr(out.get("xolp_std")),
                                ptr(out.get("normals")), ptr(out.get("ints")), ptr(tables), tables.numel(),
-                               B, H, W, Wout, mode, int(bool(precise)) | (2 if ieee_rho else 0), stream_ptr()), "pd_polar_fwd")
+                               B, H, W, Wout, mode, int(bool(precise)) | (2 if ieee_rho else 0) |
+                               (0 if nt_loads is None else (4 if nt_loads else 8)), stream_ptr()), "pd_polar_fwd")
     return out
 
 

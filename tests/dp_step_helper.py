@@ -32,8 +32,25 @@ def main(out_path):
     PF.DropoutState.manual_seed(7)
     tr.set_train()
     losses = []
-    for step in range(2):
+    # PD_DP_GRAPH=segmented|capture: two eager steps, then the step as a hipGraph (polardepth/graph.py) for three more --
+    # PD_DP_STEPS=5 without it runs the same five steps eagerly
+    graph_comm = os.environ.get("PD_DP_GRAPH")
+    n_steps = int(os.environ.get("PD_DP_STEPS", 5 if graph_comm else 2))
+    gs = None
+    host_ms = None
+    for step in range(n_steps):
         batch = synthetic.make_batch(2, 64, 96, frame_w=92, device="cuda", seed=step)
+        if graph_comm and step >= 2:
+            if gs is None:
+                from polardepth.graph import GraphedTrainStep
+                gs = GraphedTrainStep(tr, batch, warmup=1, restore_state=True, comm=graph_comm)
+            import time
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = gs.step(batch)
+            host_ms = (time.perf_counter() - t0) * 1e3
+            losses.append(loss.detach().cpu().clone())
+            continue
         tr.model_optimizer.zero_grad()
         _, L, _ = tr.process_batch(dict(batch), is_train=True)
         L["loss"].backward()
@@ -67,7 +84,7 @@ def main(out_path):
                  "bucket0_streams": len(red.deps[0]), "waited_s": time.time() - t0}
         red.finish()
         torch.cuda.synchronize()
-    info = {"probe": probe, "flat": tr.store.flat.cpu(), "losses": torch.stack(losses), "distributed": tr.distributed,
+    info = {"probe": probe, "graph_host_ms": host_ms, "adam_steps": tr.model_optimizer.step_count, "flat": tr.store.flat.cpu(), "losses": torch.stack(losses), "distributed": tr.distributed,
             "reducer_active": bool(tr.reducer is not None and tr.reducer.active),
             "buckets": 0 if tr.reducer is None else len(tr.reducer.buckets),
             "global_norm": tr.loss_cfg.global_norm}

@@ -252,7 +252,7 @@ def test_rectangular_filter_with_separate_padding(geom):
         wd = wd.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     y = torch.empty(N, Co, Ho, Wo, device="cuda").contiguous(memory_format=torch.channels_last)
     sN, sC, sH, sW = xd.stride()
-    check(lib.pd_conv2d_rect(ptr(xd), ptr(wd), ptr(y), N, H, W, C, sN, sH, sW, sC, Ho, Wo, Co, KH, KW, ph, pw, 0, Co, None),
+    check(lib.pd_conv2d_rect(ptr(xd), ptr(wd), ptr(y), N, H, W, C, sN, sH, sW, sC, Ho, Wo, Co, KH, KW, ph, pw, 0, Co, 0, None),
           "pd_conv2d_rect")
     torch.cuda.synchronize()
     _close(y.cpu(), ref)
@@ -461,17 +461,17 @@ def test_bf16x3_kernel_keeps_fp32_accuracy(case, monkeypatch):
     dbe = {}
     ref_db = dy.double().sum((0, 2, 3))
     for knob in ("1", "0"):
-        monkeypatch.setenv("PD_CONV_X3", knob)
-        monkeypatch.setenv("PD_WGRAD_X3C", knob)          # weight gradient: every element split once (conv_wgrad_x3c_kernel)
-        monkeypatch.setenv("PD_WGRAD_X3", "0")
+        fl = ops.CONV_AUTO if knob == "1" else ops.CONV_FP32_MFMA      # the `flags` word of pd_conv2d* / pd_conv2d_wgrad
+        monkeypatch.setattr(ops, "CONV_FLAGS", fl)
+        monkeypatch.setattr(ops, "WGRAD_FLAGS", fl)        # weight gradient: every element split once (conv_wgrad_x3c_kernel)
         dw, db = ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p, want_bias=True)
         dwe[knob] = (dw.cpu().double() - ref_dw).abs().max().item() / ref_dw.abs().max().item()
         dbe[knob] = (db.cpu().double() - ref_db).abs().max().item() / ref_db.abs().max().item()
         if knob == "1":                                   # ... and the in-register split of the uniform-tap kernel
-            monkeypatch.setenv("PD_WGRAD_X3C", "0"); monkeypatch.setenv("PD_WGRAD_X3", "1")
+            monkeypatch.setattr(ops, "WGRAD_FLAGS", ops.CONV_WGRAD_SPLIT_IN_REGS)
             dw = ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p)
             dwe["r"] = (dw.cpu().double() - ref_dw).abs().max().item() / ref_dw.abs().max().item()
-            monkeypatch.setenv("PD_WGRAD_X3", "0")
+            monkeypatch.setattr(ops, "WGRAD_FLAGS", fl)
         y, st = ops.conv2d_fwd(xd, wd, bd, stride=s, pad=p, want_stats=True)
         errs[knob] = (y.cpu().double() - ref).abs().max().item() / scale
         stats[knob] = st.double().sum(0).cpu()
@@ -508,8 +508,177 @@ def test_bf16x3_kernel_reflection_padding_bias_elu(case, monkeypatch):
     wd = w.cuda().contiguous(memory_format=torch.channels_last)
     errs = {}
     for knob in ("1", "0"):
-        monkeypatch.setenv("PD_CONV_X3", knob)
-        assert bool(ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, 3, 3, 1, 1, ops.MODE_REFLECT, ops.ACT_ELU, 0)) == (knob == "1")
+        monkeypatch.setattr(ops, "CONV_FLAGS", ops.CONV_AUTO if knob == "1" else ops.CONV_FP32_MFMA)
+        assert bool(ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, 3, 3, 1, 1, ops.MODE_REFLECT, ops.ACT_ELU, 0, ops.CONV_FLAGS)) == (knob == "1")
         y = ops.conv2d_fwd(xd, wd, b.cuda(), stride=1, pad=1, mode=ops.MODE_REFLECT, act=ops.ACT_ELU)
         errs[knob] = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert errs["1"] <= 5e-6 and errs["1"] <= 1.5 * errs["0"] + 1e-7, errs
+
+
+# ------------------------------------------------------------------ the bf16-split kernels on inputs that are not `randn`
+def _field(mask_shape, n, h, w, k):
+    """Boolean [N,1,H,W] mask of the output pixels whose k x k window (pad k//2, stride 1) contains input pixel (n, h, w)."""
+    m = torch.zeros(mask_shape[0], 1, mask_shape[2], mask_shape[3], dtype=torch.bool)
+    r = k // 2
+    m[n, 0, max(h - r, 0):h + r + 1, max(w - r, 0):w + r + 1] = True
+    return m
+
+
+def _three(fn):
+    """fn() under flags AUTO (bf16-split where eligible) and PD_CONV_FP32_MFMA: returns (split result, fp32-MFMA result)."""
+    with ops.conv_flags(conv=ops.CONV_AUTO, wgrad=ops.CONV_AUTO):
+        a = fn()
+    with ops.conv_flags(conv=ops.CONV_FP32_MFMA, wgrad=ops.CONV_FP32_MFMA):
+        b = fn()
+    torch.cuda.synchronize()
+    return a.cpu(), b.cpu()
+
+
+BF16_OVERFLOW = 3.3961775292304e38          # (2 - 2^-8) * 2^127: fp32 values from here on round to bf16 infinity
+
+
+def test_bf16x3_kernels_nonfinite_and_extreme_inputs():
+    """What the bf16-split kernels (forward, data gradient, weight gradient) do with operands the fp32 MFMA handles by IEEE
+    rules (the reference's arithmetic: plain fp32 nn.Conv2d, pre_encoders.py:8-34) -- documented at pd_conv2d (polardepth.h):
+      * NaN stays NaN: every output that contracts a NaN operand is NaN in both kernel families;
+      * +-inf: the fp32 kernel returns +-inf (or NaN where infinities cancel), the split kernel a NON-FINITE value -- hi = inf
+        makes mid = x - hi = NaN -- at exactly the same outputs; nothing else is touched;
+      * |x| >= (2 - 2^-8) 2^127 ~ 3.396e38 rounds to bf16 infinity: non-finite in the split kernel, finite in fp32 (a caller
+        who needs that range passes PD_CONV_FP32_MFMA); |x| just below it is exact (hi + mid + lo = x);
+      * everywhere else the two families agree with the fp64 reference as on `randn` inputs (<= 5e-6 of the scale, split
+        <= 1.5x fp32)."""
+    N, C, H, W, Co, k = 2, 64, 256, 320, 64, 3
+    g = torch.Generator().manual_seed(20)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = (torch.rand(Co, C, k, k, generator=g) + 0.5) / (C * k * k)          # all weights positive: an infinity cannot cancel
+    dyv = torch.randn(N, Co, H, W, generator=g)
+    special = {"nan": (0, 5, 10, 10, float("nan")), "pinf": (0, 7, 100, 50, float("inf")), "ninf": (1, 3, 200, 300, float("-inf")),
+               "big": (1, 9, 30, 30, 3.39e38), "over": (1, 11, 60, 200, 3.4e38)}
+    assert 3.39e38 < BF16_OVERFLOW < 3.4e38
+
+    def inject(t):
+        t = t.clone()
+        for n, c, h, ww, v in special.values():
+            t[n, c, h, ww] = v
+        return t
+
+    fields = {name: _field((N, 1, H, W), n, h, ww, k) for name, (n, c, h, ww, v) in special.items()}
+    plain = ~torch.stack(list(fields.values())).any(0)
+
+    def check_maps(name, split, fp32, ref):
+        sf, ff, rf = torch.isfinite(split), torch.isfinite(fp32), torch.isfinite(ref)
+        for nm in ("nan", "pinf", "ninf"):
+            m = fields[nm].expand_as(ref)
+            assert not rf[m].any() and not ff[m].any() and not sf[m].any(), f"{name}: {nm} field must be non-finite in every path"
+        assert torch.isnan(split[fields["nan"].expand_as(ref)]).all() and torch.isnan(fp32[fields["nan"].expand_as(ref)]).all()
+        assert torch.isinf(fp32[fields["pinf"].expand_as(ref)]).all() and torch.isinf(fp32[fields["ninf"].expand_as(ref)]).all()
+        m = fields["over"].expand_as(ref)
+        assert ff[m].all() and rf[m].all(), f"{name}: 3.4e38 is finite in fp32"
+        assert not sf[m].any(), f"{name}: 3.4e38 rounds to bf16 infinity in the split kernel (documented deviation)"
+        m = fields["big"].expand_as(ref)
+        sc = ref[m].abs().max().item()
+        e_s, e_f = (split[m].double() - ref[m]).abs().max().item() / sc, (fp32[m].double() - ref[m]).abs().max().item() / sc
+        assert sf[m].all() and e_s <= 5e-6 and e_s <= 1.5 * e_f + 1e-7, f"{name}: 3.39e38 field {e_s:.2e} vs {e_f:.2e}"
+        m = plain.expand_as(ref)
+        assert sf[m].all() and ff[m].all(), f"{name}: a special value leaked outside its receptive field"
+        sc = ref[m].abs().max().item()
+        e_s, e_f = (split[m].double() - ref[m]).abs().max().item() / sc, (fp32[m].double() - ref[m]).abs().max().item() / sc
+        assert e_s <= 5e-6 and e_f <= 5e-6 and e_s <= 1.5 * e_f + 1e-8, f"{name}: plain region {e_s:.2e} vs {e_f:.2e}"
+
+    # forward: special values in the activation
+    xs = inject(x)
+    ref = F.conv2d(xs.double(), w.double(), None, padding=1)
+    xd = xs.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    assert ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, k, k, 1, 1, 0, 0, 0, ops.CONV_AUTO) == 2
+    check_maps("forward", *_three(lambda: ops.conv2d_fwd(xd, wd, None, stride=1, pad=1)), ref)
+    # data gradient: special values in dY (same channel count in and out: the same fields)
+    dys = inject(dyv)
+    ref = F.conv_transpose2d(dys.double(), w.double(), None, stride=1, padding=1)
+    dyd = dys.cuda().contiguous(memory_format=torch.channels_last)
+    check_maps("dgrad", *_three(lambda: ops.conv2d_dgrad(dyd, wd, (H, W), stride=1, pad=1)), ref)
+    # weight gradient: special values in X reach dW[:, ci, :, :] of their channel; dY small so that 3.39e38 * dy stays finite
+    dsm = (dyv * 1e-3).cuda().contiguous(memory_format=torch.channels_last)
+    assert ops.lib.pd_conv2d_wgrad_uses_x3(N * H * W, Co, C, k, k, 1, 1, 0, H, W, H, W, ops.CONV_AUTO) == 1
+    split, fp32 = _three(lambda: ops.conv2d_wgrad(xd, dsm, w.shape, stride=1, pad=1))
+    ref = torch.autograd.grad(F.conv2d(xs.double(), wv := w.double().requires_grad_(True), None, padding=1), wv, (dyv * 1e-3).double())[0]
+    ch = {name: c for name, (n, c, h, ww, v) in special.items()}
+    for nm in ("nan", "pinf", "ninf"):
+        assert not torch.isfinite(split[:, ch[nm]]).any() and not torch.isfinite(fp32[:, ch[nm]]).any() and not torch.isfinite(ref[:, ch[nm]]).any()
+    assert torch.isnan(split[:, ch["nan"]]).all() and torch.isnan(fp32[:, ch["nan"]]).all()
+    assert torch.isfinite(fp32[:, ch["over"]]).all() and not torch.isfinite(split[:, ch["over"]]).any()
+    rest = [c for c in range(C) if c not in (ch["nan"], ch["pinf"], ch["ninf"], ch["over"])]
+    assert torch.isfinite(split[:, rest]).all() and torch.isfinite(fp32[:, rest]).all()
+    for cs in ([ch["big"]], [c for c in rest if c != ch["big"]]):
+        sc = ref[:, cs].abs().max().item()
+        e_s = (split[:, cs].double() - ref[:, cs]).abs().max().item() / sc
+        e_f = (fp32[:, cs].double() - ref[:, cs]).abs().max().item() / sc
+        assert e_s <= 2e-5 and e_s <= 3 * e_f + 2e-7, (cs[:2], e_s, e_f)
+
+
+@pytest.mark.parametrize("magnitude", [1e-39, 1e-36])
+def test_bf16x3_kernels_denormal_range(magnitude):
+    """fp32 denormals (1e-39) and normal values whose mid / lo terms fall into the bf16 denormal range (1e-36: x - hi ~ 2e-39).
+    A priori bound from the formats alone: whatever an implementation flushes, it treats a number below FLT_MIN = 2^-126 as
+    zero at worst, so |error| <= K * max|w| * 2^-126 on top of the fp32 kernel's own error -- for forward, data and weight
+    gradient.  (The outputs themselves are ~1e-38: this is a statement about absolute noise, not relative accuracy.)"""
+    N, C, H, W, Co, k = 2, 64, 256, 320, 64, 3
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(N, C, H, W, generator=g) * 2 - 1) * magnitude
+    w = torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5
+    K = C * k * k
+    slack = K * w.abs().max().item() * 2.0 ** -126
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    split, fp32 = _three(lambda: ops.conv2d_fwd(xd, wd, None, stride=1, pad=1))
+    e_s, e_f = (split.double() - ref).abs().max().item(), (fp32.double() - ref).abs().max().item()
+    assert torch.isfinite(split).all() and e_s <= 1.5 * e_f + slack, ("fwd", e_s, e_f, slack)
+    ref = F.conv_transpose2d(x.double(), w.double(), None, stride=1, padding=1)          # (x as dY: same shape)
+    split, fp32 = _three(lambda: ops.conv2d_dgrad(xd, wd, (H, W), stride=1, pad=1))
+    e_s, e_f = (split.double() - ref).abs().max().item(), (fp32.double() - ref).abs().max().item()
+    assert torch.isfinite(split).all() and e_s <= 1.5 * e_f + slack, ("dgrad", e_s, e_f, slack)
+    dy = torch.randn(N, Co, H, W, generator=g)
+    ref = torch.autograd.grad(F.conv2d(x.double(), wv := w.double().requires_grad_(True), None, padding=1), wv, dy.double())[0]
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    split, fp32 = _three(lambda: ops.conv2d_wgrad(xd, dyd, w.shape, stride=1, pad=1))
+    slack_w = N * H * W * dy.abs().max().item() * 2.0 ** -126
+    e_s, e_f = (split.double() - ref).abs().max().item(), (fp32.double() - ref).abs().max().item()
+    assert torch.isfinite(split).all() and e_s <= 3 * e_f + slack_w, ("wgrad", e_s, e_f, slack_w)
+
+
+def test_bf16x3_kernel_cancellation_heavy_contraction():
+    """K = 1600 (5x5x64) products of magnitude ~1e4 that sum to O(1): the three dropped terms of the split (mid*lo, lo*mid,
+    lo*lo <= 2^-23 of a product) are no longer small against the RESULT, only against the addends -- as is every fp32
+    rounding of the fp32-MFMA kernel's own accumulation.  Same bar as on `randn`: the split kernel's error against an fp64
+    convolution is at most 1.5x the fp32 kernel's (forward and data gradient), both measured against the size of the addends
+    (1e4 * sqrt(K)), where they are ~1e-7."""
+    N, C, H, W, Co, k = 2, 64, 256, 320, 64, 5
+    g = torch.Generator().manual_seed(22)
+    K = C * k * k
+    # x: +-100 with a smooth random magnitude; w: +-100-ish, then each filter is made orthogonal to the all-ones window so
+    # that a locally constant input cancels; the image is locally constant up to a small perturbation
+    base = (torch.rand(N, C, 1, 1, generator=g) + 0.5) * 100.0 * torch.sign(torch.randn(N, C, 1, 1, generator=g))
+    x = base.expand(N, C, H, W) + 1e-2 * torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, k, k, generator=g) * 100.0
+    w = w - (w * base[0:1]).sum((1, 2, 3), keepdim=True) / (base[0:1] ** 2).sum() / (k * k) * base[0:1]      # sum_k w * base[0] == 0
+    ref = F.conv2d(x.double(), w.double(), None, padding=2)
+    inner = ref[0, :, 2:-2, 2:-2]
+    addends = 100.0 * 100.0
+    assert inner.abs().max().item() < 1e-3 * addends * K ** 0.5, "the contraction does not cancel"
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    assert ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, k, k, 1, 2, 0, 0, 0, ops.CONV_AUTO) == 2
+    split, fp32 = _three(lambda: ops.conv2d_fwd(xd, wd, None, stride=1, pad=2))
+    sc = addends * K ** 0.5
+    e_s, e_f = (split.double() - ref).abs().max().item() / sc, (fp32.double() - ref).abs().max().item() / sc
+    assert e_s <= 5e-6 and e_s <= 1.5 * e_f + 1e-9, ("fwd", e_s, e_f)
+    # image 0, interior: the O(1) results themselves
+    e_s0 = (split[0, :, 2:-2, 2:-2].double() - inner).abs().max().item()
+    e_f0 = (fp32[0, :, 2:-2, 2:-2].double() - inner).abs().max().item()
+    assert e_s0 <= 1.5 * e_f0 + 1e-9 * sc, ("fwd, cancelling region", e_s0, e_f0)
+    # data gradient with the same operands (dY := x, a Co == C layer)
+    ref = F.conv_transpose2d(x.double(), w.double(), None, stride=1, padding=2)
+    split, fp32 = _three(lambda: ops.conv2d_dgrad(xd, wd, (H, W), stride=1, pad=2))
+    e_s, e_f = (split.double() - ref).abs().max().item() / sc, (fp32.double() - ref).abs().max().item() / sc
+    assert e_s <= 5e-6 and e_s <= 1.5 * e_f + 1e-9, ("dgrad", e_s, e_f)

@@ -47,6 +47,23 @@ def _worker(rank, world, port, ret):
             for i, p in enumerate(params):
                 exp = 0.0 if p is skip else 3.0 * (i + 1)          # (1 + 2) * (i + 1)
                 assert torch.all(p.grad == exp), (step, i)
+        # deferred mode (the backward pass runs inside a hipGraph replay: polardepth/graph.py, segmented): hooks that fire
+        # while it is set launch nothing; exchange_now() reduces every bucket with the per-bucket calls of the overlapped
+        # path; finish() afterwards (FusedAdam.step calls it) must not reduce a second time
+        store.zero_grad(); red.reset()
+        red.deferred = True
+        for i, p in enumerate(store.used_params()):
+            p.grad.copy_(torch.full_like(p, float(rank + 1) * (i + 1)))
+            p._pd_grad_ready()
+        assert sum(red.launched) == 0 and not red.works
+        red.finish()                                               # still deferred: a no-op
+        assert sum(red.launched) == 0
+        red.deferred = False
+        red.exchange_now()
+        assert all(red.launched) and not red.works
+        red.finish()
+        for i, p in enumerate(store.used_params()):
+            assert torch.all(p.grad == 3.0 * (i + 1)), i
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

@@ -43,3 +43,17 @@ def test_busy_encoder_stream_does_not_stall_a_decoder_bucket(tmp_path):
     assert r["probe"] is not None
     assert r["probe"]["comm_done_while_encoder_busy"], r["probe"]
     assert r["probe"]["bucket0_streams"] <= 2          # main + weight-gradient stream, no encoder stream
+
+
+@pytest.mark.parametrize("comm", ["segmented", "capture"])
+def test_graphed_step_with_the_reducer_is_bit_equal_to_eager_dp_steps(tmp_path, comm):
+    """polardepth/graph.py under torch.distributed (world-1 RCCL group, every bucket / comm-stream / all-reduce live): two
+    eager DP steps + three replays leave the parameters of five eager DP steps, bit for bit.  "segmented": graph of
+    zero_grad..backward, the bucketed all-reduce behind it, eager Adam; "capture": the collectives inside the graph.
+    Host cost of a step: one replay (+ the collectives and two launches), not ~520 Python launches."""
+    eager = _run(tmp_path, "eager5", PD_DIST_TEST=1, PD_DP_STEPS=5)
+    graph = _run(tmp_path, "graph_" + comm, PD_DIST_TEST=1, PD_DP_GRAPH=comm)
+    assert eager["reducer_active"] and graph["reducer_active"] and graph["adam_steps"] == eager["adam_steps"] == 5
+    assert torch.equal(eager["losses"], graph["losses"]), (eager["losses"], graph["losses"])
+    assert torch.equal(eager["flat"], graph["flat"])
+    assert graph["graph_host_ms"] < 3.0, graph["graph_host_ms"]

@@ -91,3 +91,56 @@ def test_run_epoch_with_the_graphed_step_matches_the_eager_epoch(tmp_path, monke
         out.append((tr.store.flat.clone(), tr.model_optimizer.step_count, tr.model_optimizer.exp_avg.clone()))
     assert out[0][1] == out[1][1] > 0
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][2], out[1][2])
+
+
+def test_graphed_step_follows_the_learning_rate_schedule(tmp_path, monkeypatch):
+    """trainer.py:238-240,467: StepLR multiplies the learning rate by 0.1 every scheduler_step_size epochs.  lr (and the
+    reducer's grad_scale) are device words of the optimizer (pd_step_set_hyper), not arguments frozen at capture: two
+    epochs with scheduler_step_size = 1 through the captured step leave the parameters of the eager run, bit for bit --
+    and they differ from a run whose learning rate stayed at its first value."""
+    from polardepth import functional as PF
+    out = {}
+    for mode in ("eager", "graph", "eager_const_lr"):
+        monkeypatch.setenv("PD_STEP_GRAPH", "1" if mode == "graph" else "0")
+        PF.DropoutState.manual_seed(11)
+        from test_step_gpu import _opts
+        from manydepth.trainer import Trainer
+        torch.manual_seed(0)
+        tr = Trainer(_opts(tmp_path / mode, ["--dropout_rate", "0.1", "--scheduler_step_size", "1"]))
+        tr.opt.log_frequency = 10 ** 9
+        tr.step = 1
+        lrs = []
+        for _ in range(2):
+            lrs.append(tr.model_optimizer.param_groups[0]["lr"])
+            tr.run_epoch()                       # ends with model_lr_scheduler.step()
+            if mode == "eager_const_lr":
+                tr.model_optimizer.param_groups[0]["lr"] = lrs[0]
+        torch.cuda.synchronize()
+        if mode != "eager_const_lr":
+            assert abs(lrs[1] - 0.1 * lrs[0]) < 1e-12 * lrs[0], lrs
+        out[mode] = (tr.store.flat.clone(), tr.model_optimizer.exp_avg.clone())
+    assert torch.equal(out["eager"][0], out["graph"][0]) and torch.equal(out["eager"][1], out["graph"][1])
+    assert not torch.equal(out["eager"][0], out["eager_const_lr"][0])
+
+
+def test_two_optimizers_keep_their_own_device_step_words(tmp_path):
+    """Adam's device-side t / lr / grad_scale belong to the optimizer, not to the device: a second trainer stepping in
+    between does not disturb the first one's bias corrections."""
+    from polardepth import synthetic
+    tr_a, tr_b = _trainer(tmp_path, "a"), _trainer(tmp_path, "b")
+    for tr in (tr_a, tr_b):
+        tr.set_train()
+        tr.model_optimizer.use_device_step(True)
+    assert tr_a.model_optimizer.dev_state.data_ptr() != tr_b.model_optimizer.dev_state.data_ptr()
+    b = synthetic.make_batch(2, 64, 96, frame_w=92, device="cuda", seed=3)
+
+    def one(tr):
+        tr.model_optimizer.zero_grad()
+        _, L, _ = tr.process_batch(dict(b), is_train=True)
+        L["loss"].backward()
+        tr.model_optimizer.step()
+
+    one(tr_a); one(tr_b); one(tr_b); one(tr_b); one(tr_a)
+    torch.cuda.synchronize()
+    assert int(tr_a.model_optimizer.dev_state[1]) == 2 and int(tr_b.model_optimizer.dev_state[1]) == 3
+    assert tr_a.model_optimizer.step_count == 2 and tr_b.model_optimizer.step_count == 3

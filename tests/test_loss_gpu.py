@@ -100,7 +100,7 @@ def test_fused_supervised_backward_equals_the_two_pass_form(geom, monkeypatch):
     color = torch.rand(N, 3, H, W, generator=g).cuda()
     out = []
     for two_pass in ("0", "1"):
-        monkeypatch.setenv("PD_SUP_BWD_TWO_PASS", two_pass)
+        monkeypatch.setattr(PF, "SUP_BWD_TWO_PASS", two_pass == "1")       # pd_sup_loss_bwd(two_pass_form=...)
         disp = torch.rand(N, 1, H, W, generator=torch.Generator().manual_seed(5)).cuda().requires_grad_(True)
         vals, _ = PF.multiscale_loss(cfg, gt, K, [disp], [color])
         vals[0].backward()
@@ -122,10 +122,9 @@ def test_upsample_gradient_gather_specialisations_are_bit_exact(f, monkeypatch):
     d = torch.zeros(N, 1, hs, ws, requires_grad=True)
     F.interpolate(d, size=(H, W), mode="bilinear", align_corners=False).backward(gup)
     out = []
-    for generic in ("0", "1"):
-        monkeypatch.setenv("PD_UP_GATHER_GENERIC", generic)
+    for generic in (0, 1):
         gd = torch.empty(N, 1, hs, ws, device="cuda")
-        check(lib.pd_up_gather_bwd(ptr(gup.cuda()), ptr(gd), N, hs, ws, H, W, 0, None), "pd_up_gather_bwd")
+        check(lib.pd_up_gather_bwd(ptr(gup.cuda()), ptr(gd), N, hs, ws, H, W, 0, generic, None), "pd_up_gather_bwd")
         torch.cuda.synchronize()
         out.append(gd.cpu())
     assert torch.equal(out[0], out[1])

@@ -2,7 +2,7 @@
 
 Every launch works on a different buffer set (``--sets`` rotating copies, sized so that their total exceeds the
 256 MB Infinity Cache): the figure is an HBM figure, as in the training step, where 79 ms of other traffic
-separate two K1 launches.  ``PD_POLAR_THREADS`` (256 | 512 | 1024) selects the workgroup size of the fast kernel.
+separate two K1 launches.  ``nt_loads`` (None | True | False) is pd_polar_fwd's PD_POLAR_NT_LOADS / PD_POLAR_PLAIN_LOADS flag.
 """
 import argparse
 import json
@@ -29,7 +29,7 @@ def make_planes(B, H, W, realistic, seed=0):
     return torch.randint(0, 256, (B, 4, H, W), dtype=torch.uint8, device="cuda", generator=g)
 
 
-def time_variant(B, want, iters=24, H=512, W=612, realistic=True, precise=False, sets=None, out_width=None):
+def time_variant(B, want, iters=24, H=512, W=612, realistic=True, precise=False, sets=None, out_width=None, nt_loads=None):
     bpp = 4 + (8 if "xolp" in want else 0) + (8 if "xolp_std" in want else 0) + (36 if "normals" in want else 0)
     if sets is None:                       # enough rotating sets to exceed 2.5x the Infinity Cache
         per_set = B * H * (out_width or W) * bpp
@@ -39,7 +39,7 @@ def time_variant(B, want, iters=24, H=512, W=612, realistic=True, precise=False,
     for p in pols:
         o = pdpolar.polar_forward(p, want=want, precise=precise, out_width=out_width)
         outs.append(o)
-    kw = dict(want=want, precise=precise, out_width=out_width)
+    kw = dict(want=want, precise=precise, out_width=out_width, nt_loads=nt_loads)
     for i in range(sets):
         pdpolar.polar_forward(pols[i], out=outs[i], **kw)
     torch.cuda.synchronize()
@@ -54,7 +54,7 @@ def time_variant(B, want, iters=24, H=512, W=612, realistic=True, precise=False,
     ms = ts[iters // 2]
     gbs = B * H * W * bpp / (ms * 1e-3) / 1e9
     return {"B": B, "want": list(want), "realistic": realistic, "precise": precise, "sets": sets,
-            "out_width": out_width, "threads": os.environ.get("PD_POLAR_THREADS", "default") + "/g" + os.environ.get("PD_POLAR_GLOBAL_TABLES", "0"),
+            "out_width": out_width, "nt_loads": nt_loads,
             "ms": round(ms, 4), "ms_min": round(ts[0], 4), "bytes_px": bpp,
             "GBps": round(gbs, 1), "frac_8TBps": round(gbs / 8000, 3)}
 
