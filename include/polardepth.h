@@ -101,6 +101,13 @@ int pd_polar_fwd(const void* pol, const void* mask, void* xolp, void* xolp_std, 
 int pd_polar_normals_from_xolp(const void* xolp, void* normals, const void* tables, size_t tables_bytes,
                                int B, int H, int W, int flags, void* stream);
 
+/* calc_normals (manydepth/normals_vec.py:53-60): out [B,3,P] = (cos(phi) sin(theta), sin(phi) sin(theta), cos(theta)) for
+ * phi, theta [B,P].  Element types as torch promotes them there: *_f64 != 0 marks an fp64 operand; the output is fp64 when
+ * either operand is (the reference's get_normals hands over an fp32 phi and an fp64 theta: cos(phi) is evaluated in fp32
+ * and promoted, normals_vec.py:56-58), fp32 otherwise. */
+int pd_polar_calc_normals(const void* phi, const void* theta, void* out, int B, long P, int phi_f64, int theta_f64,
+                          void* stream);
+
 /* rho_diffuse / rho_spec as functions of their own (manydepth/normals_vec.py:11-22, 25-50): rho fp32 [n] ->
  * theta_d, theta_s1, theta_s2 fp64 [n] (each may be NULL) = scipy interp1d(fill_value="extrapolate") of the three
  * tables, evaluated in scipy's operation order (slope * (rho - x_lo) + y_lo, fp64), so rho beyond a table extrapolates
@@ -299,6 +306,16 @@ int pd_up_bwd(const void* dout, long ld_d, void* da, int N, int H, int W, int Ca
  * leaves multiplied by (a > 0 ? 1 : a + 1), i.e. as the gradient of the convolution output. elu_y NULL = pd_up_bwd. */
 int pd_up_bwd_elu(const void* dout, long ld_d, const void* elu_y, void* da, int N, int H, int W, int Ca, void* stream);
 
+/* DPT decoder glue (reference manydepth/dpt/blocks.py; --train_dpt, trainer.py:147-171):
+ * pd_up2x_ac_fwd / _bwd: nn.functional.interpolate(scale_factor=2, mode="bilinear", align_corners=True) of an NHWC
+ *   tensor [N,H,W,C] -> [N,2H,2W,C] (blocks.py:138-172 Interpolate, :375-377 in FeatureFusionBlock_custom) and its
+ *   gradient in gather form (deterministic);
+ * pd_relu_add: out = (relu ? max(x, 0) : x) + (res ? res : 0) over n floats -- the activation in front of the first
+ *   convolution and the skip sum of ResidualConvUnit_custom (blocks.py:289-307). */
+int pd_up2x_ac_fwd(const void* a, void* out, int N, int H, int W, int C, void* stream);
+int pd_up2x_ac_bwd(const void* dout, void* da, int N, int H, int W, int C, void* stream);
+int pd_relu_add(const void* x, const void* res, void* out, long n, int relu, void* stream);
+
 /* dz = dy * f'(.) through the activation OUTPUT y: act 1 ReLU, 2 ELU (layers.py:337), 3 sigmoid. */
 int pd_act_bwd(const void* dy, const void* y, void* dz, long n, int act, void* stream);
 /* Gradient of ReflectionPad2d(1): dxp [N,H+2,W+2,C] -> dx [N,H,W,C]  (layers.py:372). */
@@ -389,8 +406,14 @@ int pd_multiscale_loss_bwd(const void* const* disps, const void* const* colors, 
 int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, const void* gt_normals, const void* wts,
                     const void* sums, void* ab_ws, void* gout, int N, int H, int W, float min_depth, float max_depth,
                     int with_normals, int to_disp, int two_pass_form, void* stream);
-/* edge_w (optional, NULL = recompute in the backward pass): [N,h,w,2] floats, the image-only edge weights
- * e^{-|dx I|}, e^{-|dy I|} (layers.py:452-465) written by the forward pass and read by the backward pass. */
+/* Edge-aware smoothness (layers.py:452-465 get_smooth_loss) of the mean-normalised disparity of trainer.py:1256-1258:
+ * partial[block][2] = (sum |dx (disp / (mean + 1e-7))| e^{-|dx I|}, same for y); the caller divides by the element
+ * counts N h (w-1) and N (h-1) w.  mean [N] receives the per-image means; mean == NULL evaluates the term on disp as it
+ * is -- layers.get_smooth_loss as a function of its own (the facade's manydepth.layers.get_smooth_loss).
+ * edge_w (optional, NULL = recompute in the backward pass): [N,h,w,2] floats, the image-only edge weights
+ * e^{-|dx I|}, e^{-|dy I|} written by the forward pass and read by the backward pass.
+ * pd_smooth_bwd: wts[2] = d loss / d (smooth_x + smooth_y) (the two terms are averaged separately, as in the reference);
+ * g_ws [N,h,w] floats, gd_acc N doubles. */
 int pd_smooth_fwd(const void* disp, const void* img, void* mean, void* partial, void* edge_w, int N, int h, int w,
                   void* stream);
 int pd_smooth_bwd(const void* disp, const void* img, const void* mean, const void* wts, const void* edge_w, void* g_ws,

@@ -599,6 +599,83 @@ __global__ __launch_bounds__(EW_T) void upcat_fwd_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------- bilinear x2, align_corners = True (DPT)
+// nn.functional.interpolate(scale_factor=2, mode="bilinear", align_corners=True) of the DPT fusion blocks and output head
+// (reference manydepth/dpt/blocks.py:138-172, 375-377): src = dst * (in - 1) / (out - 1), evaluated in fp32 like torch's
+// area_pixel_compute_source_index; i0 = int(src), i1 = i0 + (i0 < in - 1), l1 = src - i0.
+__device__ __forceinline__ void ac_tap(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+    const float s = scale * (float)o;
+    i0 = (int)s; i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - (float)i0; l0 = 1.f - l1;
+}
+__global__ __launch_bounds__(EW_T) void up2x_ac_fwd_kernel(const float* __restrict__ a, float* __restrict__ out, int N, int H,
+                                                           int W, int C) {
+    const int cq = C >> 2, Ho = 2 * H, Wo = 2 * W;
+    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long total = (long)N * Ho * Wo * cq;
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        int c4, x, y;
+        long pix = divmod(i, cq, c4); c4 *= 4;
+        const long opix = pix;
+        pix = divmod(pix, Wo, x);
+        const long n = divmod(pix, Ho, y);
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        ac_tap(y, sh, H, y0, y1, ly0, ly1);
+        ac_tap(x, sw, W, x0, x1, lx0, lx1);
+        const float* b = a + n * H * W * C + c4;
+        const float4 v00 = ld4(b + ((long)y0 * W + x0) * C), v01 = ld4(b + ((long)y0 * W + x1) * C);
+        const float4 v10 = ld4(b + ((long)y1 * W + x0) * C), v11 = ld4(b + ((long)y1 * W + x1) * C);
+        st4(out + opix * C + c4, make_float4(ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x),
+                                             ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y),
+                                             ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z),
+                                             ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w)));
+    }
+}
+// da[n,h,w,:] = sum over the output pixels whose taps include (h, w), in a fixed order (gather: deterministic).  The rows
+// that read input row h lie in [ceil((h-1)/s), floor((h+1)/s)] (s = (H-1)/(2H-1) ~ 1/2): at most five, tested one by one
+__global__ __launch_bounds__(EW_T) void up2x_ac_bwd_kernel(const float* __restrict__ dout, float* __restrict__ da, int N, int H,
+                                                           int W, int C) {
+    const int cq = C >> 2, Ho = 2 * H, Wo = 2 * W;
+    const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long total = (long)N * H * W * cq;
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < total; i += (long)gridDim.x * EW_T) {
+        int c4, w, h;
+        long pix = divmod(i, cq, c4); c4 *= 4;
+        pix = divmod(pix, W, w);
+        const long n = divmod(pix, H, h);
+        const int oy_lo = max(2 * h - 3, 0), oy_hi = min(2 * h + 3, Ho - 1), ox_lo = max(2 * w - 3, 0), ox_hi = min(2 * w + 3, Wo - 1);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* d = dout + n * Ho * Wo * C + c4;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly0, ly1;
+            ac_tap(oy, sh, H, y0, y1, ly0, ly1);
+            if (y0 != h && y1 != h) continue;
+            const float wy = (y0 == h ? ly0 : 0.f) + (y1 == h ? ly1 : 0.f);      // (last row: y0 == y1 == h, both weights)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx0, lx1;
+                ac_tap(ox, sw, W, x0, x1, lx0, lx1);
+                if (x0 != w && x1 != w) continue;
+                const float wx = (x0 == w ? lx0 : 0.f) + (x1 == w ? lx1 : 0.f);
+                const float4 g = ld4(d + ((long)oy * Wo + ox) * C);
+                const float k = wy * wx;
+                acc.x += k * g.x; acc.y += k * g.y; acc.z += k * g.z; acc.w += k * g.w;
+            }
+        }
+        st4(da + (n * H * W + (long)h * W + w) * C + c4, acc);
+    }
+}
+
+// out = max(x, 0) [+ res]  /  out = x + res: the element-wise glue of the DPT residual units (blocks.py:289-307)
+__global__ __launch_bounds__(EW_T) void relu_add_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        float* __restrict__ out, long n4, int relu) {
+    for (long i = blockIdx.x * (long)EW_T + threadIdx.x; i < n4; i += (long)gridDim.x * EW_T) {
+        float4 v = ld4(x + 4 * i);
+        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (res) { const float4 r = ld4(res + 4 * i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        st4(out + 4 * i, v);
+    }
+}
+
 // da[n,h,w,:] = sum over the (up to 4x4) output pixels that read a[h,w], times their bilinear weights
 // elu_y != NULL: a = ELU(z) came from a ConvBlock; da is multiplied by ELU'(z) (through a) and leaves as dz
 __global__ __launch_bounds__(EW_T) void up_bwd_kernel(const float* __restrict__ dout, long ld_d, const float* __restrict__ elu_y,
@@ -1016,6 +1093,31 @@ extern "C" int pd_upcat_fwd(const void* a, const void* skip, long ld_skip, void*
     hipLaunchKernelGGL(upcat_fwd_kernel, dim3(ew_grid((long)N * 4 * H * W * ((Ca + Cs) / 4))), dim3(EW_T), 0,
                        (hipStream_t)stream, (const float*)a, (const float*)skip, ld_skip, (float*)out, N, H, W, Ca, Cs);
     return pd::check_launch("pd_upcat_fwd");
+}
+
+extern "C" int pd_up2x_ac_fwd(const void* a, void* out, int N, int H, int W, int C, void* stream) {
+    PD_REQUIRE(a && out && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_up2x_ac_fwd: bad arguments");
+    if (N == 0) return PD_OK;
+    hipLaunchKernelGGL(up2x_ac_fwd_kernel, dim3(ew_grid((long)N * 4 * H * W * (C / 4))), dim3(EW_T), 0, (hipStream_t)stream,
+                       (const float*)a, (float*)out, N, H, W, C);
+    return pd::check_launch("pd_up2x_ac_fwd");
+}
+
+extern "C" int pd_up2x_ac_bwd(const void* dout, void* da, int N, int H, int W, int C, void* stream) {
+    PD_REQUIRE(dout && da && N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "pd_up2x_ac_bwd: bad arguments");
+    if (N == 0) return PD_OK;
+    hipLaunchKernelGGL(up2x_ac_bwd_kernel, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(EW_T), 0, (hipStream_t)stream,
+                       (const float*)dout, (float*)da, N, H, W, C);
+    return pd::check_launch("pd_up2x_ac_bwd");
+}
+
+extern "C" int pd_relu_add(const void* x, const void* res, void* out, long n, int relu, void* stream) {
+    PD_REQUIRE(x && out && n >= 0 && n % 4 == 0 && pd::aligned16(x) && pd::aligned16(out) && pd::aligned16(res),
+               "pd_relu_add: bad arguments (element count must be a multiple of 4, pointers 16-byte aligned)");
+    if (n == 0) return PD_OK;
+    hipLaunchKernelGGL(relu_add_kernel, dim3(ew_grid(n / 4)), dim3(EW_T), 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)res, (float*)out, n / 4, relu);
+    return pd::check_launch("pd_relu_add");
 }
 
 extern "C" int pd_up_bwd_elu(const void* dout, long ld_d, const void* elu_y, void* da, int N, int H, int W, int Ca,

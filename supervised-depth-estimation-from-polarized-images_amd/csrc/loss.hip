@@ -586,7 +586,7 @@ __device__ __forceinline__ void smooth_fwd_body(float* sm, const float* __restri
         int x, y;
         const long t = divmod(i, w, x);
         const long n = divmod(t, h, y);
-        const float inv = 1.f / (mean[n] + 1e-7f);
+        const float inv = mean ? 1.f / (mean[n] + 1e-7f) : 1.f;     // mean == nullptr: the raw term (layers.get_smooth_loss)
         const float v = disp[i] * inv;
         const long ib = n * 3 * P, p = (long)y * w + x;
         float ex = 0.f, ey = 0.f;
@@ -638,7 +638,7 @@ __device__ __forceinline__ void smooth_bwd_g_body(double (&smd)[4], const float*
             int x, y;
             const long t = divmod(i, w, x);
             n = divmod(t, h, y);
-            const float inv = 1.f / (mean[n] + 1e-7f);
+            const float inv = mean ? 1.f / (mean[n] + 1e-7f) : 1.f;
             const float v = disp[i] * inv;
             const long ib = n * 3 * P, p = (long)y * w + x;
             auto sgn = [](float a) { return a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f); };
@@ -683,6 +683,7 @@ __device__ __forceinline__ void smooth_bwd_final_body(const float* __restrict__ 
     const long total = N * P;
     for (long i = bid * (long)LT + threadIdx.x; i < total; i += (long)nb * LT) {
         const long n = i / P;
+        if (!mean) { gdisp[i] = accumulate ? gdisp[i] + G[i] : G[i]; continue; }       // no normalisation: d/d disp = G
         const float me = mean[n] + 1e-7f;
         const float v = G[i] / me - (float)(gd_acc[n] / ((double)me * me * (double)P));
         gdisp[i] = accumulate ? gdisp[i] + v : v;
@@ -1021,9 +1022,9 @@ extern "C" int pd_sup_loss_bwd(const void* pred, const void* gt, const void* K, 
 
 extern "C" int pd_smooth_fwd(const void* disp, const void* img, void* mean, void* partial, void* edge_w, int N, int h, int w,
                              void* stream) {
-    PD_REQUIRE(disp && img && mean && partial && N > 0 && h > 1 && w > 1, "pd_smooth_fwd: bad arguments");
+    PD_REQUIRE(disp && img && partial && N > 0 && h > 1 && w > 1, "pd_smooth_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(image_mean_kernel, dim3(N), dim3(1024), 0, st, (const float*)disp, (float*)mean, h * w);
+    if (mean) hipLaunchKernelGGL(image_mean_kernel, dim3(N), dim3(1024), 0, st, (const float*)disp, (float*)mean, h * w);
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(lgrid((long)N * h * w)), dim3(LT), 0, st, (const float*)disp,
                        (const float*)img, (const float*)mean, (float*)partial, (float2*)edge_w, N, h, w);
     return pd::check_launch("pd_smooth_fwd");
@@ -1031,7 +1032,7 @@ extern "C" int pd_smooth_fwd(const void* disp, const void* img, void* mean, void
 
 extern "C" int pd_smooth_bwd(const void* disp, const void* img, const void* mean, const void* wts, const void* edge_w,
                              void* g_ws, void* gd_acc, void* gdisp, int N, int h, int w, int accumulate, void* stream) {
-    PD_REQUIRE(disp && img && mean && wts && g_ws && gd_acc && gdisp && N > 0 && h > 1 && w > 1, "pd_smooth_bwd: bad arguments");
+    PD_REQUIRE(disp && img && wts && g_ws && gd_acc && gdisp && N > 0 && h > 1 && w > 1, "pd_smooth_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(gd_acc, 0, sizeof(double) * N, st) != hipSuccess) return pd::fail(PD_ELAUNCH, "pd_smooth_bwd: memset");
     const unsigned grid = lgrid((long)N * h * w);

@@ -939,6 +939,43 @@ extern "C" int pd_polar_normals_from_xolp(const void* xolp, void* normals, const
     return pd::check_launch("pd_polar_normals_from_xolp");
 }
 
+namespace {
+// normals_vec.py:53-60 with torch's type promotion: a factor computed from an fp32 operand is evaluated in fp32 and then
+// promoted (cos(phi_f32) * sin(theta_f64) = double(cosf(phi)) * sin(theta))
+template <typename TP, typename TT, typename TO>
+__global__ __launch_bounds__(256) void calc_normals_kernel(const TP* __restrict__ phi, const TT* __restrict__ theta,
+                                                          TO* __restrict__ out, int B, long P) {
+    const long total = (long)B * P;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / P, p = i - b * P;
+        const TP ph = phi[i];
+        const TT th = theta[i];
+        const TO c = (TO)cos(ph), s = (TO)sin(ph), st = (TO)sin(th), ct = (TO)cos(th);
+        TO* o = out + b * 3 * P + p;
+        o[0] = c * st; o[P] = s * st; o[2 * P] = ct;
+    }
+}
+}  // namespace
+
+extern "C" int pd_polar_calc_normals(const void* phi, const void* theta, void* out, int B, long P, int phi_f64, int theta_f64,
+                                     void* stream) {
+    PD_REQUIRE(B >= 0 && P >= 0, "pd_polar_calc_normals: bad shape");
+    if ((long)B * P == 0) return PD_OK;
+    PD_REQUIRE(phi && theta && out, "pd_polar_calc_normals: null pointer");
+    const long total = (long)B * P;
+    const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 4096);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (phi_f64 && theta_f64)
+        hipLaunchKernelGGL((calc_normals_kernel<double, double, double>), dim3(grid), dim3(256), 0, st, (const double*)phi, (const double*)theta, (double*)out, B, P);
+    else if (phi_f64)
+        hipLaunchKernelGGL((calc_normals_kernel<double, float, double>), dim3(grid), dim3(256), 0, st, (const double*)phi, (const float*)theta, (double*)out, B, P);
+    else if (theta_f64)
+        hipLaunchKernelGGL((calc_normals_kernel<float, double, double>), dim3(grid), dim3(256), 0, st, (const float*)phi, (const double*)theta, (double*)out, B, P);
+    else
+        hipLaunchKernelGGL((calc_normals_kernel<float, float, float>), dim3(grid), dim3(256), 0, st, (const float*)phi, (const float*)theta, (float*)out, B, P);
+    return pd::check_launch("pd_polar_calc_normals");
+}
+
 extern "C" int pd_polar_theta(const void* rho, void* theta_d, void* theta_s1, void* theta_s2, void* bins,
                               const void* tables, size_t tables_bytes, long n, void* stream) {
     PD_REQUIRE(n >= 0, "pd_polar_theta: bad element count");

@@ -48,8 +48,8 @@ class Conv5x5(nn.Module):
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 5)
         self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x):
-        return PF.padded_conv(x, self.conv, 2, reflect=self.use_refl)
+    def forward(self, x, act=ops.ACT_NONE):
+        return PF.padded_conv(x, self.conv, 2, reflect=self.use_refl, act=act)
 
 
 class ConvBlock(nn.Module):
@@ -70,55 +70,33 @@ def upsample(x):
 
 
 def get_smooth_loss(disp, img):
-    """layers.py:452-465."""
-    grad_disp_x = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
-    grad_disp_y = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
-    grad_img_x = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
-    grad_img_y = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
-    return (grad_disp_x * torch.exp(-grad_img_x)).mean() + (grad_disp_y * torch.exp(-grad_img_y)).mean()
+    """layers.py:452-465 (edge-aware first-order smoothness of `disp` as given) on the K5 kernels, differentiable in disp."""
+    return PF.smooth_loss(disp, img)
 
 
 class SSIM(nn.Module):
-    """layers.py:468-499; constructed by the trainer, inactive under --depth_supervision_only."""
+    """layers.py:468-499 as fused HIP kernels, forward and backward (pd_ssim_fwd / pd_ssim_bwd); constructed by the trainer,
+    inactive under --depth_supervision_only."""
 
     def __init__(self):
         super().__init__()
-        self.pool = nn.AvgPool2d(3, 1)
-        self.refl = nn.ReflectionPad2d(1)
-        self.C1, self.C2 = 0.01 ** 2, 0.03 ** 2
+        self.C1, self.C2 = 0.01 ** 2, 0.03 ** 2       # (the kernels carry the same constants)
 
     def forward(self, x, y):
-        if x.is_cuda:
-            return ops.ssim(x, y)             # fused HIP kernels, forward and backward (pd_ssim_fwd / pd_ssim_bwd)
-        x, y = self.refl(x), self.refl(y)
-        mu_x, mu_y = self.pool(x), self.pool(y)
-        sigma_x = self.pool(x ** 2) - mu_x ** 2
-        sigma_y = self.pool(y ** 2) - mu_y ** 2
-        sigma_xy = self.pool(x * y) - mu_x * mu_y
-        n = (2 * mu_x * mu_y + self.C1) * (2 * sigma_xy + self.C2)
-        d = (mu_x ** 2 + mu_y ** 2 + self.C1) * (sigma_x + sigma_y + self.C2)
-        return torch.clamp((1 - n / d) / 2, 0, 1)
+        return ops.ssim(x, y)
 
 
 def compute_depth_errors(gt, pred):
-    """layers.py:539-557."""
-    thresh = torch.max((gt / pred), (pred / gt))
-    a1 = (thresh < 1.25).float().mean()
-    a2 = (thresh < 1.25 ** 2).float().mean()
-    a3 = (thresh < 1.25 ** 3).float().mean()
-    rmse = torch.sqrt(((gt - pred) ** 2).mean())
-    rmse_log = torch.sqrt(((torch.log(gt) - torch.log(pred)) ** 2).mean())
-    abs_rel = torch.mean(torch.abs(gt - pred) / gt)
-    sq_rel = torch.mean((gt - pred) ** 2 / gt)
-    return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+    """layers.py:539-557 on the device (pd_depth_metrics over all elements handed in, which the reference's callers have
+    masked already): (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3) as 0-dim tensors."""
+    m = ops.depth_metrics(gt.reshape(1, -1), pred.reshape(1, -1), 0.0, float("inf"))[0]
+    return tuple(m[i] for i in range(7))
 
 
 def compute_depth_errors_numpy(gt, pred):
-    """layers.py:559-577."""
-    thresh = np.maximum((gt / pred), (pred / gt))
-    a1, a2, a3 = (thresh < 1.25).mean(), (thresh < 1.25 ** 2).mean(), (thresh < 1.25 ** 3).mean()
-    rmse = np.sqrt(((gt - pred) ** 2).mean())
-    rmse_log = np.sqrt(((np.log(gt) - np.log(pred)) ** 2).mean())
-    abs_rel = np.mean(np.abs(gt - pred) / gt)
-    sq_rel = np.mean(((gt - pred) ** 2) / gt)
-    return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+    """layers.py:559-577: the same seven numbers for NumPy arrays (evaluation.py:215-288), as Python floats."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("compute_depth_errors_numpy runs on the MI355X; there is no CPU fallback")
+    vals = compute_depth_errors(torch.from_numpy(np.ascontiguousarray(gt, dtype=np.float32)).cuda(),
+                                torch.from_numpy(np.ascontiguousarray(pred, dtype=np.float32)).cuda())
+    return tuple(float(v) for v in vals)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from manydepth.layers import ConvBlock, Conv3x3
+from manydepth.layers import ConvBlock, Conv3x3, Conv5x5
 from polardepth import functional as PF
 from polardepth import ops
 
@@ -18,8 +18,6 @@ from polardepth import ops
 class DepthDecoder(nn.Module):
     def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True, uncertainty=False):
         super().__init__()
-        if uncertainty:
-            raise NotImplementedError("uncertainty heads are not on the supervised hot path")
         self.num_output_channels = num_output_channels
         self.use_skips = use_skips
         self.upsample_mode = 'nearest'      # attribute kept; like the reference it is unused (bilinear is applied)
@@ -36,16 +34,21 @@ class DepthDecoder(nn.Module):
             self.convs[("upconv", i, 1)] = ConvBlock(cin, self.num_ch_dec[i])
         for s in self.scales:
             self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], self.num_output_channels)
+        self.uncertainty = bool(uncertainty)
+        if self.uncertainty:            # depth_decoder.py:46-50: two 5x5 heads per scale, ModuleList entries 14.. in this order
+            for s in self.scales:
+                self.convs[("unc_conv", s)] = Conv5x5(self.num_ch_dec[s], self.num_output_channels)
+                self.convs[("unc_conv_color", s)] = Conv5x5(self.num_ch_dec[s], self.num_output_channels)
         self.decoder = nn.ModuleList(list(self.convs.values()))
         self.sigmoid = nn.Sigmoid()
-        self.uncertainty = False
 
     def forward(self, input_features):
         self.outputs = {}
         x = input_features[-1]
         # ActGrad mailboxes: the ELU derivative of every ConvBlock is applied by the kernel that produces its output
         # gradient (upsample gradient / disparity head), and the head sums the two gradients of upconv(i,1)'s output
-        fuse = PF.USE_ACT_FUSION and torch.is_grad_enabled()
+        # (with the uncertainty heads upconv(i,1)'s output has four consumers: plain autograd routes, off the supervised path)
+        fuse = PF.USE_ACT_FUSION and torch.is_grad_enabled() and not self.uncertainty
         pend = None
         for i in range(4, -1, -1):
             m0 = PF.ActGrad() if fuse else None
@@ -56,6 +59,9 @@ class DepthDecoder(nn.Module):
             x = self.convs[("upconv", i, 1)](x, act_mail=m1)
             if i in self.scales:
                 self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act=ops.ACT_SIGMOID, head_mail=m1)
+                if self.uncertainty:     # depth_decoder.py:71-73: sigmoid(Conv5x5(x)), the sigmoid in the conv epilogue
+                    self.outputs[("uncertainty", i)] = self.convs[("unc_conv", i)](x, act=ops.ACT_SIGMOID)
+                    self.outputs[("uncertainty_color", i)] = self.convs[("unc_conv_color", i)](x, act=ops.ACT_SIGMOID)
             pend = m1
         if fuse and len(self.outputs) > 1:
             # every head an ancestor of every output: a backward pass from a subset of the scales still runs all heads,

@@ -34,10 +34,6 @@ def rho_spec(rho, n):
 
 
 def calc_normals(phi, theta):
-    """normals_vec.py:53-60: N = (cos(phi) sin(theta), sin(phi) sin(theta), cos(theta)) on the GPU, [B,3,H,W]; the
-    dtype follows torch's promotion (fp32 phi with fp64 theta gives fp64, like the reference)."""
-    phi, theta = _device(phi), _device(theta)
-    N1 = (torch.cos(phi) * torch.sin(theta)).unsqueeze(dim=1)
-    N2 = (torch.sin(phi) * torch.sin(theta)).unsqueeze(dim=1)
-    N3 = torch.cos(theta).unsqueeze(dim=1)
-    return torch.cat((N1, N2, N3), dim=1)
+    """normals_vec.py:53-60: the unit normal of azimuth phi and zenith theta, [B,3,H,W] on the GPU (pd_polar_calc_normals);
+    the dtype follows torch's promotion there (fp32 phi with fp64 theta gives fp64)."""
+    return _polar.calc_normals(_device(phi), _device(theta))

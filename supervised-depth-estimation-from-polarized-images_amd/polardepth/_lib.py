@@ -34,6 +34,7 @@ SIGNATURES = {
     "pd_polar_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
     "pd_polar_normals_from_xolp": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     "pd_polar_theta": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _l, _vp]),
+    "pd_polar_calc_normals": (_i, [_vp, _vp, _vp, _i, _l, _i, _i, _vp]),
     "pd_conv2d_tile_m": (_i, [_l, _i]),
     "pd_conv2d_stats_rows": (_l, [_l, _i]),
     "pd_conv2d_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u]),
@@ -70,6 +71,9 @@ SIGNATURES = {
     "pd_up_bwd": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _vp]),
     "pd_up_bwd_elu": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_act_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+    "pd_up2x_ac_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_up2x_ac_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pd_relu_add": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "pd_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pd_reflect_fold_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pd_reflect_dgrad_border": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -639,23 +639,27 @@ class PaddedConvFn(torch.autograd.Function):
     step): general implicit-GEMM forward, data gradient on the padded grid + pd_reflect_fold_pad, general weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, reflect):
+    def forward(ctx, x, weight, bias, pad, reflect, act=ops.ACT_NONE):
         x = ops.as_nhwc(x)
         mode = ops.MODE_REFLECT if reflect else ops.MODE_ZERO
-        y = ops.conv2d_fwd(x, weight, bias, 1, pad, mode=mode)
-        ctx.geom = (pad, mode)
+        y = ops.conv2d_fwd(x, weight, bias, 1, pad, mode=mode, act=act)
+        ctx.geom = (pad, mode, act)
         ctx.params = (weight, bias)
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, y if act != ops.ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x, y = ctx.saved_tensors
         weight, bias = ctx.params
-        pad, mode = ctx.geom
+        pad, mode, act = ctx.geom
         N, Ci, H, W = x.shape
         Co = weight.shape[0]
         dy = dy.contiguous(memory_format=CL) if Co > 1 else dy.contiguous()
+        if act != ops.ACT_NONE:                 # the epilogue's activation (sigmoid of the uncertainty heads), through its output
+            dz = torch.empty_like(dy)
+            check(lib.pd_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), act, stream_ptr()), "pd_act_bwd")
+            dy = dz
         if weight.requires_grad:
             db = grad_buf(bias) if bias is not None and bias.requires_grad else None
             gw = grad_buf(weight)
@@ -671,11 +675,11 @@ class PaddedConvFn(torch.autograd.Function):
         for p in (weight, bias):
             if p is not None:
                 _ready(p)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def padded_conv(x, conv, pad, reflect=True):
-    return PaddedConvFn.apply(x, conv.weight, conv.bias, int(pad), bool(reflect))
+def padded_conv(x, conv, pad, reflect=True, act=ops.ACT_NONE):
+    return PaddedConvFn.apply(x, conv.weight, conv.bias, int(pad), bool(reflect), int(act))
 
 
 class UpCatFn(torch.autograd.Function):
@@ -1109,3 +1113,154 @@ def normals_pred_loss(pred, gt, K, min_depth, max_depth):
 def multiscale_loss(cfg, gt, K, disps, colors):
     out = MultiScaleLossFn.apply(cfg, gt, K, *disps, *colors)
     return out[0], list(out[1:])
+
+
+# ------------------------------------------------------------------ layers.get_smooth_loss as a function of its own
+class SmoothLossFn(torch.autograd.Function):
+    """layers.py:452-465 on the K5 kernels: mean |dx disp| e^{-|dx I|} + mean |dy disp| e^{-|dy I|} of the disparity AS GIVEN
+    (pd_smooth_fwd / pd_smooth_bwd with mean = NULL: no mean normalisation -- the caller of the reference function applies
+    it first, trainer.py:1256-1258).  Differentiable in disp; the image is data."""
+
+    @staticmethod
+    def forward(ctx, disp, img):
+        N, _, h, w = disp.shape
+        dev = disp.device
+        st = stream_ptr()
+        rows = lib.pd_loss_rows(N * h * w)
+        part = _f32(dev, rows, 2)
+        edge = _f32(dev, N, h, w, 2) if disp.requires_grad else None
+        check(lib.pd_smooth_fwd(ptr(disp), ptr(img), None, ptr(part), ptr(edge), N, h, w, st), "pd_smooth_fwd")
+        sx, sy = part.double().sum(0)                      # ordered fp64 sum of the per-workgroup partials
+        ctx.save_for_backward(disp, img, edge)
+        return (sx / (N * h * (w - 1)) + sy / (N * (h - 1) * w)).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, img, edge = ctx.saved_tensors
+        N, _, h, w = disp.shape
+        dev = disp.device
+        wts = torch.zeros(3, dtype=torch.float32, device=dev)
+        wts[2] = g.float()
+        gws = _f32(dev, N, h, w)
+        gacc = torch.empty(N, dtype=torch.float64, device=dev)
+        gd = torch.empty_like(disp)
+        check(lib.pd_smooth_bwd(ptr(disp), ptr(img), None, ptr(wts), ptr(edge), ptr(gws), ptr(gacc), ptr(gd), N, h, w, 0,
+                                stream_ptr()), "pd_smooth_bwd")
+        return gd, None
+
+
+def smooth_loss(disp, img):
+    if not (disp.is_cuda and img.is_cuda):
+        raise RuntimeError("get_smooth_loss runs on the MI355X; there is no CPU fallback")
+    if disp.shape[1] != 1 or img.shape[1] != 3 or disp.shape[2] < 2 or disp.shape[3] < 2:
+        raise ValueError(f"get_smooth_loss: disp [N,1,h,w] and img [N,3,h,w] expected, got {tuple(disp.shape)} / {tuple(img.shape)}")
+    return SmoothLossFn.apply(disp.float().contiguous(), img.float().contiguous())
+
+
+# ------------------------------------------------------------------ DPT decoder glue (manydepth/dpt/blocks.py; --train_dpt)
+class ConvBiasActFn(torch.autograd.Function):
+    """nn.Conv2d (zero padding, bias) with the activation of the NEXT module in its epilogue (ReLU: the residual units of
+    the DPT fusion blocks, blocks.py:289-300); backward through the activation output (pd_act_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act):
+        x = ops.as_nhwc(x)
+        y = ops.conv2d_fwd(x, weight, bias, stride, pad, act=act)
+        ctx.geom = (stride, pad, act)
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x, y if act != ops.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, bias = ctx.params
+        stride, pad, act = ctx.geom
+        dy = ops.as_nhwc(dy)
+        if act != ops.ACT_NONE:
+            dz = torch.empty_like(dy)
+            check(lib.pd_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), act, stream_ptr()), "pd_act_bwd")
+            dy = dz
+        if weight.requires_grad:
+            db = grad_buf(bias) if bias is not None and bias.requires_grad else None
+            gw = grad_buf(weight)
+            _wgrad_async(x, dy, lambda: ops.conv2d_wgrad(x, dy, weight.shape, stride, pad, dw=gw, dbias=db, accumulate=True))
+        dx = ops.conv2d_dgrad(dy, weight, (x.shape[2], x.shape[3]), stride, pad) if ctx.needs_input_grad[0] else None
+        for p in (weight, bias):
+            if p is not None:
+                _ready(p)
+        return dx, None, None, None, None, None
+
+
+def conv_bias_act(x, conv, act=ops.ACT_NONE):
+    return ConvBiasActFn.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], int(act))
+
+
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = ops.as_nhwc(x)
+        y = torch.empty_like(x)
+        check(lib.pd_relu_add(ptr(x), None, ptr(y), x.numel(), 1, stream_ptr()), "pd_relu_add")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = ops.as_nhwc(dy)
+        dz = torch.empty_like(dy)
+        check(lib.pd_act_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), ops.ACT_RELU, stream_ptr()), "pd_act_bwd")
+        return dz
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = ops.as_nhwc(a), ops.as_nhwc(b)
+        y = torch.empty_like(a)
+        check(lib.pd_relu_add(ptr(a), ptr(b), ptr(y), a.numel(), 0, stream_ptr()), "pd_relu_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class Upsample2xAlignedFn(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) (blocks.py:138-172, 375-377)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = ops.as_nhwc(x)
+        N, C, H, W = x.shape
+        y = ops.empty_nhwc(N, C, 2 * H, 2 * W, x.device)
+        check(lib.pd_up2x_ac_fwd(ptr(x), ptr(y), N, H, W, C, stream_ptr()), "pd_up2x_ac_fwd")
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = ctx.shape
+        dy = ops.as_nhwc(dy)
+        dx = ops.empty_nhwc(N, C, H, W, dy.device)
+        check(lib.pd_up2x_ac_bwd(ptr(dy), ptr(dx), N, H, W, C, stream_ptr()), "pd_up2x_ac_bwd")
+        return dx
+
+
+def _need_cuda4(x, what):
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.shape[1] % 4 == 0):
+        raise RuntimeError(f"{what} needs a CUDA(HIP) NCHW tensor with a multiple of 4 channels; there is no CPU fallback")
+    return x.float()
+
+
+def relu(x):
+    return ReluFn.apply(_need_cuda4(x, "relu"))
+
+
+def add(a, b):
+    return AddFn.apply(_need_cuda4(a, "add"), _need_cuda4(b, "add"))
+
+
+def upsample2x_aligned(x):
+    return Upsample2xAlignedFn.apply(_need_cuda4(x, "upsample2x_aligned"))

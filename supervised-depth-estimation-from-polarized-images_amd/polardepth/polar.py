@@ -149,3 +149,22 @@ def theta_from_rho(rho, n=1.5, want=("d", "s1", "s2"), want_bins=False):
     if want_bins:
         out["bins"] = bins
     return out
+
+
+def calc_normals(phi, theta):
+    """normals_vec.py:53-60 on the GPU (pd_polar_calc_normals): phi, theta of one shape [B, ...] -> [B,3,...]; fp64 when
+    either operand is fp64 (a factor of an fp32 operand is evaluated in fp32 and promoted, as torch does there)."""
+    if not (phi.is_cuda and theta.is_cuda):
+        raise RuntimeError("calc_normals needs CUDA(HIP) tensors; there is no CPU fallback")
+    if phi.shape != theta.shape:
+        raise ValueError(f"calc_normals: phi {tuple(phi.shape)} and theta {tuple(theta.shape)} must have one shape")
+    conv = lambda t: t.contiguous() if t.dtype in (torch.float32, torch.float64) else t.float().contiguous()
+    phi, theta = conv(phi), conv(theta)
+    B = phi.shape[0] if phi.dim() > 0 else 1
+    P = phi.numel() // max(B, 1)
+    f64 = phi.dtype == torch.float64 or theta.dtype == torch.float64
+    out = torch.empty((B, 3) + tuple(phi.shape[1:]), dtype=torch.float64 if f64 else torch.float32, device=phi.device)
+    with torch.cuda.device(phi.device):
+        check(lib.pd_polar_calc_normals(ptr(phi), ptr(theta), ptr(out), B, P, int(phi.dtype == torch.float64),
+                                        int(theta.dtype == torch.float64), stream_ptr()), "pd_polar_calc_normals")
+    return out

@@ -5,7 +5,7 @@ Runs only in the build container (needs /root/reference, which never travels to
 the GPU box).  The outputs are data only (.npz of inputs + expected outputs);
 no reference source text is stored.  Re-run with:
 
-    python tests/golden/make_golden.py [group ...]      # groups: polar stokes nets loss options
+    python tests/golden/make_golden.py [group ...]      # groups: polar stokes nets loss options dpt unc
 
 How the reference is imported:
   * polarisation.xolp, manydepth.layers, manydepth.normals_vec import directly;
@@ -385,7 +385,91 @@ def make_options():
     print("options golden written:", len(defaults), "flags")
 
 
-GROUPS = {"polar": make_polar, "stokes": make_stokes, "nets": make_nets, "loss": make_loss, "options": make_options}
+# ------------------------------------------------------------------ group: dpt (fusion block of the DPT decoder)
+def make_dpt():
+    """G8 -- manydepth/dpt/blocks.py: FeatureFusionBlock_custom / ResidualConvUnit_custom / Interpolate exactly as
+    dpt/models.py:15-23 builds them (activation nn.ReLU(False), bn = False, expand = False, align_corners = True): outputs,
+    input gradients and parameter gradients of the two-input form (refinenet1..3) and the one-input form (refinenet4), and
+    of the output head's Interpolate.  blocks.py is loaded by file path; its `.vit` sibling (timm ViT factories, absent
+    here) is an empty stub -- the fusion blocks do not touch it."""
+    from synth_weights import fill_state_dict
+    _ref_imports()
+    import manydepth  # noqa: F401
+    pkg = types.ModuleType("manydepth.dpt")
+    pkg.__path__ = [os.path.join(REF, "manydepth", "dpt")]
+    sys.modules["manydepth.dpt"] = pkg
+    vit = types.ModuleType("manydepth.dpt.vit")
+    for name in ("_make_pretrained_vitb_rn50_384", "_make_pretrained_vitl16_384", "_make_pretrained_vitb16_384", "forward_vit"):
+        setattr(vit, name, None)
+    sys.modules["manydepth.dpt.vit"] = vit
+    blocks = _load_by_path("manydepth.dpt.blocks", "manydepth/dpt/blocks.py")
+    import torch.nn as nn
+    out = {}
+    g = torch.Generator().manual_seed(8)
+    F_, N, H, W = 64, 2, 12, 16
+    for tag, n_in in (("two", 2), ("one", 1)):
+        blk = blocks.FeatureFusionBlock_custom(F_, nn.ReLU(False), deconv=False, bn=False, expand=False, align_corners=True)
+        fill_state_dict(blk, 0, prefix="fusion.")
+        xs = [torch.randn(N, F_, H, W, generator=g).requires_grad_(True) for _ in range(n_in)]
+        y = blk(*xs)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        out[f"{tag}.out"] = y.detach().numpy(); out[f"{tag}.gout"] = gy.numpy()
+        for i, x in enumerate(xs):
+            out[f"{tag}.x{i}"] = x.detach().numpy(); out[f"{tag}.gx{i}"] = x.grad.numpy()
+        for k, v in _grad_summary(blk).items():
+            out[f"{tag}.grad.{k}"] = v.numpy()
+    rcu = blocks.ResidualConvUnit_custom(F_, nn.ReLU(False), False)
+    fill_state_dict(rcu, 0, prefix="fusion.resConfUnit2.")
+    x = torch.randn(N, F_, H, W, generator=g).requires_grad_(True)
+    y = rcu(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out.update({"rcu.x": x.detach().numpy(), "rcu.out": y.detach().numpy(), "rcu.gout": gy.numpy(), "rcu.gx": x.grad.numpy()})
+    ip = blocks.Interpolate(scale_factor=2, mode="bilinear", align_corners=True)
+    x = torch.randn(N, 32, 7, 9, generator=g).requires_grad_(True)
+    y = ip(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out.update({"interp.x": x.detach().numpy(), "interp.out": y.detach().numpy(), "interp.gout": gy.numpy(), "interp.gx": x.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, "g8_dpt_fusion.npz"), **out)
+    print("dpt golden written:", len(out), "arrays")
+
+
+# ------------------------------------------------------------------ group: unc (DepthDecoder with uncertainty heads)
+def make_unc():
+    """G9 -- depth_decoder.py:46-50,71-73: DepthDecoder(uncertainty=True) on the feature maps of G4 (dec.feat.*): the twelve
+    output maps, the gradients of the input features and of the parameters (heads in full, the rest sampled as in G4)."""
+    from synth_weights import fill_state_dict
+    _, dec = ref_networks()
+    g4 = np.load(os.path.join(OUT, "g4_nets.npz"))
+    feats = [torch.from_numpy(g4[f"dec.feat.{i}"]) for i in range(5)]
+    dd = dec.DepthDecoder(np.array([64, 64, 128, 256, 512]), range(4), uncertainty=True)
+    fill_state_dict(dd, 0, prefix="mono_depth.")
+    fg = [f.clone().requires_grad_(True) for f in feats]
+    res = dd(fg)
+    out, obj = {}, 0
+    for j, kind in enumerate(("disp", "uncertainty", "uncertainty_color")):
+        for s in range(4):
+            t = res[(kind, s)]
+            out[f"{kind}.{s}"] = t.detach().clone()
+            obj = obj + (t * torch.randn(t.shape, generator=torch.Generator().manual_seed(300 + 10 * j + s))).sum()
+    obj.backward()
+    for i, f in enumerate(fg):
+        out[f"featgrad.{i}"] = f.grad.clone()
+    for k, g in _grad_summary(dd).items():
+        if g.numel() <= 20000:
+            out[f"grad.{k}"] = g
+        else:
+            out[f"gradsample.{k}"] = g.flatten()[::max(1, g.numel() // 4096)].clone()
+            out[f"gradabssum.{k}"] = g.abs().sum()
+    out["keys"] = np.array(list(dd.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "g9_decoder_uncertainty.npz"), **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()})
+    print("uncertainty-decoder golden written:", len(out), "arrays")
+
+
+GROUPS = {"unc": make_unc, "polar": make_polar, "stokes": make_stokes, "nets": make_nets, "loss": make_loss, "options": make_options,
+          "dpt": make_dpt}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

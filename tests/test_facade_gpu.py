@@ -141,3 +141,33 @@ def test_supervised_normals_loss_honours_the_callers_mask(tmp_path):
     ref = ol.normals_loss(gt, pred, K, masks["range"]).item()
     got = tr.compute_supervised_normals_losses(gt.cuda(), pred.cuda(), K.cuda()).item()
     assert abs(got - ref) <= 1e-5 * abs(ref)
+
+
+def test_layers_helpers_run_on_the_kernels_and_match_the_reference_fixture():
+    """manydepth.layers.get_smooth_loss / compute_depth_errors / compute_depth_errors_numpy (reference layers.py:452-465,
+    539-577) are served by pd_smooth_fwd / pd_smooth_bwd (mean = NULL) and pd_depth_metrics: values against fixture G5
+    (outputs of the reference's own functions), the smoothness gradient against autograd of the formula on the CPU."""
+    import os
+    from conftest import ROOT
+    from manydepth import layers
+    G5 = np.load(os.path.join(ROOT, "tests", "golden", "g5_loss.npz"))
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    disp, img = T(G5["smooth.disp"]).float(), T(G5["ssim.x"]).float()
+    d = disp.cuda().requires_grad_(True)
+    out = layers.get_smooth_loss(d, img.cuda())
+    assert out.dim() == 0 and abs(out.item() - float(G5["smooth.out"])) <= 1e-6 * abs(float(G5["smooth.out"])) + 1e-9
+    out.backward()
+    dc = disp.clone().requires_grad_(True)
+    gx = (dc[:, :, :, :-1] - dc[:, :, :, 1:]).abs() * torch.exp(-(img[:, :, :, :-1] - img[:, :, :, 1:]).abs().mean(1, keepdim=True))
+    gy = (dc[:, :, :-1, :] - dc[:, :, 1:, :]).abs() * torch.exp(-(img[:, :, :-1, :] - img[:, :, 1:, :]).abs().mean(1, keepdim=True))
+    (gx.mean() + gy.mean()).backward()
+    assert (d.grad.cpu() - dc.grad).abs().max().item() <= 1e-6 * dc.grad.abs().max().item() + 1e-10
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layers.get_smooth_loss(disp, img)
+    gt, pred = T(G5["err.gt"]).float(), T(G5["err.pred"]).float()
+    want = np.asarray(G5["err.out"], dtype=np.float64)
+    got = torch.stack(layers.compute_depth_errors(gt.cuda(), pred.cuda())).cpu().double().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(np.array(layers.compute_depth_errors_numpy(gt.numpy(), pred.numpy())), want, rtol=1e-5, atol=1e-7)
+    with pytest.raises(RuntimeError):
+        layers.SSIM()(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))          # no CPU branch

@@ -440,3 +440,98 @@ def test_bf16_attention_pipelined_kernels(shape, kind):
     _close(o, ref.detach().float(), 1e-2, "bf16 attention fwd")
     for name, a, b in (("dq", qc, qr), ("dk", kc, kr), ("dv", vc, vr)):
         _close(a.grad, b.grad.float(), 2e-2, "bf16 attention " + name)
+
+
+def test_dpt_fusion_block_matches_the_reference_fixture(golden_dir):
+    """manydepth.dpt.blocks (reference manydepth/dpt/blocks.py:138-172, 255-383; dpt/models.py:15-23) against
+    g8_dpt_fusion.npz -- outputs of the reference's own FeatureFusionBlock_custom / ResidualConvUnit_custom / Interpolate with
+    the seeded weights of tests/golden/synth_weights.py: outputs, input gradients and parameter gradients of the two-input
+    and one-input forms (fp32: 2e-5 of the scale forward, 1e-4 backward)."""
+    import os
+    import sys
+    import numpy as np
+    import torch.nn as nn
+    sys.path.insert(0, golden_dir)
+    from synth_weights import fill_state_dict
+    from manydepth.dpt import blocks
+    from polardepth import functional as PF
+    g = np.load(os.path.join(golden_dir, "g8_dpt_fusion.npz"))
+    T = lambda k: torch.from_numpy(g[k])
+
+    def close(got, want, tol, what):
+        sc = want.abs().max().item() + 1e-12
+        err = (got.detach().cpu() - want).abs().max().item()
+        assert err <= tol * sc, f"{what}: {err:.3e} vs scale {sc:.3e}"
+
+    for tag, n_in in (("two", 2), ("one", 1)):
+        blk = blocks.FeatureFusionBlock_custom(64, nn.ReLU(False), deconv=False, bn=False, expand=False, align_corners=True)
+        want_keys = [k[len(tag) + 6:] for k in g.files if k.startswith(tag + ".grad.")]
+        if tag == "two":
+            assert sorted(dict(blk.named_parameters())) == sorted(want_keys)   # the reference's state_dict keys
+        fill_state_dict(blk, 0, prefix="fusion.")
+        blk.cuda()
+        xs = [T(f"{tag}.x{i}").cuda().requires_grad_(True) for i in range(n_in)]
+        y = blk(*xs)
+        close(y, T(f"{tag}.out"), 2e-5, f"{tag}: output")
+        y.backward(T(f"{tag}.gout").cuda())
+        PF.sync_wgrad_stream()
+        torch.cuda.synchronize()
+        for i, x in enumerate(xs):
+            close(x.grad, T(f"{tag}.gx{i}"), 1e-4, f"{tag}: d x{i}")
+        for k, p in blk.named_parameters():
+            if tag == "one" and k.startswith("resConfUnit1."):
+                assert p.grad is None or p.grad.abs().max().item() == 0     # unused with one input, as in the reference
+                continue
+            close(p.grad, T(f"{tag}.grad.{k}"), 1e-4, f"{tag}: grad {k}")
+    rcu = blocks.ResidualConvUnit_custom(64, nn.ReLU(False), False)
+    fill_state_dict(rcu, 0, prefix="fusion.resConfUnit2.")
+    rcu.cuda()
+    x = T("rcu.x").cuda().requires_grad_(True)
+    y = rcu(x)
+    close(y, T("rcu.out"), 2e-5, "rcu: output")
+    y.backward(T("rcu.gout").cuda())
+    close(x.grad, T("rcu.gx"), 1e-4, "rcu: dx")
+    ip = blocks.Interpolate(scale_factor=2, mode="bilinear", align_corners=True)
+    x = T("interp.x").cuda().requires_grad_(True)
+    y = ip(x)
+    close(y, T("interp.out"), 2e-6, "interpolate: output")
+    y.backward(T("interp.gout").cuda())
+    close(x.grad, T("interp.gx"), 2e-6, "interpolate: dx")
+    with pytest.raises(NotImplementedError):
+        blocks.FeatureFusionBlock_custom(64, nn.ReLU(False), bn=True)
+
+
+def test_depth_decoder_with_uncertainty_heads_matches_reference(golden_dir):
+    """DepthDecoder(uncertainty=True) (depth_decoder.py:46-50,71-73: two Conv5x5 + sigmoid heads per scale, ModuleList entries
+    14..21) against g9_decoder_uncertainty.npz -- outputs of the reference's own class on the feature maps of G4: the twelve
+    output maps, feature gradients and parameter gradients; state_dict keys in the reference's order."""
+    import os
+    from manydepth import networks
+    from polardepth import functional as PF
+    G9 = np.load(os.path.join(golden_dir, "g9_decoder_uncertainty.npz"))
+    feats = [T(G4[f"dec.feat.{i}"]).cuda().requires_grad_(True) for i in range(5)]
+    dd = networks.DepthDecoder(np.array([64, 64, 128, 256, 512]), range(4), uncertainty=True)
+    assert list(dd.state_dict().keys()) == [str(k) for k in G9["keys"]]
+    fill_state_dict(dd, 0, prefix="mono_depth.")
+    dd.cuda()
+    res = dd(feats)
+    assert len(res) == 12
+    obj = 0
+    for j, kind in enumerate(("disp", "uncertainty", "uncertainty_color")):
+        for s in range(4):
+            t = res[(kind, s)]
+            _close(t, T(G9[f"{kind}.{s}"]), FWD_TOL, f"{kind}{s}")
+            obj = obj + (t * torch.randn(t.shape, generator=torch.Generator().manual_seed(300 + 10 * j + s)).cuda()).sum()
+    obj.backward()
+    PF.sync_wgrad_stream()
+    torch.cuda.synchronize()
+    for i, f in enumerate(feats):
+        _close(f.grad, T(G9[f"featgrad.{i}"]), GRAD_TOL, f"featgrad{i}")
+    n = 0
+    for k, p in dd.named_parameters():
+        if f"grad.{k}" in G9:
+            _close(p.grad, T(G9[f"grad.{k}"]), GRAD_TOL, k); n += 1
+        elif f"gradsample.{k}" in G9:
+            g = p.grad.cpu().contiguous().flatten()
+            _close(g[::max(1, g.numel() // 4096)], T(G9[f"gradsample.{k}"]), GRAD_TOL, k); n += 1
+    assert n == 28 + 16

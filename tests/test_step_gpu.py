@@ -304,10 +304,13 @@ def test_reference_format_checkpoint_loads_and_continues_like_torch_adam(tmp_pat
 
 def test_evaluation_runs_on_the_device_with_per_material_metrics(tmp_path, capsys):
     """manydepth.evaluation.Evaluation (evaluation.py:120-288): forward in eval mode + per-material metrics reduced by
-    pd_depth_metrics; the device numbers equal the reference's NumPy loop (compute_depth_errors_numpy) on the same
-    predictions."""
+    pd_depth_metrics; the device numbers equal the reference's per-image loop (evaluation.py:215-288 with
+    compute_depth_errors, restated in oracle/losses.py and pinned by fixture G5) on the same predictions."""
     from manydepth.evaluation import Evaluation, _MATERIAL_GREY
-    from manydepth.layers import compute_depth_errors_numpy
+    from oracle import losses as ol
+
+    def compute_depth_errors_numpy(gt, pred):
+        return [float(v) for v in ol.compute_depth_errors(torch.from_numpy(gt), torch.from_numpy(pred))]
     with pytest.raises(FileNotFoundError):
         Evaluation(data_path=str(tmp_path / "missing"))
     ev = Evaluation(data_path="synthetic", height=64, width=96, batch_size=4)
