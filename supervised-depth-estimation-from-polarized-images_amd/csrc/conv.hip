@@ -2102,15 +2102,17 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
     const unsigned m0_d = lds0 + (unsigned)wave * 8 * D_ROW, m0_x = lds0 + 2 * D_BYTES + (unsigned)wave * 8 * X_ROW;
 
     // dY pieces of chunk s_qd (four pixels each; rows >= nrows read as zero through the per-instruction descriptor)
-    auto load_d = [&](auto dst_tag) {
+    auto load_d_piece = [&](auto dst_tag, auto p_tag) {
         constexpr unsigned DST = decltype(dst_tag)::value;
-#pragma unroll
-        for (int P = 0; P < 2; ++P) {
-            const int r0 = WG_MC * s_qd + 8 * wave + 4 * P, left = nrows - r0;
-            const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy0 + (long)r0 * a.ldd, left > 0 ? (unsigned)(left * (int)a.ldd) * 4u : 0u);
-            dma16s(rd, m0_d + DST * D_BYTES + P * 4 * D_ROW, vd, 0u);
-        }
-        ++s_qd;
+        constexpr int P = decltype(p_tag)::value;
+        const int r0 = WG_MC * s_qd + 8 * wave + 4 * P, left = nrows - r0;
+        const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy0 + (long)r0 * a.ldd, left > 0 ? (unsigned)(left * (int)a.ldd) * 4u : 0u);
+        dma16s(rd, m0_d + DST * D_BYTES + P * 4 * D_ROW, vd, 0u);
+        if constexpr (P == 1) ++s_qd;
+    };
+    auto load_d = [&](auto dst_tag) {
+        load_d_piece(dst_tag, std::integral_constant<int, 0>{});
+        load_d_piece(dst_tag, std::integral_constant<int, 1>{});
     };
     // X piece J (one pixel pair) of the chunk the scalar pixel state points at
     auto load_x = [&](auto dst_tag, auto piece_tag) {
@@ -2149,33 +2151,37 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
         }
     };
 
-    // the four pairs of a chunk (ROW8: they share an output row)
-    auto load_x_all = [&](auto dst_tag) {
+    // the four pairs of a chunk (ROW8: they share an output row: one row class, the pair's column class per piece, one
+    // 32-pixel advance behind the last piece)
+    auto load_x_piece = [&](auto dst_tag, auto j_tag) {
+        constexpr int J = decltype(j_tag)::value;
         if constexpr (ROW8) {
             constexpr unsigned DST = decltype(dst_tag)::value;
             const int ch = min(s_oh, ua.nb) + max(s_oh - (a.Ho - ua.nb) + 1, 0);
             const unsigned dead = s_p < nrows ? 0u : 31u;                    // (slices end on 8-pixel boundaries)
-            const int pw0 = s_ow >> 1, pwe = (a.Wo >> 1) - ua.nbw;
+            const int pw = (s_ow >> 1) + J, pwe = (a.Wo >> 1) - ua.nbw;
+            const int cw = min(pw, ua.nbw) + max(pw - pwe + 1, 0);
+            const unsigned bad = __builtin_amdgcn_ubfe(xmask, (unsigned)(ch * ncw + cw) | dead, 1u);
+            dma16s(rx, m0_x + DST * X_BYTES + J * 2 * X_ROW, (bad << 31) + vx, (unsigned)(s_soff + J * 2 * st_w4));
+            if constexpr (J == 3) {
+                s_p += WG_MC; s_ow += WG_MC; s_soff += WG_MC * st_w4;
 #pragma unroll
-            for (int J = 0; J < 4; ++J) {
-                const int cw = min(pw0 + J, ua.nbw) + max(pw0 + J - pwe + 1, 0);
-                const unsigned bad = __builtin_amdgcn_ubfe(xmask, (unsigned)(ch * ncw + cw) | dead, 1u);
-                dma16s(rx, m0_x + DST * X_BYTES + J * 2 * X_ROW, (bad << 31) + vx, (unsigned)(s_soff + J * 2 * st_w4));
-            }
-            s_p += WG_MC; s_ow += WG_MC; s_soff += WG_MC * st_w4;
-#pragma unroll
-            for (int w = 0; w < 3; ++w) {              // Wo >= 14 (host check): 32 columns wrap at most three times
-                const int ow0 = s_ow;
-                s_ow = ow0 >= a.Wo ? ow0 - a.Wo : ow0;
-                s_soff += ow0 >= a.Wo ? d_row4 : 0;
-                const int oh1 = ow0 >= a.Wo ? s_oh + 1 : s_oh;
-                s_soff += oh1 == a.Ho ? d_img4 : 0;
-                s_oh = oh1 == a.Ho ? 0 : oh1;
+                for (int w = 0; w < 3; ++w) {          // Wo >= 14 (host check): 32 columns wrap at most three times
+                    const int ow0 = s_ow;
+                    s_ow = ow0 >= a.Wo ? ow0 - a.Wo : ow0;
+                    s_soff += ow0 >= a.Wo ? d_row4 : 0;
+                    const int oh1 = ow0 >= a.Wo ? s_oh + 1 : s_oh;
+                    s_soff += oh1 == a.Ho ? d_img4 : 0;
+                    s_oh = oh1 == a.Ho ? 0 : oh1;
+                }
             }
         } else {
-            load_x(dst_tag, std::integral_constant<int, 0>{}); load_x(dst_tag, std::integral_constant<int, 1>{});
-            load_x(dst_tag, std::integral_constant<int, 2>{}); load_x(dst_tag, std::integral_constant<int, 3>{});
+            load_x(dst_tag, j_tag);
         }
+    };
+    auto load_x_all = [&](auto dst_tag) {
+        load_x_piece(dst_tag, std::integral_constant<int, 0>{}); load_x_piece(dst_tag, std::integral_constant<int, 1>{});
+        load_x_piece(dst_tag, std::integral_constant<int, 2>{}); load_x_piece(dst_tag, std::integral_constant<int, 3>{});
     };
 
     // ---- fragment / split addresses: lane -> (index inside a 32-wide block = lane % 32, pixel half = lane / 32); the eight
@@ -2197,11 +2203,24 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
     char* lds_c = reinterpret_cast<char*>(smem_all);
 
     typedef float accv_t __attribute__((ext_vector_type(16)));
-    accv_t acc[2];
+    accv_t acc[2], acc_sum[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; acc_sum[t][r] = 0.f; }
+    // The bf16 MFMA aligns its sixteen products and the accumulator by TRUNCATION: a bias of about -2^-32 of the largest
+    // addend per instruction, negligible for a forward convolution (600 instructions per output) but proportional to
+    // instructions x |accumulator| here, where a slice contracts thousands of pixels (12 instructions per chunk and
+    // accumulator; 200 chunks per slice at batch 16).  Every FLUSH chunks the MFMA accumulators are added to a second
+    // fp32 set (round to nearest: unbiased) and restart from zero, so the truncated quantity stays ~sqrt(FLUSH / chunks) of
+    // its final size: 32 adds + 32 moves per 8 chunks next to their 864 split instructions.
+    constexpr int FLUSH = 8;
+    auto flush = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc_sum[t][r] += acc[t][r]; acc[t][r] = 0.f; }
+    };
     float bsum = 0.f;
     const bool do_bias = BIAS && a.bpart != nullptr && kt == 0;
     auto bf = [](u32x4 v) { return __builtin_bit_cast(x3::bf16x8, v); };
@@ -2224,8 +2243,16 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
     auto chunk = [&](auto buf_tag) {
         constexpr unsigned BUF = decltype(buf_tag)::value, NXT = BUF ^ 1;
         const std::integral_constant<unsigned, NXT> nxt{};
-        load_x_all(nxt);
-        load_d(buf_tag);                                   // chunk q + 2 into the slot whose chunk q was split during chunk q - 1
+        // The six LDS-DMA pieces of a chunk: at its head, or (SPREAD) one behind each of the first six MFMAs.  After the
+        // barrier all eight waves of a CU stand at their chunk heads together: six back-to-back issues per wave are a phase
+        // in which nobody feeds the matrix pipe; threaded in, each issue rides in the shadow of the wave's own MFMA.
+        // (round 4, same box: 3x3x64 @256x320 114 -> 123 TF, @128x160 108 -> 126, 5x5x64 @256x320 144 -> 155, 5x5 256 -> 512
+        //  @32x40 139 -> 148 together with the lean walker on every plane: profiles/r04_wgrad_variants.log)
+        constexpr bool SPREAD = true;
+        if (!SPREAD || !active) {
+            load_x_all(nxt);
+            load_d(buf_tag);                               // chunk q + 2 into the slot whose chunk q was split during chunk q - 1
+        }
         if (!active) {                                     // (wave-uniform) no valid k column: only its share of the dY split
             split_d(nxt);
             dma_wait();
@@ -2259,12 +2286,16 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
 #define PD_SB __builtin_amdgcn_sched_barrier(0);
         x3::sp_h<0>(x0, t0); x3::sp_h<1>(x0, t0); x3::sp_h<2>(x0, t0); x3::sp_h<3>(x0, t0);
         PD_SB
-        mm(t0, PD_I(0), PD_I(0)); x3::sp_m<0>(x0, t0); PD_SB
-        mm(t0, PD_I(0), PD_I(1)); x3::sp_m<1>(x0, t0); PD_SB
-        mm(t0, PD_I(0), PD_I(2)); x3::sp_m<2>(x0, t0); PD_SB
-        mm(t0, PD_I(0), PD_I(3)); x3::sp_m<3>(x0, t0); PD_SB
-        mm(t0, PD_I(0), PD_I(4)); x3::sp_h<0>(dv, td); x3::sp_h<1>(dv, td); x3::sp_h<2>(dv, td); x3::sp_h<3>(dv, td); PD_SB
-        mm(t0, PD_I(0), PD_I(5)); x3::sp_m<0>(dv, td); PD_SB
+#define PD_XP(j) if constexpr (SPREAD) load_x_piece(nxt, PD_I(j));
+#define PD_DP(j) if constexpr (SPREAD) load_d_piece(buf_tag, PD_I(j));
+        mm(t0, PD_I(0), PD_I(0)); x3::sp_m<0>(x0, t0); PD_XP(0) PD_SB
+        mm(t0, PD_I(0), PD_I(1)); x3::sp_m<1>(x0, t0); PD_XP(1) PD_SB
+        mm(t0, PD_I(0), PD_I(2)); x3::sp_m<2>(x0, t0); PD_XP(2) PD_SB
+        mm(t0, PD_I(0), PD_I(3)); x3::sp_m<3>(x0, t0); PD_XP(3) PD_SB
+        mm(t0, PD_I(0), PD_I(4)); x3::sp_h<0>(dv, td); x3::sp_h<1>(dv, td); x3::sp_h<2>(dv, td); x3::sp_h<3>(dv, td); PD_DP(0) PD_SB
+        mm(t0, PD_I(0), PD_I(5)); x3::sp_m<0>(dv, td); PD_DP(1) PD_SB
+#undef PD_XP
+#undef PD_DP
         mm(t0, PD_I(0), PD_I(6)); x3::sp_l<0>(t0); x3::sp_h<0>(x1, t1); PD_SB
         mm(t0, PD_I(0), PD_I(7)); x3::sp_l<1>(t0); x3::sp_h<1>(x1, t1); PD_SB
         mm(t0, PD_I(0), PD_I(8)); x3::sp_l<2>(t0); x3::sp_h<2>(x1, t1); PD_SB
@@ -2308,7 +2339,9 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
     for (int q = 0; q < nchunks; q += 2) {
         chunk(std::integral_constant<unsigned, 0>{});
         if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
+        if ((q & (FLUSH - 2)) == FLUSH - 2) flush();       // (wave-uniform; q is even)
     }
+    flush();
 
     // C/D layout: col = lane % 32 -> k; row -> co: (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -2317,7 +2350,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * fk;
-            if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc[blk][r];
+            if (co < a.Co && k < a.K) a.part[((long)s * a.Co + co) * a.K + k] = acc_sum[blk][r];
         }
     }
     if constexpr (BIAS) {
@@ -2511,10 +2544,11 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
                 return e;
             }();
             PD_REQUIRE(lds_ok == hipSuccess, "pd_conv2d_wgrad: cannot reserve %u bytes of LDS", x3c::LDS_BYTES);
-            // The lean walker pays on the small planes (3x3x256 @32x40: 133 -> 145 TF, 5x5 128 -> 256 @64x80: 159 -> 171) and
-            // loses on the large ones (5x5x64 @256x320: 148 -> 134; its four loads leave back to back instead of ~40 scalar
-            // instructions apart): planes of up to 8192 pixels take it.
-            const bool row8 = Wo % 8 == 0 && a.mper % 8 == 0 && a.M % 8 == 0 && (long)Ho * Wo <= 8192;
+            // The lean walker (one row class and one 32-pixel advance per chunk: 5 scalar instructions per MFMA instead of 8)
+            // whenever the eight pixels a wave stages cannot straddle an output row.  (Round 3 kept it off the large planes,
+            // where its four loads left back to back at the chunk head: 148 -> 134 TF on 5x5x64 @256x320; with the pieces
+            // threaded behind the chunk's first MFMAs it wins there too: 144 -> 155.)
+            const bool row8 = Wo % 8 == 0 && a.mper % 8 == 0 && a.M % 8 == 0;
             if (mode == MODE_REFLECT) {
                 if (dbias) hipLaunchKernelGGL((conv_wgrad_x3c_kernel<true, false, true>), grid, block, x3c::LDS_BYTES, st, ua);
                 else hipLaunchKernelGGL((conv_wgrad_x3c_kernel<false, false, true>), grid, block, x3c::LDS_BYTES, st, ua);

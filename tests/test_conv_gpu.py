@@ -487,10 +487,11 @@ def test_bf16x3_kernel_keeps_fp32_accuracy(case, monkeypatch):
     _close(stats["1"][:, 1], (ref ** 2).sum((0, 2, 3)), 1e-5)
     if s == 1:
         assert dxe["1"] <= 5e-6 and dxe["1"] <= 1.5 * dxe["0"] + 1e-8, dxe
-    # the weight gradient sums 65536+ products per element: slices of <= 4096 pixels in fp32, partial tiles added in order
-    # (the two kernels cut the pixels into different numbers of slices -- 512 vs 768 resident workgroups -- and the split
-    #  kernel's longer slices collect more of the bf16 MFMA's truncation bias: 3x the fp32 kernel's error is the bar here)
-    assert dwe["1"] <= 2e-5 and dwe["1"] <= 3 * dwe["0"] + 2e-7 and dwe["r"] <= 1.5 * dwe["0"] + 1e-7, dwe
+    # the weight gradient sums 65536+ products per element: slices of <= 4096 pixels in fp32, partial tiles added in order.
+    # The bf16 MFMA truncates where it aligns its addends (a bias that grows with instructions x |accumulator|); the split
+    # kernel therefore restarts its MFMA accumulators every 8 chunks and sums them in fp32 (round to nearest) -- with that the
+    # bar is the forward / data-gradient one: 1.5x the fp32 kernel's error (round 3, without the restart: 3x)
+    assert dwe["1"] <= 2e-5 and dwe["1"] <= 1.5 * dwe["0"] + 2e-7 and dwe["r"] <= 1.5 * dwe["0"] + 1e-7, dwe
     assert dbe["1"] <= 2e-5 and dbe["0"] <= 2e-5, dbe
 
 
