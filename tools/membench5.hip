@@ -8,8 +8,9 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s at line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ void st16(float* p, float4 v) {
-    if (NT) __builtin_nontemporal_store(v, (float4*)p); else *(float4*)p = v;
+    if (NT) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, (f32x4*)p); else *(float4*)p = v;
 }
 template <bool NT> __global__ __launch_bounds__(1024) void copy4(const float4* a, float4* b, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) st16<NT>((float*)(b + i), a[i]);
