@@ -156,16 +156,20 @@ int pd_polar_theta(const void* rho, void* theta_d, void* theta_s1, void* theta_s
 #define PD_CONV_BF16X3 2u
 #define PD_CONV_WGRAD_SPLIT_IN_REGS 4u
 #define PD_CONV_GENERAL_KERNELS 8u
-#define PD_CONV_FLAGS_ALL 15u
+#define PD_CONV_X3_IM2COL 16u   /* bf16-split forward / data gradient through the per-tap gather kernel (conv_igemm_x3_kernel)
+                                 * also where the halo-tile kernel (conv_halo_x3_kernel) fits: A/B measurement and tests */
+#define PD_CONV_FLAGS_ALL 31u
 int pd_conv2d_tile_m(long M, int Cout);
 long pd_conv2d_stats_rows(long M, int Cout);
-/* Non-zero (2 | 1: 256- | 128-row tiles) when pd_conv2d / pd_conv2d_add send this shape (16-byte aligned NHWC operands assumed) to the kernel that forms the fp32
+/* Non-zero (3: the halo-tile kernel conv_halo_x3_kernel -- 3x3 / 5x5, stride 1, zero padding or the stride-1 data gradient,
+ * C % 16 == 0, Ho % 8 == 0, Wo % 32 == 0, given the output grid Ho x Wo (0 x 0: unknown, never 3) --; 2 | 1: the per-tap
+ * gather kernel with 256- | 128-row tiles) when pd_conv2d / pd_conv2d_add send this shape (16-byte aligned NHWC operands assumed) to the kernel that forms the fp32
  * products on the bf16 matrix cores (conv_igemm_x3_kernel: x = hi + mid + lo in bf16, six MFMAs per 32x32x16 block, fp32
  * accumulation; PD_CONV_FP32_MFMA in `flags` keeps every layer on the fp32 MFMA): zero padding, the stride-1 data gradient or 3x3 reflection padding (a same-size layer is assumed), C % 4 == 0 and >= 8 (16-channel groups, the last may be partly empty),
  * Cout % 64 == 0, at least 512 tiles of 256 x 64 (M % 256 == 0) or 320 of 128 x 64 (M % 128 == 0), no out_scale, activation none or ELU.  The profiler label of a launch
  * (ops._igemm_label) and bench.py's roofline object use it. */
 int pd_conv2d_uses_x3(long M, int Cout, int C, int KH, int KW, int stride, int pad, int mode, int act, int has_out_scale,
-                      unsigned flags);
+                      int Ho, int Wo, unsigned flags);
 int pd_conv2d(const void* x, const void* w, const void* bias, const void* out_scale, void* y, void* stats,
               int N, int H, int W, int C, long sN, long sH, long sW, long sC,
               int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode, int act,

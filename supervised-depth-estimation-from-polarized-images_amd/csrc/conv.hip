@@ -1223,6 +1223,8 @@ static int x3_eligible(const ConvArgs& a, bool vec) {
     return (force || (a.M / 128) * ct >= X3_MIN_WG1) ? 1 : 0;
 }
 
+#include "conv_x3_halo.hpp"
+
 static int launch_conv_x3(ConvArgs& a, int rb, hipStream_t st) {
     a.mtiles = (int)(a.M / (128 * rb));
     a.ntiles = a.Co / x3::BN;
@@ -1293,15 +1295,20 @@ int launch_conv(ConvArgs& a, bool vec, hipStream_t st) {
 }  // namespace
 
 extern "C" int pd_conv2d_uses_x3(long M, int Co, int C, int KH, int KW, int stride, int pad, int mode, int act,
-                                 int has_out_scale, unsigned flags) {
+                                 int has_out_scale, int Ho, int Wo, unsigned flags) {
     ConvArgs a{};
     a.flags = flags;
     a.M = M; a.Co = Co; a.C = C; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = a.pad_w = pad; a.mode = mode; a.act = act;
     a.K = KH * KW * C; a.ldy = Co;
-    a.H = a.Ho = a.W = a.Wo = 16;             // (reflection padding: a same-size 3x3 layer is assumed)
+    a.H = a.Ho = Ho > 0 ? Ho : 16;            // (reflection padding: a same-size 3x3 layer is assumed)
+    a.W = a.Wo = Wo > 0 ? Wo : 16;
+    a.N = Ho > 0 && Wo > 0 ? (int)(M / ((long)Ho * Wo)) : 1;
+    a.sC = 1; a.sW = C; a.sH = (long)a.W * C; a.sN = a.sH * a.H;
     a.oscale = has_out_scale ? reinterpret_cast<const float*>(16) : nullptr;
     while ((1 << a.sshift) < stride) ++a.sshift;
-    return x3_eligible(a, true);
+    a.stats_rows = pd_conv2d_tile_m(M, Co);
+    const int rb = x3_eligible(a, true);
+    return rb && !(flags & PD_CONV_X3_IM2COL) && Ho > 0 && Wo > 0 && x3_halo_eligible(a) ? 3 : rb;
 }
 
 extern "C" int pd_conv2d_tile_m(long M, int Co) {
@@ -1404,7 +1411,11 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
     const int bm = pd_conv2d_tile_m(a.M, Co);
     // 96 output columns (the data gradient of the decoder's 96 -> 32 layer): three 32-wide column tiles instead of a full and a
     // half-empty 64-wide one (a quarter of the matrix work of that launch was padding)
-    if (const int rb = x3_eligible(a, vec)) return launch_conv_x3(a, rb, st);
+    if (const int rb = x3_eligible(a, vec)) {
+        // the halo-tile kernel (every activation element staged and split once per tile) where its tiling fits
+        if (!(flags & PD_CONV_X3_IM2COL) && x3_halo_eligible(a)) return launch_conv_x3_halo(a, st);
+        return launch_conv_x3(a, rb, st);
+    }
     if (Co == 96 && bm == 128) return launch_conv<128, 32, 32, 32>(a, vec, st);
     if (Co > 32) return bm == 128 ? launch_conv<128, 64, 64, 32>(a, vec, st) : launch_conv<64, 64, 32, 32>(a, vec, st);
     if (Co > 16) return launch_conv<128, 32, 32, 32>(a, vec, st);

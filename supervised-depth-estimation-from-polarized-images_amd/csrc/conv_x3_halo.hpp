@@ -1,0 +1,323 @@
+// conv_halo_x3_kernel -- the bf16-split convolution with the ACTIVATION split out of the MFMA loop (included by conv.hip).
+//
+// conv_igemm_x3_kernel gathers the im2col rows of every filter tap from L2 (LDS-DMA), and every wave splits its 64 x 16
+// activation block into bf16 hi / mid / lo terms once PER TAP: the same input element is fetched and split 9 (3x3) or 25
+// (5x5) times per tile -- 3.75 vector instructions and ~680 B of L2 -> LDS traffic per MFMA.  On a chip that runs this
+// kernel at its power limit (1.29 GHz) both are energy that buys no products.  Here a workgroup owns an
+// 8 x 32 OUTPUT tile and, per 16-channel group, stages the (8 + K - 1) x (32 + K - 1) input HALO of that tile ONCE:
+//   * global -> registers (16-byte bounds-checked loads, issued one channel group ahead, in flight under a whole group
+//     of MFMAs), split once in registers, written as bf16 planes to LDS: [term][k half][halo pixel] x 16 bytes;
+//   * the A fragment of tap (kh, kw) for output row y is the plane row y + kh shifted by kw pixels: 32 consecutive
+//     16-byte slots per half-wave -- one conflict-free ds_read_b128 per term at  lane base + tap offset  (one v_add per
+//     tap), no gather, no masks, no per-tap split: the loop is 24 MFMAs, 12 ds_read_b128, the weight chunk's split
+//     (0.75 vector instructions per MFMA instead of 3.75) and one barrier;
+//   * an input element crosses L2 -> CU 1.33x (3x3) / 1.69x (5x5) per tile instead of 9x / 25x.
+// The weight chunk (64 x 16 per tap) keeps the pipeline of conv_igemm_x3_kernel: LDS-DMA two chunks ahead, split once per
+// workgroup one chunk ahead into three bf16 planes.  Epilogue (bias, ELU, addend, BatchNorm partial sums, LDS transposition
+// to full 128-byte lines) as there.  Zero padding or the stride-1 data gradient, K = 3 | 5, C % 16 == 0, Cout % 64 == 0,
+// Ho % 8 == 0, Wo % 32 == 0.
+namespace x3h {
+constexpr int TW = 32, TR = 8, CK = 16;
+constexpr unsigned BS_BYTES = 64 * CK * 4, BP_BYTES = 64 * CK * 2;
+template <int KS> struct Geo {
+    static constexpr int HW = TW + KS - 1, HH = TR + KS - 1, HP = HW * HH;
+    static constexpr int NI = (HP * 4 + NT - 1) / NT;                 // 16-byte halo items per thread and channel group
+    static constexpr unsigned AP_BYTES = 3 * 2 * HP * 16;             // A planes: [term][half][halo pixel] x 16 B
+    static constexpr unsigned BS_BASE = AP_BYTES, BP_BASE = BS_BASE + 2 * BS_BYTES;
+    static constexpr unsigned LDS_BYTES = BP_BASE + 2 * 3 * BP_BYTES;
+};
+}  // namespace x3h
+
+template <int MODE, int KS>
+__global__ __launch_bounds__(NT, 2) void conv_halo_x3_kernel(const ConvArgs a) {
+    using namespace x3h;
+    using G = Geo<KS>;
+    constexpr int HW = G::HW, HP = G::HP, NI = G::NI, T = KS * KS;
+    constexpr unsigned BS_BASE = G::BS_BASE, BP_BASE = G::BP_BASE;
+    static_assert(G::LDS_BYTES >= 4 * 64 * 32 * 4 + 4 * 64 * 2 * 4, "the epilogue's transposition tiles reuse the ring");
+    __shared__ __attribute__((aligned(16))) float smem_all[G::LDS_BYTES / 4];
+
+    // ---- tile: XCD-aware order as everywhere (consecutive logical tiles -- neighbours in x, then y -- share an L2)
+    const int tiles_w = a.Wo / TW, tiles_h = a.Ho / TR;
+    const int ntile_m = a.N * tiles_h * tiles_w;
+    const int nblk = ntile_m * a.ntiles;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (logical >= nblk) return;
+    const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
+    const int n0 = nt * 64;
+    const int img = mt / (tiles_h * tiles_w);
+    const int trem = mt - img * (tiles_h * tiles_w);
+    const int ty = trem / tiles_w, tx = trem - ty * tiles_w;
+    const int oy0 = ty * TR, ox0 = tx * TW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int padh = MODE == MODE_TRANSPOSED ? KS - 1 - a.pad : a.pad, padw = MODE == MODE_TRANSPOSED ? KS - 1 - a.pad_w : a.pad_w;
+
+    const long img_bytes = (long)a.sN * 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img * a.sN, (unsigned)img_bytes);
+    const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, a.w_bytes);
+
+    // ---- halo items of this thread: item = pixel * 4 + channel quad; byte offset inside the image (without the channel
+    // group), OOB where the pixel lies outside the image (zero padding) or beyond the halo
+    unsigned hoff[NI], hdst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int item = tid + NT * i;
+        const int p = item >> 2, quad = item & 3;
+        const int hy = p / HW, hx = p - hy * HW;
+        const int iy = oy0 - padh + hy, ix = ox0 - padw + hx;
+        const bool ok = p < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        hoff[i] = ok ? (unsigned)(iy * (int)a.sH + ix * (int)a.sW + quad * 4) * 4u : OOB;
+        hdst[i] = p < HP ? (unsigned)(((quad >> 1) * HP + p) * 16 + (quad & 1) * 8) : 0xffffffffu;       // + term * 2 * HP * 16
+    }
+    // weights: wave w stages rows 16w .. 16w+15 of the 64 x 16 chunk (lane -> row lane/4, physical slot lane%4 holding the
+    // LOGICAL slot (lane%4) ^ ((row/4)%4)), as conv_igemm_x3_kernel
+    const int prow = lane >> 2;
+    const unsigned col4 = 16u * ((lane & 3) ^ ((lane >> 4) & 3));
+    const unsigned vb = (unsigned)((n0 + 16 * wave + prow) * a.K) * 4u + col4;
+
+    const int ngroups = a.C / CK;
+    const int nchunks = ngroups * T;
+    int s_qb = 0, sb_tap = 0;
+    unsigned s_boff = 0, sb_c4 = 0;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
+    const unsigned m0_b = lds0 + BS_BASE + 1024u * (unsigned)wave;
+    auto load_b = [&](auto dst_tag) {                             // chunk s_qb (past the end: chunk 0 again, never used)
+        constexpr unsigned DST = decltype(dst_tag)::value;
+        dma16s(rw_, m0_b + DST * BS_BYTES, vb, s_qb < nchunks ? s_boff : 0u);
+        ++s_qb;
+        s_boff += (unsigned)a.C * 4u;                             // next tap of the same channel group
+        if (++sb_tap == T) { sb_tap = 0; sb_c4 += CK * 4; s_boff = sb_c4; }
+    };
+
+    // ---- fragment addresses
+    const int frow = lane & 31, fh = lane >> 5;
+    const unsigned fa_base = (unsigned)((fh * HP + 2 * wave * HW + frow) * 16);     // + tap offset + (term * 2 * HP + i * HW) * 16
+    unsigned fb_off = BP_BASE + (unsigned)frow * (CK * 2) + 16u * (fh ^ ((frow >> 3) & 1));
+    asm volatile("" : "+v"(fb_off));
+    const int srow = tid >> 2, sls = (tid & 3) ^ ((srow >> 2) & 3);            // weight split: thread -> its 16 bytes of the staging tile
+    const unsigned ss_off = BS_BASE + 16u * (unsigned)tid;
+    const unsigned sp_off = BP_BASE + (unsigned)srow * (CK * 2) + 16u * ((sls >> 1) ^ ((srow >> 3) & 1)) + 8u * (sls & 1);
+    char* lds_c = reinterpret_cast<char*>(smem_all);
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto bf = [](u32x4 v) { return __builtin_bit_cast(x3::bf16x8, v); };
+
+    // ---- halo pipeline: loads of channel group g + 1 fly under the MFMAs of group g
+    float4 hv[NI];
+    auto halo_load = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            hv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, hoff[i], g * (CK * 4), 0));
+    };
+    auto halo_split = [&]() {                                    // registers -> bf16 planes (every element split once per tile)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            uint2 h, m, l;
+            x3::split2(hv[i].x, hv[i].y, h.x, m.x, l.x);
+            x3::split2(hv[i].z, hv[i].w, h.y, m.y, l.y);
+            if (hdst[i] != 0xffffffffu) {
+                *reinterpret_cast<uint2*>(lds_c + hdst[i] + 0 * (2 * HP * 16)) = h;
+                *reinterpret_cast<uint2*>(lds_c + hdst[i] + 1 * (2 * HP * 16)) = m;
+                *reinterpret_cast<uint2*>(lds_c + hdst[i] + 2 * (2 * HP * 16)) = l;
+            }
+        }
+    };
+    auto split_b = [&](auto src_tag) {          // staging tile SRC -> planes SRC (prologue only; the loop threads it)
+        constexpr unsigned SRC = decltype(src_tag)::value;
+        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + SRC * BS_BYTES);
+        uint2 h, m, l;
+        x3::split2(w4.x, w4.y, h.x, m.x, l.x);
+        x3::split2(w4.z, w4.w, h.y, m.y, l.y);
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 0) * BP_BYTES) = h;
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 1) * BP_BYTES) = m;
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 2) * BP_BYTES) = l;
+    };
+
+    // scalar tap state of the chunk being multiplied
+    int s_kh = 0, s_kw = 0, s_g = 0;
+
+    // One chunk = one tap of one channel group: 24 MFMAs; the next chunk's weights are split between them.
+    auto chunk = [&](auto buf_tag) {
+        constexpr unsigned BUF = decltype(buf_tag)::value, NXT = BUF ^ 1;
+        const bool halo_issue = (s_kh | s_kw) == 0 && s_g + 1 < ngroups;    // (uniform) first tap of a group that has a successor
+        load_b(buf_tag);
+        if (halo_issue) halo_load(s_g + 1);
+        const int ey = MODE == MODE_TRANSPOSED ? KS - 1 - s_kh : s_kh, ex = MODE == MODE_TRANSPOSED ? KS - 1 - s_kw : s_kw;
+        const unsigned fa = fa_base + (unsigned)((ey * HW + ex) * 16);
+        u32x4 av[2][3], fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                av[i][t] = *reinterpret_cast<const u32x4*>(lds_c + fa + (unsigned)((t * 2 * HP + i * HW) * 16));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                fb[j][t] = *reinterpret_cast<const u32x4*>(lds_c + fb_off + ((BUF * 3 + t) * BP_BYTES + (unsigned)j * 32 * CK * 2));
+        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + NXT * BS_BYTES);      // next chunk's weights (fp32)
+        const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+        x3::Terms tw;
+        // MFMA N (0..11) of row block I: products largest first -- hi*hi, hi*mid, hi*lo, mid*hi, mid*mid, lo*hi; column block N % 2
+        auto mm = [&](auto i_tag, auto n_tag) {
+            constexpr int I = decltype(i_tag)::value, N = decltype(n_tag)::value, TT = N / 2, J = N % 2;
+            constexpr int TA = TT < 3 ? 0 : TT < 5 ? 1 : 2, TB = TT == 0 ? 0 : TT == 1 ? 1 : TT == 2 ? 2 : TT == 3 ? 0 : TT == 4 ? 1 : 0;
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(av[I][TA]), bf(fb[J][TB]), acc[I][J], 0, 0, 0);
+        };
+#define PD_I(n) std::integral_constant<int, n>{}
+#define PD_SB __builtin_amdgcn_sched_barrier(0);
+        PD_SB
+        mm(PD_I(0), PD_I(0)); x3::sp_h<0, true>(ws, tw); PD_SB
+        mm(PD_I(0), PD_I(1)); x3::sp_h<1, true>(ws, tw); PD_SB
+        mm(PD_I(1), PD_I(0)); x3::sp_m<0, true>(ws, tw); PD_SB
+        mm(PD_I(1), PD_I(1)); PD_SB
+        mm(PD_I(0), PD_I(2)); x3::sp_m<1, true>(ws, tw); PD_SB
+        mm(PD_I(0), PD_I(3)); PD_SB
+        mm(PD_I(1), PD_I(2)); x3::sp_l<0, true>(tw); PD_SB
+        mm(PD_I(1), PD_I(3)); x3::sp_l<1, true>(tw); PD_SB
+        mm(PD_I(0), PD_I(4)); PD_SB
+        mm(PD_I(0), PD_I(5));
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
+        PD_SB
+        mm(PD_I(1), PD_I(4)); mm(PD_I(1), PD_I(5));
+        mm(PD_I(0), PD_I(6)); mm(PD_I(0), PD_I(7)); mm(PD_I(1), PD_I(6)); mm(PD_I(1), PD_I(7));
+        mm(PD_I(0), PD_I(8)); mm(PD_I(0), PD_I(9)); mm(PD_I(1), PD_I(8)); mm(PD_I(1), PD_I(9));
+        mm(PD_I(0), PD_I(10)); mm(PD_I(0), PD_I(11)); mm(PD_I(1), PD_I(10)); mm(PD_I(1), PD_I(11));
+#undef PD_SB
+#undef PD_I
+        // advance the tap; at the end of a channel group the halo of the next one replaces the planes
+        const bool last_tap = s_kh == KS - 1 && s_kw == KS - 1;
+        if (++s_kw == KS) { s_kw = 0; if (++s_kh == KS) { s_kh = 0; ++s_g; } }
+        // the weight load of this chunk must have landed (the halo loads issued behind it may still fly: vmcnt counts in order)
+        if (halo_issue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (last_tap && s_g < ngroups) {                                      // (uniform)
+            halo_split();
+            __syncthreads();
+        }
+    };
+
+    // ---- prologue: halo of group 0, weights of chunks 0 and 1; planes of both
+    {
+        const std::integral_constant<unsigned, 0> d0{};
+        const std::integral_constant<unsigned, 1> d1{};
+        halo_load(0);
+        load_b(d0);
+        load_b(d1);
+        halo_split();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        split_b(d0);
+        __syncthreads();
+    }
+    for (int q = 0; q < nchunks; q += 2) {
+        chunk(std::integral_constant<unsigned, 0>{});
+        if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
+    }
+
+    // ---- epilogue: per column block the wave transposes its 64 x 32 block (two output rows of 32 pixels) through LDS and
+    // leaves with full 128-byte lines; BatchNorm partial sums: one row of `stats` per 128 output pixels (waves 0-1 | 2-3)
+    {
+        float* Tt = smem_all + wave * (64 * 32);
+        float (*red)[64][2] = reinterpret_cast<float (*)[64][2]>(smem_all + 4 * 64 * 32);
+        const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+        const bool elu = a.act == ACT_ELU;
+        const long img_m = (long)img * a.Ho * a.Wo;
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + img_m * a.ldy, (unsigned)((long)a.Ho * a.Wo * a.ldy * 4));
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.add ? a.add + img_m * a.ld_add : a.y, a.add ? (unsigned)((long)a.Ho * a.Wo * a.ld_add * 4) : 0u);
+        // pixel index (inside the image) of row block i of this wave, row lane/8 of an 8-row store group
+        const int pix0 = (oy0 + 2 * wave) * a.Wo + ox0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 addv[8];
+            if (a.add) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int pix = pix0 + (t >> 2) * a.Wo + (t & 3) * 8 + (lane >> 3);
+                    addv[t] = buf_ld4(ra, (unsigned)(pix * (int)a.ld_add + n0 + 32 * j + 4 * (lane & 7)) * 4u);
+                }
+            }
+            float s1 = 0.f, s2 = 0.f;
+            const float bv = a.bias ? a.bias[n0 + 32 * j + col_l] : 0.f;     // (the statistics are those of conv + bias)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] + bv;
+                    Tt[(32 * i + (r & 3) + 8 * (r >> 2) + rbase) * 32 + col_l] =
+                        elu ? (v > 0.f ? v : __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f) : v;
+                    s1 += v;
+                    s2 = __builtin_fmaf(v, v, s2);
+                }
+            const float4* Tq = reinterpret_cast<const float4*>(Tt) + lane;
+            float4 v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                v[t] = Tq[t * 64];
+                if (a.add) { v[t].x += addv[t].x; v[t].y += addv[t].y; v[t].z += addv[t].z; v[t].w += addv[t].w; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int pix = pix0 + (t >> 2) * a.Wo + (t & 3) * 8 + (lane >> 3);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[t]), ry,
+                                                      (unsigned)(pix * (int)a.ldy + n0 + 32 * j + 4 * (lane & 7)) * 4u, 0, 0);
+            }
+            asm volatile("s_nop 1");
+            __builtin_amdgcn_sched_barrier(0);
+            if (a.stats) {
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
+            }
+        }
+        if (a.stats) {
+            __syncthreads();
+            if (tid < 2 * 64) {
+                const int row_l = tid >> 6, cl = tid & 63;
+                const float t1 = red[2 * row_l][cl][0] + red[2 * row_l + 1][cl][0];
+                const float t2 = red[2 * row_l][cl][1] + red[2 * row_l + 1][cl][1];
+                float* o = a.stats + ((long)(mt * 2 + row_l) * a.Co + n0 + cl) * 2;
+                o[0] = t1; o[1] = t2;
+            }
+        }
+    }
+}
+
+// Shapes the halo kernel takes (the caller has established x3 eligibility: vector path, Cout % 64 == 0, alignment, no scale,
+// activation none | ELU): square 3x3 / 5x5 filter, stride 1, zero padding or the stride-1 data gradient, whole 16-channel
+// groups, whole 8 x 32 output tiles, 128-row BatchNorm statistics, an image within 32-bit byte offsets.
+static bool x3_halo_eligible(const ConvArgs& a) {
+    return (a.KH == 3 || a.KH == 5) && a.KW == a.KH && a.stride == 1 && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) &&
+           a.C % x3h::CK == 0 && a.Ho % x3h::TR == 0 && a.Wo % x3h::TW == 0 && a.stats_rows == 128 && a.sC == 1 &&
+           (long)a.sN * 4 < 0x7fffffffL && (long)a.Ho * a.Wo * a.ldy * 4 < 0x7fffffffL &&
+           (!a.add || (long)a.Ho * a.Wo * a.ld_add * 4 < 0x7fffffffL);
+}
+
+static int launch_conv_x3_halo(ConvArgs& a, hipStream_t st) {
+    a.mtiles = a.N * (a.Ho / x3h::TR) * (a.Wo / x3h::TW);
+    a.ntiles = a.Co / 64;
+    const long nblk = (long)a.mtiles * a.ntiles;
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
+    if (a.KH == 3) {
+        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, 3>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, 3>), grid, block, 0, st, a);
+    } else {
+        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, 5>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, 5>), grid, block, 0, st, a);
+    }
+    return pd::check_launch("pd_conv2d");
+}

@@ -37,7 +37,7 @@ SIGNATURES = {
     "pd_polar_calc_normals": (_i, [_vp, _vp, _vp, _i, _l, _i, _i, _vp]),
     "pd_conv2d_tile_m": (_i, [_l, _i]),
     "pd_conv2d_stats_rows": (_l, [_l, _i]),
-    "pd_conv2d_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u]),
+    "pd_conv2d_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u]),
     "pd_conv2d_wgrad_uses_x3": (_i, [_l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u]),
     "pd_conv2d": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                        _i, _f, _f, _l, _u, _vp]),

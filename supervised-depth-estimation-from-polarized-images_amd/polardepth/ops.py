@@ -18,9 +18,11 @@ PROFILE = None      # bench.py sets this to a list: (kernel label, algorithmic f
 # Kernel family / arithmetic of the convolutions: the `flags` word of pd_conv2d* / pd_conv2d_wgrad (include/polardepth.h).
 # The library reads no environment variable; this module owns the knobs and reads them ONCE, at import:
 #   PD_CONV_X3=0    forward / data gradient on the fp32 MFMA only      PD_WGRAD_X3C=0   weight gradients likewise
+#   PD_CONV_HALO=0  bf16-split forward / data gradient through conv_igemm_x3_kernel also where the halo-tile kernel fits
 # Tests and bench.py switch families in-process by assigning CONV_FLAGS / WGRAD_FLAGS (or `with conv_flags(...)`).
-CONV_AUTO, CONV_FP32_MFMA, CONV_BF16X3, CONV_WGRAD_SPLIT_IN_REGS, CONV_GENERAL_KERNELS = 0, 1, 2, 4, 8
-CONV_FLAGS = CONV_FP32_MFMA if os.environ.get("PD_CONV_X3", "1") == "0" else CONV_AUTO        # pd_conv2d, _add, _rect
+CONV_AUTO, CONV_FP32_MFMA, CONV_BF16X3, CONV_WGRAD_SPLIT_IN_REGS, CONV_GENERAL_KERNELS, CONV_X3_IM2COL = 0, 1, 2, 4, 8, 16
+CONV_FLAGS = (CONV_FP32_MFMA if os.environ.get("PD_CONV_X3", "1") == "0" else       # pd_conv2d, _add, _rect
+              CONV_X3_IM2COL if os.environ.get("PD_CONV_HALO", "1") == "0" else CONV_AUTO)   # PD_CONV_HALO=0: the per-tap gather kernel everywhere
 WGRAD_FLAGS = CONV_FP32_MFMA if os.environ.get("PD_WGRAD_X3C", "1") == "0" else CONV_AUTO     # pd_conv2d_wgrad
 
 
@@ -56,9 +58,11 @@ def _profiled(label, flops, fn, shape=None):
     return r
 
 
-def _igemm_label(M, Co, vec, kind, C=0, KH=1, KW=1, stride=1, pad=0, mode=0, act=ACT_NONE, out_scale=False):
+def _igemm_label(M, Co, vec, kind, C=0, KH=1, KW=1, stride=1, pad=0, mode=0, act=ACT_NONE, out_scale=False, out_hw=(0, 0)):
     """Profiler label = the kernel family pd_conv2d launches for this call (same rule as launch_conv in conv.hip)."""
-    rb = lib.pd_conv2d_uses_x3(M, Co, C, KH, KW, stride, pad, mode, act, int(out_scale), CONV_FLAGS) if vec else 0
+    rb = lib.pd_conv2d_uses_x3(M, Co, C, KH, KW, stride, pad, mode, act, int(out_scale), out_hw[0], out_hw[1], CONV_FLAGS) if vec else 0
+    if rb == 3:
+        return "conv_halo_x3_kernel<8x32,64>"
     if rb:
         return f"conv_igemm_x3_kernel<{128 * rb},64>"
     bm = lib.pd_conv2d_tile_m(M, Co)
@@ -143,7 +147,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, mode=MODE_ZERO, act=ACT_NONE, w
                                               0, act, stream_ptr()), "pd_conv16"),
                   shape=("fwd", N, C, H, W, Co, KH, stride, mode))
         return out
-    _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd", C, KH, KW, stride, pad, mode, act, out_scale is not None), 2.0 * N * Ho * Wo * Co * (alg_k if alg_k is not None else C * KH * KW),
+    _profiled(_igemm_label(N * Ho * Wo, Co, vec, "fwd", C, KH, KW, stride, pad, mode, act, out_scale is not None, (Ho, Wo)), 2.0 * N * Ho * Wo * Co * (alg_k if alg_k is not None else C * KH * KW),
               lambda: check(lib.pd_conv2d(ptr(x), ptr(w), ptr(bias), ptr(out_scale), ptr(out), ptr(stats), N, H, W, C, sN, sH, sW, sC,
                                           Ho, Wo, Co, KH, KW, stride, pad, mode, act, int(affine is not None), sub,
                                           div, ldy, CONV_FLAGS, stream_ptr()), "pd_conv2d"),
@@ -219,7 +223,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
         assert addend.shape == dx.shape and addend.stride(1) == 1 and addend.is_cuda
         ld_add = addend.stride(3)
         assert addend.stride(2) == W * ld_add and addend.stride(0) == H * W * ld_add
-        _profiled(_igemm_label(N * H * W, Ci, True, "dgrad", Co, KH, KW, stride, pad, MODE_TRANSPOSED),
+        _profiled(_igemm_label(N * H * W, Ci, True, "dgrad", Co, KH, KW, stride, pad, MODE_TRANSPOSED, out_hw=(H, W)),
                   2.0 * N * Hy * Wy * Co * Ci * KH * KW,
                   lambda: check(lib.pd_conv2d_add(ptr(dy), ptr(wt), ptr(addend), ld_add, ptr(dx), N, Hy, Wy, Co, sN, sH, sW,
                                                   sC, H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, Ci, CONV_FLAGS, stream_ptr()),
@@ -227,7 +231,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, wt=None, addend=None):
                   shape=("dgrad", N, Ci, H, W, Co, KH, stride, MODE_TRANSPOSED))
         return dx
     # algorithmic flops of the data gradient = those of the forward conv it differentiates
-    _profiled(_igemm_label(N * H * W, Ci, True, "dgrad", Co, KH, KW, stride, pad, MODE_TRANSPOSED), 2.0 * N * Hy * Wy * Co * Ci * KH * KW,
+    _profiled(_igemm_label(N * H * W, Ci, True, "dgrad", Co, KH, KW, stride, pad, MODE_TRANSPOSED, out_hw=(H, W)), 2.0 * N * Hy * Wy * Co * Ci * KH * KW,
               lambda: check(lib.pd_conv2d(ptr(dy), ptr(wt), None, None, ptr(dx), None, N, Hy, Wy, Co, sN, sH, sW, sC,
                                           H, W, Ci, KH, KW, stride, pad, MODE_TRANSPOSED, ACT_NONE, 0, 0.0, 1.0, Ci,
                                           CONV_FLAGS, stream_ptr()), "pd_conv2d(dgrad)"),

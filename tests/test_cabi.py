@@ -194,35 +194,42 @@ def test_which_shapes_take_the_bf16_split_kernels():
     """pd_conv2d_uses_x3 / pd_conv2d_wgrad_uses_x3 (host logic, no GPU): the routing rule the profiler labels, bench.py's
     roofline object and the production-size tests rely on.  Arguments: M, Cout, C, KH, KW, stride, pad, mode, act, scale."""
     lib = _lib.lib
-    AUTO, FP32, X3, REGS, GEN = 0, 1, 2, 4, 8          # PD_CONV_* flags (include/polardepth.h), the last argument of every query
+    AUTO, FP32, X3, REGS, GEN, IM2COL = 0, 1, 2, 4, 8, 16     # PD_CONV_* flags (include/polardepth.h), the last argument of every query
     M16 = 16 * 256 * 320
-    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, AUTO) == 2            # encoder 5x5 at batch 16: 256-row tiles
-    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 2, 0, 0, AUTO) == 2            # its stride-1 data gradient
-    assert lib.pd_conv2d_uses_x3(256 * 320, 64, 64, 3, 3, 1, 1, 0, 0, 0, AUTO) == 1      # 320 tiles of 256 rows, 640 of 128
-    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 0, 0, AUTO) == 1  # 320 tiles of 128 rows
-    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 256, 512, 3, 3, 1, 1, 0, 0, 0, AUTO) == 0  # 160 tiles of 128 rows: fp32 kernel
-    assert lib.pd_conv2d_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 0, 0, AUTO) == 0            # 32 output channels
-    assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, AUTO) == 2            # space-to-depth stem: 36 = 2 channel groups + 4
-    assert lib.pd_conv2d_uses_x3(M16, 64, 4, 4, 4, 1, 2, 0, 0, 0, AUTO) == 0             # a group of 16 with 4 valid channels: no
-    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 2, 0, AUTO) == 2           # decoder ConvBlock: 3x3 reflection padding + ELU
-    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 5, 5, 1, 2, 1, 0, 0, AUTO) == 0           # 5x5 reflection padding
-    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 1, 0, AUTO) == 0            # ReLU in the epilogue
-    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 3, 0, AUTO) == 0            # sigmoid in the epilogue
-    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 0, 1, AUTO) == 0            # folded BatchNorm scale
-    assert lib.pd_conv2d_uses_x3(4 * M16, 64, 128, 3, 3, 2, 1, 2, 0, 0, AUTO) == 0       # stride-2 data gradient (parity launches)
-    assert lib.pd_conv2d_uses_x3(M16 // 4, 128, 64, 3, 3, 2, 1, 0, 0, 0, AUTO) == 2      # stride-2 forward
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 0, 0, AUTO) == 2            # encoder 5x5 at batch 16: 256-row tiles
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 2, 0, 0, 0, 0, AUTO) == 2            # its stride-1 data gradient
+    assert lib.pd_conv2d_uses_x3(256 * 320, 64, 64, 3, 3, 1, 1, 0, 0, 0, 0, 0, AUTO) == 1      # 320 tiles of 256 rows, 640 of 128
+    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 0, 0, 0, 0, AUTO) == 1  # 320 tiles of 128 rows
+    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 256, 512, 3, 3, 1, 1, 0, 0, 0, 0, 0, AUTO) == 0  # 160 tiles of 128 rows: fp32 kernel
+    assert lib.pd_conv2d_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 0, 0, 0, 0, AUTO) == 0            # 32 output channels
+    assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 0, 0, AUTO) == 2            # space-to-depth stem: 36 = 2 channel groups + 4
+    assert lib.pd_conv2d_uses_x3(M16, 64, 4, 4, 4, 1, 2, 0, 0, 0, 0, 0, AUTO) == 0             # a group of 16 with 4 valid channels: no
+    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 2, 0, 0, 0, AUTO) == 2           # decoder ConvBlock: 3x3 reflection padding + ELU
+    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 5, 5, 1, 2, 1, 0, 0, 0, 0, AUTO) == 0           # 5x5 reflection padding
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 1, 0, 0, 0, AUTO) == 0            # ReLU in the epilogue
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 3, 0, 0, 0, AUTO) == 0            # sigmoid in the epilogue
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 0, 1, 0, 0, AUTO) == 0            # folded BatchNorm scale
+    assert lib.pd_conv2d_uses_x3(4 * M16, 64, 128, 3, 3, 2, 1, 2, 0, 0, 0, 0, AUTO) == 0       # stride-2 data gradient (parity launches)
+    assert lib.pd_conv2d_uses_x3(M16 // 4, 128, 64, 3, 3, 2, 1, 0, 0, 0, 0, 0, AUTO) == 2      # stride-2 forward
     # M, Cout, C, KH, KW, stride, pad, mode, H, W, Ho, Wo
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 1
     assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 1   # decoder: ReflectionPad2d(1) + Conv3x3
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 5, 5, 1, 2, 1, 256, 320, 256, 320, AUTO) == 0       # reflect 5x5: general kernel
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 0       # 32-wide co tile
+    # with the output grid known, the halo-tile kernel takes the 3x3 / 5x5 stride-1 layers with whole 8 x 32 tiles
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 256, 320, AUTO) == 3
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 2, 0, 0, 256, 320, AUTO) == 3            # stride-1 data gradient
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 256, 320, IM2COL) == 2          # ... unless the caller asks for the gather kernel
+    assert lib.pd_conv2d_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 0, 0, 64, 80, AUTO) == 2   # Wo = 80: no whole 32-column tiles
+    assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 256, 320, AUTO) == 2            # 4x4 stem / partly empty channel group
+    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 2, 0, 256, 320, AUTO) == 2           # reflection padding
     # the caller's flags decide the arithmetic -- no environment variable is read by the library
-    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, FP32) == 0
+    assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 0, 0, FP32) == 0
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, FP32) == 0
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, REGS) == 0     # the in-register split is the uni kernel's
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, GEN) == 0
-    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 256, 512, 3, 3, 1, 1, 0, 0, 0, X3) == 1                # forced: 160 tiles of 128 rows
-    assert lib.pd_conv2d_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 0, 0, X3) == 0                           # ... but never a shape the kernel cannot run
+    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 256, 512, 3, 3, 1, 1, 0, 0, 0, 0, 0, X3) == 1                # forced: 160 tiles of 128 rows
+    assert lib.pd_conv2d_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 0, 0, 0, 0, X3) == 0                           # ... but never a shape the kernel cannot run
     # workspace of the weight gradient follows the same flags (the two families plan different slice counts)
     assert lib.pd_conv2d_wgrad_workspace(M16, 64, 576, AUTO) != lib.pd_conv2d_wgrad_workspace(M16, 64, 576, FP32)
 
@@ -231,7 +238,7 @@ def test_conv_flags_are_validated():
     """Unknown bits, or fp32-MFMA and bf16-split requested together: PD_EINVAL before anything is launched (null tensors
     would be the next complaint)."""
     lib = _lib.lib
-    for bad in (16, 1 | 2, 0x80000000):
+    for bad in (32, 1 | 2, 0x80000000):
         rc = lib.pd_conv2d(8, 8, None, None, 8, None, 1, 4, 4, 4, 64, 16, 4, 1, 4, 4, 4, 1, 1, 1, 0, 0, 0, 0, 0.0, 1.0, 4, bad, None)
         assert rc == -22 and b"flags" in lib.pd_last_error(), bad
         rc = lib.pd_conv2d_wgrad(8, 8, 8, None, 8, 1 << 20, 1, 4, 4, 4, 64, 16, 4, 1, 4, 4, 4, 1, 1, 1, 0, 0, 0, 0.0, 1.0, 4, 0, bad, None)

@@ -510,7 +510,7 @@ def test_bf16x3_kernel_reflection_padding_bias_elu(case, monkeypatch):
     errs = {}
     for knob in ("1", "0"):
         monkeypatch.setattr(ops, "CONV_FLAGS", ops.CONV_AUTO if knob == "1" else ops.CONV_FP32_MFMA)
-        assert bool(ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, 3, 3, 1, 1, ops.MODE_REFLECT, ops.ACT_ELU, 0, ops.CONV_FLAGS)) == (knob == "1")
+        assert bool(ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, 3, 3, 1, 1, ops.MODE_REFLECT, ops.ACT_ELU, 0, H, W, ops.CONV_FLAGS)) == (knob == "1")
         y = ops.conv2d_fwd(xd, wd, b.cuda(), stride=1, pad=1, mode=ops.MODE_REFLECT, act=ops.ACT_ELU)
         errs[knob] = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert errs["1"] <= 5e-6 and errs["1"] <= 1.5 * errs["0"] + 1e-7, errs
@@ -591,7 +591,7 @@ def test_bf16x3_kernels_nonfinite_and_extreme_inputs():
     ref = F.conv2d(xs.double(), w.double(), None, padding=1)
     xd = xs.cuda().contiguous(memory_format=torch.channels_last)
     wd = w.cuda().contiguous(memory_format=torch.channels_last)
-    assert ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, k, k, 1, 1, 0, 0, 0, ops.CONV_AUTO) == 2
+    assert ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, k, k, 1, 1, 0, 0, 0, H, W, ops.CONV_AUTO) == 3          # the halo-tile kernel
     check_maps("forward", *_three(lambda: ops.conv2d_fwd(xd, wd, None, stride=1, pad=1)), ref)
     # data gradient: special values in dY (same channel count in and out: the same fields)
     dys = inject(dyv)
@@ -669,7 +669,7 @@ def test_bf16x3_kernel_cancellation_heavy_contraction():
     assert inner.abs().max().item() < 1e-3 * addends * K ** 0.5, "the contraction does not cancel"
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     wd = w.cuda().contiguous(memory_format=torch.channels_last)
-    assert ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, k, k, 1, 2, 0, 0, 0, ops.CONV_AUTO) == 2
+    assert ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, k, k, 1, 2, 0, 0, 0, H, W, ops.CONV_AUTO) == 3
     split, fp32 = _three(lambda: ops.conv2d_fwd(xd, wd, None, stride=1, pad=2))
     sc = addends * K
     e_s, e_f = (split.double() - ref).abs().max().item() / sc, (fp32.double() - ref).abs().max().item() / sc

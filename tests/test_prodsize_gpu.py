@@ -77,16 +77,18 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     wd = w.cuda().contiguous(memory_format=torch.channels_last)
 
-    def expect(Mx, Cox, Cx, sx, mode):
-        rb = ops.lib.pd_conv2d_uses_x3(Mx, Cox, Cx, k, k, sx, p, mode, 0, 0, fl)
+    def expect(Mx, Cox, Cx, sx, mode, ho, wo):
+        rb = ops.lib.pd_conv2d_uses_x3(Mx, Cox, Cx, k, k, sx, p, mode, 0, 0, ho, wo, fl)
         want = 0
         if x3 == "1" and Cox % 64 == 0 and Cx % 4 == 0 and -(-Cx // 16) * 16 <= 2 * Cx:
             want = 2 if (Mx % 256 == 0 and (Mx // 256) * (Cox // 64) >= 512) else 1 if (Mx % 128 == 0 and (Mx // 128) * (Cox // 64) >= 320) else 0
+            if want and k in (3, 5) and sx == 1 and Cx % 16 == 0 and ho % 8 == 0 and wo % 32 == 0 and Mx >= 65536:
+                want = 3                               # the halo-tile kernel
         assert rb == want, (rb, want)
-        return [f"conv_igemm_x3_kernel<{128 * rb},64>" if rb else "conv_igemm_uni_kernel<128,64>"]
+        return ["conv_halo_x3_kernel<8x32,64>" if rb == 3 else f"conv_igemm_x3_kernel<{128 * rb},64>" if rb else "conv_igemm_uni_kernel<128,64>"]
 
     (y, stats), lab = _labels(lambda: ops.conv2d_fwd(xd, wd, None, stride=s, pad=p, want_stats=True))
-    assert lab == expect(M, Co, C, s, 0), lab
+    assert lab == expect(M, Co, C, s, 0, ref.shape[2], ref.shape[3]), lab
     _close(y.cpu(), ref.detach(), what="fwd")
     # BatchNorm partials of the transposed epilogue: one row per 128-pixel tile
     assert stats.shape[0] == (M + 127) // 128
@@ -116,7 +118,7 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
 
     dx, lab = _labels(lambda: ops.conv2d_dgrad(dyd, wd, (H, W), stride=s, pad=p))
     if s == 1:
-        assert lab == expect(N * H * W, C, Co, 1, 2), lab
+        assert lab == expect(N * H * W, C, Co, 1, 2, H, W), lab
     else:
         assert lab == ["conv_dgrad_s2_phases"], lab
     _close(dx.cpu(), xr.grad, what="dgrad")
@@ -318,11 +320,11 @@ def test_full_resolution_training_step_matches_oracle(B, tmp_path, monkeypatch):
         tr.model_optimizer.zero_grad()
         (outputs, losses), lab = _labels(step)
         torch.cuda.synchronize()
-        n_prod = sum(l.startswith(("conv_igemm_uni_kernel<128,64>", "conv_igemm_x3_kernel")) for l in lab)
+        n_prod = sum(l.startswith(("conv_igemm_uni_kernel<128,64>", "conv_igemm_x3_kernel", "conv_halo_x3_kernel")) for l in lab)
         assert n_prod >= 30, f"production tiles not exercised: {n_prod}"
-        assert any(l.startswith("conv_igemm_x3_kernel") for l in lab) == (knob == "1")
+        assert any(l.startswith(("conv_igemm_x3_kernel", "conv_halo_x3_kernel")) for l in lab) == (knob == "1")
         if B == 16 and knob == "1":          # the launch labels of bench.py's step: both split tile sizes and the split weight gradient
-            assert {"conv_igemm_x3_kernel<256,64>", "conv_igemm_x3_kernel<128,64>", "conv_wgrad_x3c_kernel"} <= set(lab), sorted(set(lab))
+            assert {"conv_halo_x3_kernel<8x32,64>", "conv_igemm_x3_kernel<256,64>", "conv_igemm_x3_kernel<128,64>", "conv_wgrad_x3c_kernel"} <= set(lab), sorted(set(lab))
         gpu_grads = {f"{mn}.{k}": v.grad.detach().cpu().clone() for mn in tr.models for k, v in tr.models[mn].named_parameters()
                      if v.grad is not None}
         for s in range(4):
