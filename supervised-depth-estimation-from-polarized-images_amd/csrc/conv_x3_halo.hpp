@@ -12,26 +12,31 @@
 //     tap), no gather, no masks, no per-tap split: the loop is 24 MFMAs, 12 ds_read_b128, the weight chunk's split
 //     (0.75 vector instructions per MFMA instead of 3.75) and one barrier;
 //   * an input element crosses L2 -> CU 1.33x (3x3) / 1.69x (5x5) per tile instead of 9x / 25x.
-// The weight chunk (64 x 16 per tap) keeps the pipeline of conv_igemm_x3_kernel: LDS-DMA two chunks ahead, split once per
-// workgroup one chunk ahead into three bf16 planes.  Epilogue (bias, ELU, addend, BatchNorm partial sums, LDS transposition
+// The weight chunk (64 x 16 per tap) keeps the pipeline of conv_igemm_x3_kernel, one chunk deeper: LDS-DMA THREE chunks ahead
+// (a chunk is 24 MFMAs ~ 0.5 us, less than an L2 round trip under load: the wait at a chunk's end is for the load issued a
+// chunk earlier), split once per workgroup one chunk ahead into three bf16 planes.  The halo of the next channel group is
+// split and written between the MFMAs of the current group's LAST tap, behind a barrier that follows that tap's fragment
+// reads (the planes are free from there on): no serial split phase.  Epilogue (bias, ELU, addend, BatchNorm partial sums, LDS transposition
 // to full 128-byte lines) as there.  Zero padding or the stride-1 data gradient, K = 3 | 5, C % 16 == 0, Cout % 64 == 0,
 // Ho % 8 == 0, Wo % 32 == 0.
 namespace x3h {
 constexpr int TW = 32, TR = 8, CK = 16;
 constexpr unsigned BS_BYTES = 64 * CK * 4, BP_BYTES = 64 * CK * 2;
-template <int KS> struct Geo {
+template <int KS, int NSB> struct Geo {
     static constexpr int HW = TW + KS - 1, HH = TR + KS - 1, HP = HW * HH;
     static constexpr int NI = (HP * 4 + NT - 1) / NT;                 // 16-byte halo items per thread and channel group
     static constexpr unsigned AP_BYTES = 3 * 2 * HP * 16;             // A planes: [term][half][halo pixel] x 16 B
-    static constexpr unsigned BS_BASE = AP_BYTES, BP_BASE = BS_BASE + 2 * BS_BYTES;
+    static constexpr unsigned BS_BASE = AP_BYTES, BP_BASE = BS_BASE + NSB * BS_BYTES;    // weight staging: a ring of NSB chunks
     static constexpr unsigned LDS_BYTES = BP_BASE + 2 * 3 * BP_BYTES;
 };
 }  // namespace x3h
 
-template <int MODE, int KS>
-__global__ __launch_bounds__(NT, 2) void conv_halo_x3_kernel(const ConvArgs a) {
+// NSB = depth of the weight staging ring: 3 (requests three chunks ahead; two workgroups per CU) or 2 (as conv_igemm_x3_kernel;
+// with the 3x3 halo the workgroup then fits a CU three times -- 53 KB of LDS, <= 168 registers)
+template <int MODE, int KS, int NSB>
+__global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x3_kernel(const ConvArgs a) {
     using namespace x3h;
-    using G = Geo<KS>;
+    using G = Geo<KS, NSB>;
     constexpr int HW = G::HW, HP = G::HP, NI = G::NI, T = KS * KS;
     constexpr unsigned BS_BASE = G::BS_BASE, BP_BASE = G::BP_BASE;
     static_assert(G::LDS_BYTES >= 4 * 64 * 32 * 4 + 4 * 64 * 2 * 4, "the epilogue's transposition tiles reuse the ring");
@@ -62,16 +67,20 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_x3_kernel(const ConvArgs a) {
 
     // ---- halo items of this thread: item = pixel * 4 + channel quad; byte offset inside the image (without the channel
     // group), OOB where the pixel lies outside the image (zero padding) or beyond the halo
-    unsigned hoff[NI], hdst[NI];
+    // (item i of a thread is pixel (tid >> 2) + 64 i, quad tid & 3: its plane slot is hdst0 + 1024 i, and only the LAST item
+    //  of a thread can lie beyond the halo)
+    unsigned hoff[NI];
+    const int hquad = tid & 3;
+    const unsigned hdst0 = (unsigned)(((hquad >> 1) * HP + (tid >> 2)) * 16 + (hquad & 1) * 8);        // + term * 2 * HP * 16 + 1024 * i
+    const bool hlast_ok = (tid >> 2) + 64 * (NI - 1) < HP;
+    static_assert(64 * (NI - 1) < HP, "only the last halo item of a thread may be empty");
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int item = tid + NT * i;
-        const int p = item >> 2, quad = item & 3;
+        const int p = (tid >> 2) + 64 * i;
         const int hy = p / HW, hx = p - hy * HW;
         const int iy = oy0 - padh + hy, ix = ox0 - padw + hx;
         const bool ok = p < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        hoff[i] = ok ? (unsigned)(iy * (int)a.sH + ix * (int)a.sW + quad * 4) * 4u : OOB;
-        hdst[i] = p < HP ? (unsigned)(((quad >> 1) * HP + p) * 16 + (quad & 1) * 8) : 0xffffffffu;       // + term * 2 * HP * 16
+        hoff[i] = ok ? (unsigned)(iy * (int)a.sH + ix * (int)a.sW + hquad * 4) * 4u : OOB;
     }
     // weights: wave w stages rows 16w .. 16w+15 of the 64 x 16 chunk (lane -> row lane/4, physical slot lane%4 holding the
     // LOGICAL slot (lane%4) ^ ((row/4)%4)), as conv_igemm_x3_kernel
@@ -83,11 +92,12 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_x3_kernel(const ConvArgs a) {
     const int nchunks = ngroups * T;
     int s_qb = 0, sb_tap = 0;
     unsigned s_boff = 0, sb_c4 = 0;
+    unsigned s_ld = 0, s_rd = 1;                                  // staging slots (mod NSB): next load, next split
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
     const unsigned m0_b = lds0 + BS_BASE + 1024u * (unsigned)wave;
-    auto load_b = [&](auto dst_tag) {                             // chunk s_qb (past the end: chunk 0 again, never used)
-        constexpr unsigned DST = decltype(dst_tag)::value;
-        dma16s(rw_, m0_b + DST * BS_BYTES, vb, s_qb < nchunks ? s_boff : 0u);
+    auto load_b = [&]() {                                         // chunk s_qb into slot s_ld (past the end: chunk 0 again, never used)
+        dma16s(rw_, m0_b + s_ld * BS_BYTES, vb, s_qb < nchunks ? s_boff : 0u);
+        s_ld = s_ld == NSB - 1 ? 0u : s_ld + 1;
         ++s_qb;
         s_boff += (unsigned)a.C * 4u;                             // next tap of the same channel group
         if (++sb_tap == T) { sb_tap = 0; sb_c4 += CK * 4; s_boff = sb_c4; }
@@ -120,38 +130,49 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_x3_kernel(const ConvArgs a) {
         for (int i = 0; i < NI; ++i)
             hv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, hoff[i], g * (CK * 4), 0));
     };
-    auto halo_split = [&]() {                                    // registers -> bf16 planes (every element split once per tile)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            uint2 h, m, l;
-            x3::split2(hv[i].x, hv[i].y, h.x, m.x, l.x);
-            x3::split2(hv[i].z, hv[i].w, h.y, m.y, l.y);
-            if (hdst[i] != 0xffffffffu) {
-                *reinterpret_cast<uint2*>(lds_c + hdst[i] + 0 * (2 * HP * 16)) = h;
-                *reinterpret_cast<uint2*>(lds_c + hdst[i] + 1 * (2 * HP * 16)) = m;
-                *reinterpret_cast<uint2*>(lds_c + hdst[i] + 2 * (2 * HP * 16)) = l;
-            }
-        }
-    };
-    auto split_b = [&](auto src_tag) {          // staging tile SRC -> planes SRC (prologue only; the loop threads it)
-        constexpr unsigned SRC = decltype(src_tag)::value;
-        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + SRC * BS_BYTES);
+
+    auto split_b0 = [&]() {                     // staging slot 0 -> planes 0 (prologue only; the loop threads it)
+        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off);
         uint2 h, m, l;
         x3::split2(w4.x, w4.y, h.x, m.x, l.x);
         x3::split2(w4.z, w4.w, h.y, m.y, l.y);
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 0) * BP_BYTES) = h;
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 1) * BP_BYTES) = m;
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 2) * BP_BYTES) = l;
+        *reinterpret_cast<uint2*>(lds_c + sp_off + 0 * BP_BYTES) = h;
+        *reinterpret_cast<uint2*>(lds_c + sp_off + 1 * BP_BYTES) = m;
+        *reinterpret_cast<uint2*>(lds_c + sp_off + 2 * BP_BYTES) = l;
+    };
+    // one halo item: registers -> three plane slots (every element split once per tile)
+    auto halo_item = [&](auto i_tag) {
+        constexpr int I = decltype(i_tag)::value;
+        if constexpr (I < NI) {
+            uint2 h, m, l;
+            x3::split2(hv[I].x, hv[I].y, h.x, m.x, l.x);
+            x3::split2(hv[I].z, hv[I].w, h.y, m.y, l.y);
+            if (I < NI - 1 || hlast_ok) {
+                *reinterpret_cast<uint2*>(lds_c + hdst0 + (1024u * I + 0 * (2 * HP * 16))) = h;
+                *reinterpret_cast<uint2*>(lds_c + hdst0 + (1024u * I + 1 * (2 * HP * 16))) = m;
+                *reinterpret_cast<uint2*>(lds_c + hdst0 + (1024u * I + 2 * (2 * HP * 16))) = l;
+            }
+        }
+    };
+    auto halo_split = [&]() {                                    // prologue: all items at once
+#define PD_I(n) std::integral_constant<int, n>{}
+        halo_item(PD_I(0)); halo_item(PD_I(1)); halo_item(PD_I(2)); halo_item(PD_I(3)); halo_item(PD_I(4)); halo_item(PD_I(5)); halo_item(PD_I(6));
+#undef PD_I
     };
 
     // scalar tap state of the chunk being multiplied
     int s_kh = 0, s_kw = 0, s_g = 0;
 
-    // One chunk = one tap of one channel group: 24 MFMAs; the next chunk's weights are split between them.
+    // One chunk = one tap of one channel group: 24 MFMAs; the next chunk's weights are split between them.  LAST (the last
+    // tap of a group that has a successor): the next group's halo is split and written behind the MFMAs as well.
+    // (LAST is a run-time, wave-uniform condition: ONE copy of the MFMA stream per weight-plane parity, so that the
+    //  accumulators never move between register sets; the halo items sit behind scalar branches.)
     auto chunk = [&](auto buf_tag) {
         constexpr unsigned BUF = decltype(buf_tag)::value, NXT = BUF ^ 1;
+        const bool LAST = s_kh == KS - 1 && s_kw == KS - 1 && s_g + 1 < ngroups;
         const bool halo_issue = (s_kh | s_kw) == 0 && s_g + 1 < ngroups;    // (uniform) first tap of a group that has a successor
-        load_b(buf_tag);
+        const bool halo_near = s_kh == 0 && s_kw == 1 && s_g + 1 < ngroups; // ... and the tap behind it: the halo loads may still fly
+        load_b();
         if (halo_issue) halo_load(s_g + 1);
         const int ey = MODE == MODE_TRANSPOSED ? KS - 1 - s_kh : s_kh, ex = MODE == MODE_TRANSPOSED ? KS - 1 - s_kw : s_kw;
         const unsigned fa = fa_base + (unsigned)((ey * HW + ex) * 16);
@@ -166,7 +187,9 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 fb[j][t] = *reinterpret_cast<const u32x4*>(lds_c + fb_off + ((BUF * 3 + t) * BP_BYTES + (unsigned)j * 32 * CK * 2));
-        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + NXT * BS_BYTES);      // next chunk's weights (fp32)
+        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + s_rd * BS_BYTES);     // next chunk's weights (fp32)
+        s_rd = s_rd == NSB - 1 ? 0u : s_rd + 1;
+        if (LAST) __syncthreads();                  // every wave holds its fragments of this group's last tap: the planes are free
         const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
         x3::Terms tw;
         // MFMA N (0..11) of row block I: products largest first -- hi*hi, hi*mid, hi*lo, mid*hi, mid*mid, lo*hi; column block N % 2
@@ -192,42 +215,49 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_x3_kernel(const ConvArgs a) {
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
         PD_SB
-        mm(PD_I(1), PD_I(4)); mm(PD_I(1), PD_I(5));
-        mm(PD_I(0), PD_I(6)); mm(PD_I(0), PD_I(7)); mm(PD_I(1), PD_I(6)); mm(PD_I(1), PD_I(7));
-        mm(PD_I(0), PD_I(8)); mm(PD_I(0), PD_I(9)); mm(PD_I(1), PD_I(8)); mm(PD_I(1), PD_I(9));
-        mm(PD_I(0), PD_I(10)); mm(PD_I(0), PD_I(11)); mm(PD_I(1), PD_I(10)); mm(PD_I(1), PD_I(11));
+        // LAST: one halo item (18 vector instructions, 3 ds_write_b64) per two MFMAs
+        mm(PD_I(1), PD_I(4)); mm(PD_I(1), PD_I(5)); if (LAST) halo_item(PD_I(0)); PD_SB
+        mm(PD_I(0), PD_I(6)); mm(PD_I(0), PD_I(7)); if (LAST) halo_item(PD_I(1)); PD_SB
+        mm(PD_I(1), PD_I(6)); mm(PD_I(1), PD_I(7)); if (LAST) halo_item(PD_I(2)); PD_SB
+        mm(PD_I(0), PD_I(8)); mm(PD_I(0), PD_I(9)); if (LAST) halo_item(PD_I(3)); PD_SB
+        mm(PD_I(1), PD_I(8)); mm(PD_I(1), PD_I(9)); if (LAST) halo_item(PD_I(4)); PD_SB
+        mm(PD_I(0), PD_I(10)); mm(PD_I(0), PD_I(11)); if (LAST) halo_item(PD_I(5)); PD_SB
+        mm(PD_I(1), PD_I(10)); mm(PD_I(1), PD_I(11)); if (LAST) halo_item(PD_I(6));
+        static_assert(NI <= 7, "halo items per thread");
 #undef PD_SB
 #undef PD_I
-        // advance the tap; at the end of a channel group the halo of the next one replaces the planes
-        const bool last_tap = s_kh == KS - 1 && s_kw == KS - 1;
         if (++s_kw == KS) { s_kw = 0; if (++s_kh == KS) { s_kh = 0; ++s_g; } }
-        // the weight load of this chunk must have landed (the halo loads issued behind it may still fly: vmcnt counts in order)
-        if (halo_issue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (last_tap && s_g < ngroups) {                                      // (uniform)
-            halo_split();
-            __syncthreads();
+        // The weights the NEXT chunk splits were requested a chunk ago: all but this chunk's own request must have landed
+        // (vmcnt counts in order; the halo loads of a group's first tap were issued behind that chunk's request and may fly on
+        // until the end of the group's second tap).
+        if constexpr (NSB == 3) {
+            if (halo_issue || halo_near) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else {                                 // two slots: this chunk's own request feeds the next chunk's split
+            if (halo_issue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        __syncthreads();
     };
 
-    // ---- prologue: halo of group 0, weights of chunks 0 and 1; planes of both
+    // ---- prologue: halo of group 0, weights of chunks 0, 1, 2 (slots 0, 1, 2); planes of the halo and of chunk 0
     {
-        const std::integral_constant<unsigned, 0> d0{};
-        const std::integral_constant<unsigned, 1> d1{};
         halo_load(0);
-        load_b(d0);
-        load_b(d1);
+        load_b();
+        load_b();
+        if constexpr (NSB == 3) load_b();
         halo_split();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        split_b(d0);
+        split_b0();
         __syncthreads();
     }
     for (int q = 0; q < nchunks; q += 2) {
         chunk(std::integral_constant<unsigned, 0>{});
         if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (run-out weight requests still target the staging ring)
+    __syncthreads();
 
     // ---- epilogue: per column block the wave transposes its 64 x 32 block (two output rows of 32 pixels) through LDS and
     // leaves with full 128-byte lines; BatchNorm partial sums: one row of `stats` per 128 output pixels (waves 0-1 | 2-3)
@@ -312,12 +342,22 @@ static int launch_conv_x3_halo(ConvArgs& a, hipStream_t st) {
     a.ntiles = a.Co / 64;
     const long nblk = (long)a.mtiles * a.ntiles;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
+#ifdef PD_HALO_K3_OCC3
+    constexpr int NSB3 = 2;
+#else
+    constexpr int NSB3 = 3;
+#endif
+#ifdef PD_HALO_K5_NSB2
+    constexpr int NSB5 = 2;
+#else
+    constexpr int NSB5 = 3;
+#endif
     if (a.KH == 3) {
-        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, 3>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, 3>), grid, block, 0, st, a);
+        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, 3, NSB3>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, 3, NSB3>), grid, block, 0, st, a);
     } else {
-        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, 5>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, 5>), grid, block, 0, st, a);
+        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, 5, NSB5>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, 5, NSB5>), grid, block, 0, st, a);
     }
     return pd::check_launch("pd_conv2d");
 }

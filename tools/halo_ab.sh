@@ -1,0 +1,14 @@
+#!/bin/bash
+# GPU box: forward / data-gradient times of the halo-tile kernel's layers: product library, A/B builds (tools/build_probe.sh)
+# and the per-tap gather kernel (PD_CONV_HALO=0).  usage: tools/halo_ab.sh <out.log> [probe names...]
+cd $GRAFT_REPO_ROOT
+OUT=$1; shift
+: > $OUT
+run() {
+  for only in "ResBlock1 3x3" "enc.Conv2 5x5" "ResBlock2 3x3" "enc.Conv3"; do
+    ONLY="$only" timeout -k 10 120 python3 tools/bench_conv.py 2>/dev/null | grep layer | cut -c1-60,95-140,170-240 >> $OUT || exit 1
+  done
+}
+echo "== product (halo)" >> $OUT; unset PD_LIB; PD_CONV_HALO=1 run
+for lib in "$@"; do echo "== $lib" >> $OUT; PD_LIB=$GRAFT_REPO_ROOT/tools/bin/libpd_probe_$lib.so PD_CONV_HALO=1 run; done
+echo "== product, PD_CONV_HALO=0 (conv_igemm_x3_kernel)" >> $OUT; unset PD_LIB; PD_CONV_HALO=0 run
