@@ -5,8 +5,12 @@ cd $GRAFT_REPO_ROOT
 OUT=$1; shift
 : > $OUT
 run() {
-  for only in "ResBlock1 3x3" "enc.Conv2 5x5" "ResBlock2 3x3" "enc.Conv3"; do
-    ONLY="$only" timeout -k 10 120 python3 tools/bench_conv.py 2>/dev/null | grep layer | cut -c1-60,95-140,170-240 >> $OUT || exit 1
+  for only in "ResBlock1 3x3" "enc.Conv2 5x5" "ResBlock2 3x3" "enc.Conv3" "rgb.layer2"; do
+    ONLY="$only" timeout -k 10 120 python3 tools/bench_conv.py 2>/dev/null | grep layer | python3 -c '
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    print("%-44s fwd %6.3f ms %6.1f TF   dgrad %6.3f ms %6.1f TF" % (d["layer"], d["fwd_ms"], d["fwd_TF"], d.get("dgrad_ms", 0), d.get("dgrad_TF", 0)))' >> $OUT || exit 1
   done
 }
 echo "== product (halo)" >> $OUT; unset PD_LIB; PD_CONV_HALO=1 run
