@@ -228,7 +228,9 @@ int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* 
                     int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                     int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode,
                     int affine, float sub, float div, long ldd, int accumulate, unsigned flags, void* stream);
-/* 1 when pd_conv2d_wgrad sends this shape (zero or reflection padding; 16-byte aligned NHWC operands assumed) to the kernel that forms the
+/* 2 (conv_wgrad_halo_x3_kernel: 3x3 / 5x5, stride 1, zero padding, C % 64 == 0, Cout % 64 == 0, Ho % 2 == 0, Wo % 32 == 0: both
+ * operands split once per 2 x 32-pixel tile and read through ds_read_b64_tr_b16) or
+ * 1 when pd_conv2d_wgrad sends this shape (zero or reflection padding; 16-byte aligned NHWC operands assumed) to the kernel that forms the
  * fp32 products on the bf16 matrix cores, every element split once (conv_wgrad_x3c_kernel; PD_CONV_FP32_MFMA: fp32 MFMA) --
  * the profiler label of a launch and bench.py's roofline object use it. */
 int pd_conv2d_wgrad_uses_x3(long M, int Cout, int C, int KH, int KW, int stride, int pad, int mode, int H, int W, int Ho, int Wo,

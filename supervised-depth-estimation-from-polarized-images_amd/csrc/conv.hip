@@ -2375,6 +2375,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
     }
 }
 
+#include "conv_wgrad_halo.hpp"
+
 // out[i] (+)= sum_s part[s][i]: 64 columns x 4 slice lanes per workgroup; every lane keeps four independent
 // loads in flight; the lane partials are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -2494,8 +2496,15 @@ extern "C" int pd_conv2d_wgrad_uses_x3(long M, int Co, int C, int KH, int KW, in
     int S = 0; long mper = 0;
     wgrad_plan(M, Co, KH * KW * C, flags, &S, &mper);
     const int nb = (pad + stride - 1) / stride, nbw = (nb + 1) / 2;
-    return uni_on && wgrad_x3c_enabled(flags) && wgrad_tco(Co) == 64 && C % 4 == 0 && Co % 4 == 0 && Wo % 2 == 0 && Ho >= 2 * nb &&
+    const bool x3c = uni_on && wgrad_x3c_enabled(flags) && wgrad_tco(Co) == 64 && C % 4 == 0 && Co % 4 == 0 && Wo % 2 == 0 && Ho >= 2 * nb &&
            Wo >= 4 * nbw && Wo >= 14 && (2 * nb + 1) * (2 * nbw + 1) <= 31 && mper % WG_MC == 0 && M % 4 == 0 && KH * KW * C >= 4;
+    if (x3c && !(flags & PD_CONV_X3_IM2COL)) {      // 2: the halo-tile kernel (both operands split once per tile, transposed LDS reads)
+        WgradArgs a{};
+        a.mode = mode; a.stride = stride; a.KH = KH; a.KW = KW; a.pad = pad; a.C = C; a.Co = Co; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+        a.ldd = Co; a.sN = (long)H * W * C;
+        if (wgrad_halo_eligible(a, true)) return 2;
+    }
+    return x3c;
 }
 
 extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* workspace, size_t ws_bytes,
@@ -2528,6 +2537,17 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     PD_REQUIRE(a.mper * ldd * 4 < 0x7fffffffL, "pd_conv2d_wgrad: slice too large for 32-bit offsets");
     PD_REQUIRE((a.mper / ((long)Ho * Wo) + 2) * sN * 4 < 0x7fffffffL, "pd_conv2d_wgrad: image too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
+    if (wgrad_x3c_enabled(flags) && !(flags & (PD_CONV_GENERAL_KERNELS | PD_CONV_X3_IM2COL)) && wgrad_halo_eligible(a, vec)) {
+        // halo-tile kernel: its slice count never exceeds the plan the workspace was sized for
+        const int S = launch_wgrad_halo(a, a.S, st, dbias != nullptr);
+        int rc = pd::check_launch("pd_conv2d_wgrad");
+        if (rc) return rc;
+        const long nw = (long)Co * a.K;
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, st, a.part, (float*)dw, S, nw, accumulate);
+        if (dbias)
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((Co + 63) / 64)), dim3(256), 0, st, a.bpart, (float*)dbias, S, (long)Co, accumulate);
+        return pd::check_launch("pd_conv2d_wgrad/reduce");
+    }
     const dim3 grid((unsigned)(((long)a.ktiles * a.ctiles * a.S + 7) / 8 * 8)), block(NT);
 #define PD_WG(T, V, MD) hipLaunchKernelGGL((conv_wgrad_kernel<T, V, MD>), grid, block, 0, st, a)
     // scalar-pixel variant: 16-byte path, zero padding, 64-wide co tile, even output rows (pixel pairs stay inside a

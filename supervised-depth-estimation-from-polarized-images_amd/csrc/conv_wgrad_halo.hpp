@@ -1,0 +1,247 @@
+// conv_wgrad_halo_x3_kernel -- bf16-split weight gradient with BOTH operands split once per tile and read through the
+// hardware transpose (included by conv.hip).
+//
+//   dW[co][kh][kw][ci] = sum_p dY[p][co] * X[p + (kh, kw) - pad][ci]
+// contracts over PIXELS, but both tensors are stored pixel-major (NHWC): an MFMA operand wants eight consecutive
+// contraction indices per lane, i.e. eight pixels of ONE channel.  conv_wgrad_x3c_kernel gets them with eight ds_read_b32 per
+// fragment from an im2col image that is re-gathered (LDS-DMA) and re-split for every 128 (tap, ci) columns: every input
+// element is fetched 9 (25) times and split 9 (25) times per 64 output channels, 4.5 vector + 5-8 scalar instructions per MFMA.
+// gfx950's ds_read_b64_tr_b16 reads a 4 x 16 block of 16-bit elements per 16-lane group and hands each lane a COLUMN: from a
+// plain [pixel][channel] bf16 image a lane receives four consecutive pixels of its channel -- the operand layout, for free,
+// starting at ANY pixel.  So here a workgroup owns one filter row kh, 64 output and 64 input channels and walks 2 x 32-pixel
+// tiles of its slice:
+//   * dY tile (64 px x 64 co) and X row pair (2 x (32 + K - 1) px x 64 ci, shifted by kh) go global -> registers one tile
+//     ahead, are split ONCE into three bf16 planes [term][channel block][pixel][32 channels] and written to LDS;
+//   * wave (co block, ci block) reads its A fragments (dY) once per 16-pixel step and the B fragment of tap kw at pixel
+//     offset kw -- two ds_read_b64_tr_b16 per term -- and issues 6 MFMAs per (step, kw) into the accumulator tile of kw;
+//   * nothing is gathered per tap, no pixel walker, no masks in the loop: ~2 vector instructions per MFMA (3x3), 1.3 (5x5);
+//     52 KB of LDS, three (3x3) or two (5x5: registers) workgroups per CU.
+// Partial tiles [slice][co][K] and the ordered reduction are those of the other weight-gradient kernels.  Zero padding,
+// stride 1, K = 3 | 5, C % 64 == 0, Cout % 64 == 0, Ho % 2 == 0, Wo % 32 == 0.
+namespace wgh {
+constexpr int TW = 32, TR = 2, NPX = TR * TW;
+template <int KS> struct Geo {
+    static constexpr int HW = TW + KS - 1;                               // X columns per tile row
+    static constexpr int XPX = TR * HW;                                  // X pixels per tile (one filter row: no vertical halo)
+    static constexpr int NIX = (XPX * 16 + NT - 1) / NT;                 // 16-byte X items per thread (64 channels = 16 quads per pixel)
+    static constexpr unsigned DP_BYTES = 3 * 2 * NPX * 64;               // dY planes: [term][co block][pixel][32 ch x 2 B]
+    static constexpr unsigned XP_BASE = DP_BYTES;
+    static constexpr unsigned XP_BYTES = 3 * 2 * XPX * 64;               // X planes: [term][ci block][pixel][32 ch x 2 B]
+    static constexpr unsigned LDS_BYTES = XP_BASE + XP_BYTES;
+};
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) char lds_char;
+// 4 consecutive pixels (rows of 64 bytes) x the lane's channel: ds_read_b64_tr_b16 (all 64 lanes active); `imm` is a
+// compile-time constant at every call site and lands in the instruction's offset field
+__device__ __forceinline__ uint2 tr_read(lds_char* base, unsigned imm) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + imm));
+    return __builtin_bit_cast(uint2, v);
+}
+}  // namespace wgh
+
+struct WgradHaloArgs {
+    WgradArgs g;
+    int ncb;              // 64-channel input blocks
+    int tiles_w, tiles_img, ntiles_total, tiles_per_slice;
+};
+
+template <int KS, bool BIAS>
+__global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel(const WgradHaloArgs ha) {
+    using namespace wgh;
+    using G = Geo<KS>;
+    constexpr int HW = G::HW, XPX = G::XPX, NIX = G::NIX;
+    constexpr unsigned XP_BASE = G::XP_BASE;
+    const WgradArgs& a = ha.g;
+    __shared__ __attribute__((aligned(16))) float smem_all[G::LDS_BYTES / 4];
+    char* lds_c = reinterpret_cast<char*>(smem_all);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = KS * ha.ncb * a.ctiles * a.S;
+    int b = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (b >= nwg) return;
+    const int kh = b % KS; b /= KS;
+    const int cb = b % ha.ncb; b /= ha.ncb;
+    const int cob = b % a.ctiles;
+    const int s = b / a.ctiles;
+    const int co0 = cob * 64, ci0 = cb * 64;
+    const int t_beg = s * ha.tiles_per_slice;
+    const int t_end = min(t_beg + ha.tiles_per_slice, ha.ntiles_total);
+
+    // ---- items of this thread (tile-invariant part)
+    const int quad = tid & 15;                                          // 4 channels: block quad >> 3, unit quad & 7
+    // dY: item i = pixel (tid >> 4) + 16 i of the 2 x 32 tile
+    unsigned d_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = (tid >> 4) + 16 * i, r = p >> 5, c = p & 31;
+        d_voff[i] = (unsigned)((r * a.Wo + c) * (int)a.ldd + co0 + 4 * quad) * 4u;
+    }
+    const unsigned d_dst = (unsigned)((((quad >> 3) * NPX + (tid >> 4)) * 64) + (quad & 7) * 8);            // + term * 2 * NPX * 64 + 1024 i
+    // X: item i = pixel (tid >> 4) + 16 i of the 2 x HW strip: row hr, column hx
+    int x_hr[NIX], x_hx[NIX];
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+        const int p = (tid >> 4) + 16 * i;
+        x_hr[i] = p / HW; x_hx[i] = p - x_hr[i] * HW;
+    }
+    const bool x_last_ok = (tid >> 4) + 16 * (NIX - 1) < XPX;
+    static_assert(16 * (NIX - 1) < XPX, "only the last X item of a thread may be empty");
+    const unsigned x_dst = XP_BASE + (unsigned)((((quad >> 3) * XPX + (tid >> 4)) * 64) + (quad & 7) * 8);   // + term * 2 * XPX * 64 + 1024 i
+    const unsigned x_cq = (unsigned)(ci0 + 4 * quad) * 4u;
+
+    float4 dv[4], xv[NIX];
+    float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_bias = BIAS && a.bpart != nullptr && kh == 0 && cb == 0;
+    auto tile_load = [&](int t) {                                      // global -> registers (t < t_end: uniform)
+        const int n = t / ha.tiles_img, rem = t - n * ha.tiles_img;
+        const int ty = rem / ha.tiles_w, tx = rem - ty * ha.tiles_w;
+        const int oy0 = ty * TR, ox0 = tx * TW;
+        const long pix0 = ((long)n * a.Ho + oy0) * a.Wo + ox0;
+        const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dy + pix0 * a.ldd, (unsigned)(((long)a.Wo + TW) * a.ldd * 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dv[i] = buf_ld4(rd, d_voff[i]);
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)n * a.sN, (unsigned)((long)a.sN * 4));
+        const int iy0 = oy0 - a.pad + kh, ix0 = ox0 - a.pad;
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int iy = iy0 + x_hr[i], ix = ix0 + x_hx[i];
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && (i < NIX - 1 || x_last_ok);
+            xv[i] = buf_ld4(rx, ok ? (unsigned)(iy * (int)a.sH + ix * (int)a.sW) * 4u + x_cq : OOB);
+        }
+    };
+    auto put3 = [&](const float4 v, unsigned off, unsigned plane_stride) {
+        uint2 h, m, l;
+        x3::split2(v.x, v.y, h.x, m.x, l.x);
+        x3::split2(v.z, v.w, h.y, m.y, l.y);
+        *reinterpret_cast<uint2*>(lds_c + off) = h;
+        *reinterpret_cast<uint2*>(lds_c + off + plane_stride) = m;
+        *reinterpret_cast<uint2*>(lds_c + off + 2 * plane_stride) = l;
+    };
+    auto tile_split = [&]() {                                          // registers -> bf16 planes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            put3(dv[i], d_dst + 1024u * i, 2 * NPX * 64);
+            if (do_bias) { bs4.x += dv[i].x; bs4.y += dv[i].y; bs4.z += dv[i].z; bs4.w += dv[i].w; }
+        }
+#pragma unroll
+        for (int i = 0; i < NIX; ++i)
+            if (i < NIX - 1 || x_last_ok) put3(xv[i], x_dst + 1024u * i, 2 * XPX * 64);
+    };
+
+    // ---- fragment addresses: lane -> (half h: pixels 8h..8h+7 of the step; group gq: channels 16 gq..; row q, unit p of the block)
+    const int fh = lane >> 5, gq = (lane >> 4) & 1, fq = (lane & 15) >> 2, fp = lane & 3;
+    lds_char* const lds_a = (lds_char*)lds_c + (unsigned)((((wave & 1) * NPX + 8 * fh + fq) * 64) + 32 * gq + 8 * fp);
+    lds_char* const lds_b = (lds_char*)lds_c + (XP_BASE + (unsigned)((((wave >> 1) * XPX + 8 * fh + fq) * 64) + 32 * gq + 8 * fp));
+
+    typedef float accv_t __attribute__((ext_vector_type(16)));
+    accv_t acc[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    auto bf = [](uint2 lo, uint2 hi) { return __builtin_bit_cast(x3::bf16x8, u32x4{lo.x, lo.y, hi.x, hi.y}); };
+
+    if (t_beg < t_end) {
+        tile_load(t_beg);
+        tile_split();
+    }
+    __syncthreads();
+    for (int t = t_beg; t < t_end; ++t) {
+        if (t + 1 < t_end) tile_load(t + 1);                            // (uniform) flies under this tile's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            x3::bf16x8 fa[3];
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm)
+                fa[tm] = bf(tr_read(lds_a, (unsigned)(tm * 2 * NPX * 64 + ks * 16 * 64)),
+                            tr_read(lds_a, (unsigned)(tm * 2 * NPX * 64 + ks * 16 * 64 + 4 * 64)));
+            x3::bf16x8 fb[KS][3];
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) {
+                    const unsigned o = (unsigned)(tm * 2 * XPX * 64 + ((ks >> 1) * HW + 16 * (ks & 1) + kw) * 64);
+                    fb[kw][tm] = bf(tr_read(lds_b, o), tr_read(lds_b, o + 4 * 64));
+                }
+            // products largest first, the taps interleaved so that consecutive MFMAs never share an accumulator
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                const int ta = pr == 0 ? 0 : pr == 1 ? 0 : pr == 2 ? 1 : pr == 3 ? 0 : pr == 4 ? 1 : 2;
+                const int tb = pr == 0 ? 0 : pr == 1 ? 1 : pr == 2 ? 0 : pr == 3 ? 2 : pr == 4 ? 1 : 0;
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw)
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ta], fb[kw][tb], acc[kw], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                                // every wave is done with the planes of tile t
+        if (t + 1 < t_end) tile_split();
+        __syncthreads();
+    }
+
+    // ---- partial tile of this slice: C/D layout col = lane % 32 -> ci, row -> co: (r&3) + 8*(r>>2) + 4*(lane>>5)
+    {
+        const int ci = ci0 + (wave >> 1) * 32 + (lane & 31);
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+            const long k = (long)(kh * KS + kw) * a.C + ci;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                a.part[((long)s * a.Co + co) * a.K + k] = acc[kw][r];
+            }
+        }
+    }
+    if constexpr (BIAS) {
+        if (do_bias) {                                                   // (uniform per workgroup; the planes are dead)
+            float4* red = reinterpret_cast<float4*>(smem_all);
+            red[tid] = bs4;                                              // thread -> quad tid & 15, pixel lane tid >> 4
+            __syncthreads();
+            if (tid < 64) {
+                const int q4 = tid >> 2, e = tid & 3;
+                float sum = 0.f;
+                for (int j = 0; j < 16; ++j) sum += reinterpret_cast<const float*>(&red[j * 16 + q4])[e];
+                a.bpart[(long)s * a.Co + co0 + tid] = sum;
+            }
+        }
+    }
+}
+
+// Shapes the halo weight-gradient kernel takes (the caller has established the 16-byte path: NHWC, aligned, no affine).
+static bool wgrad_halo_eligible(const WgradArgs& a, bool vec) {
+    return vec && a.mode == MODE_ZERO && a.stride == 1 && a.KH == a.KW && (a.KH == 3 || a.KH == 5) && a.pad < a.KH &&
+           a.C % 64 == 0 && a.Co % 64 == 0 && a.Ho % wgh::TR == 0 && a.Wo % wgh::TW == 0 && a.ldd % 4 == 0 &&
+           (long)a.sN * 4 < 0x7fffffffL && ((long)a.Wo + wgh::TW) * a.ldd * 4 < 0x7fffffffL && a.Ho <= a.H + 2 * a.pad - a.KH + 1;
+}
+
+// slices: as many as keep every resident workgroup slot busy once (3x3: three per CU, 5x5: two), never more than the caller's
+// workspace plan provides (wgrad_plan's S)
+static int launch_wgrad_halo(WgradArgs a, int s_plan, hipStream_t st, bool bias) {
+    WgradHaloArgs ha;
+    ha.ncb = a.C / 64;
+    a.ctiles = a.Co / 64;
+    ha.tiles_w = a.Wo / wgh::TW;
+    ha.tiles_img = (a.Ho / wgh::TR) * ha.tiles_w;
+    ha.ntiles_total = a.N * ha.tiles_img;
+    const int per_slice_wgs = a.KH * ha.ncb * a.ctiles;
+    const int slots = (a.KH == 3 ? 768 : 512);
+    int S = slots / per_slice_wgs;
+    if (S < 1) S = 1;
+    if (S > s_plan) S = s_plan;
+    if (S > ha.ntiles_total) S = ha.ntiles_total;
+    ha.tiles_per_slice = (ha.ntiles_total + S - 1) / S;
+    S = (ha.ntiles_total + ha.tiles_per_slice - 1) / ha.tiles_per_slice;
+    a.S = S;
+    ha.g = a;
+    const long nwg = (long)per_slice_wgs * S;
+    const dim3 grid((unsigned)((nwg + 7) / 8 * 8)), block(NT);
+    if (a.KH == 3) {
+        if (bias) hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<3, true>), grid, block, 0, st, ha);
+        else hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<3, false>), grid, block, 0, st, ha);
+    } else {
+        if (bias) hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<5, true>), grid, block, 0, st, ha);
+        else hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<5, false>), grid, block, 0, st, ha);
+    }
+    return S;
+}

@@ -342,15 +342,14 @@ static int launch_conv_x3_halo(ConvArgs& a, hipStream_t st) {
     a.ntiles = a.Co / 64;
     const long nblk = (long)a.mtiles * a.ntiles;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
-#ifdef PD_HALO_K3_OCC3
-    constexpr int NSB3 = 2;
+    // Weight ring of two chunks for both filter sizes (round 4, same box): with it the 3x3 workgroup fits a CU three times
+    // (53 KB, 166 registers) -- 3x3x64 @256x320 forward 154 -> 185 TF, data gradient 185 -> 200, @128x160 180 -> 194 / 168 ->
+    // 189 against the three-chunk ring at two workgroups per CU; for 5x5 (62 KB: two per CU either way) the two rings are
+    // equal (185 / 222 TF).  PD_HALO_NSB3 (tools/build_probe.sh) builds the three-chunk ring for A/B runs.
+#ifdef PD_HALO_NSB3
+    constexpr int NSB3 = 3, NSB5 = 3;
 #else
-    constexpr int NSB3 = 3;
-#endif
-#ifdef PD_HALO_K5_NSB2
-    constexpr int NSB5 = 2;
-#else
-    constexpr int NSB5 = 3;
+    constexpr int NSB3 = 2, NSB5 = 2;
 #endif
     if (a.KH == 3) {
         if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, 3, NSB3>), grid, block, 0, st, a);

@@ -212,7 +212,9 @@ def test_which_shapes_take_the_bf16_split_kernels():
     assert lib.pd_conv2d_uses_x3(4 * M16, 64, 128, 3, 3, 2, 1, 2, 0, 0, 0, 0, AUTO) == 0       # stride-2 data gradient (parity launches)
     assert lib.pd_conv2d_uses_x3(M16 // 4, 128, 64, 3, 3, 2, 1, 0, 0, 0, 0, 0, AUTO) == 2      # stride-2 forward
     # M, Cout, C, KH, KW, stride, pad, mode, H, W, Ho, Wo
-    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 1
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 2          # halo-tile kernel (transposed LDS reads)
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, IM2COL) == 1        # ... unless the caller asks for the gather kernel
+    assert lib.pd_conv2d_wgrad_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 64, 80, 64, 80, AUTO) == 1   # Wo = 80: no whole 32-pixel tiles
     assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 1   # decoder: ReflectionPad2d(1) + Conv3x3
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 5, 5, 1, 2, 1, 256, 320, 256, 320, AUTO) == 0       # reflect 5x5: general kernel
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 0       # 32-wide co tile

@@ -600,7 +600,7 @@ def test_bf16x3_kernels_nonfinite_and_extreme_inputs():
     check_maps("dgrad", *_three(lambda: ops.conv2d_dgrad(dyd, wd, (H, W), stride=1, pad=1)), ref)
     # weight gradient: special values in X reach dW[:, ci, :, :] of their channel; dY small so that 3.39e38 * dy stays finite
     dsm = (dyv * 1e-3).cuda().contiguous(memory_format=torch.channels_last)
-    assert ops.lib.pd_conv2d_wgrad_uses_x3(N * H * W, Co, C, k, k, 1, 1, 0, H, W, H, W, ops.CONV_AUTO) == 1
+    assert ops.lib.pd_conv2d_wgrad_uses_x3(N * H * W, Co, C, k, k, 1, 1, 0, H, W, H, W, ops.CONV_AUTO) == 2          # the halo-tile kernel
     split, fp32 = _three(lambda: ops.conv2d_wgrad(xd, dsm, w.shape, stride=1, pad=1))
     ref = torch.autograd.grad(F.conv2d(xs.double(), wv := w.double().requires_grad_(True), None, padding=1), wv, (dyv * 1e-3).double())[0]
     ch = {name: c for name, (n, c, h, ww, v) in special.items()}

@@ -113,7 +113,8 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
     # (the bf16-split kernel plans for its 512 resident workgroups: one round when that leaves >= 4 slices per tile)
     assert S >= (4 if x3 == "1" else 15), f"weight gradient not in the many-slice regime (S = {S})"
     dw, lab = _labels(lambda: ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p))
-    assert lab == (["conv_wgrad_x3c_kernel"] if x3 == "1" else ["conv_wgrad_kernel"]), lab
+    halo_w = x3 == "1" and k in (3, 5) and s == 1 and C % 64 == 0 and Co % 64 == 0 and ref.shape[2] % 2 == 0 and ref.shape[3] % 32 == 0
+    assert lab == (["conv_wgrad_halo_x3_kernel"] if halo_w else ["conv_wgrad_x3c_kernel"] if x3 == "1" else ["conv_wgrad_kernel"]), lab
     _close(dw.cpu(), wr.grad, what="wgrad")
 
     dx, lab = _labels(lambda: ops.conv2d_dgrad(dyd, wd, (H, W), stride=s, pad=p))
@@ -324,7 +325,7 @@ def test_full_resolution_training_step_matches_oracle(B, tmp_path, monkeypatch):
         assert n_prod >= 30, f"production tiles not exercised: {n_prod}"
         assert any(l.startswith(("conv_igemm_x3_kernel", "conv_halo_x3_kernel")) for l in lab) == (knob == "1")
         if B == 16 and knob == "1":          # the launch labels of bench.py's step: both split tile sizes and the split weight gradient
-            assert {"conv_halo_x3_kernel<8x32,64>", "conv_igemm_x3_kernel<256,64>", "conv_igemm_x3_kernel<128,64>", "conv_wgrad_x3c_kernel"} <= set(lab), sorted(set(lab))
+            assert {"conv_halo_x3_kernel<8x32,64>", "conv_igemm_x3_kernel<256,64>", "conv_igemm_x3_kernel<128,64>", "conv_wgrad_x3c_kernel", "conv_wgrad_halo_x3_kernel"} <= set(lab), sorted(set(lab))
         gpu_grads = {f"{mn}.{k}": v.grad.detach().cpu().clone() for mn in tr.models for k, v in tr.models[mn].named_parameters()
                      if v.grad is not None}
         for s in range(4):

@@ -10,7 +10,7 @@ run() {
 import sys, json
 for l in sys.stdin:
     d = json.loads(l)
-    print("%-44s fwd %6.3f ms %6.1f TF   dgrad %6.3f ms %6.1f TF" % (d["layer"], d["fwd_ms"], d["fwd_TF"], d.get("dgrad_ms", 0), d.get("dgrad_TF", 0)))' >> $OUT || exit 1
+    print("%-44s fwd %6.3f ms %6.1f TF   dgrad %6.3f ms %6.1f TF   wgrad %6.3f ms %6.1f TF" % (d["layer"], d["fwd_ms"], d["fwd_TF"], d.get("dgrad_ms", 0), d.get("dgrad_TF", 0), d["wgrad_ms"], d["wgrad_TF"]))' >> $OUT || exit 1
   done
 }
 echo "== product (halo)" >> $OUT; unset PD_LIB; PD_CONV_HALO=1 run
