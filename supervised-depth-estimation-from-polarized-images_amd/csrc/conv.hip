@@ -2480,6 +2480,12 @@ void wgrad_plan(long M, int Co, int K, unsigned flags, int* S, long* mper) {
 extern "C" size_t pd_conv2d_wgrad_workspace(long M, int Co, int K, unsigned flags) {
     int S; long mper;
     wgrad_plan(M, Co, K, flags, &S, &mper);
+    // (the halo-tile kernel cuts its own slices; Cout and K bound their number)
+    if (wgrad_x3c_enabled(flags) && !(flags & (PD_CONV_GENERAL_KERNELS | PD_CONV_X3_IM2COL))) {
+        const int sh = wgrad_halo_slices_bound(Co, K);
+        const long cap = (M + 63) / 64;
+        S = S > (sh < cap ? sh : (int)cap) ? S : (sh < cap ? sh : (int)cap);
+    }
     return ((size_t)S * Co * K + (size_t)S * Co) * sizeof(float);
 }
 
@@ -2538,8 +2544,10 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     PD_REQUIRE((a.mper / ((long)Ho * Wo) + 2) * sN * 4 < 0x7fffffffL, "pd_conv2d_wgrad: image too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
     if (wgrad_x3c_enabled(flags) && !(flags & (PD_CONV_GENERAL_KERNELS | PD_CONV_X3_IM2COL)) && wgrad_halo_eligible(a, vec)) {
-        // halo-tile kernel: its slice count never exceeds the plan the workspace was sized for
-        const int S = launch_wgrad_halo(a, a.S, st, dbias != nullptr);
+        // halo-tile kernel: its slice count never exceeds what the workspace holds
+        const size_t per_slice = ((size_t)Co * a.K + Co) * sizeof(float);
+        const int S = launch_wgrad_halo(a, (int)std::min<size_t>(ws_bytes / per_slice, 1 << 20), st, dbias != nullptr);
+        a.bpart = dbias ? a.part + (size_t)S * Co * a.K : nullptr;
         int rc = pd::check_launch("pd_conv2d_wgrad");
         if (rc) return rc;
         const long nw = (long)Co * a.K;

@@ -215,9 +215,23 @@ static bool wgrad_halo_eligible(const WgradArgs& a, bool vec) {
            (long)a.sN * 4 < 0x7fffffffL && ((long)a.Wo + wgh::TW) * a.ldd * 4 < 0x7fffffffL && a.Ho <= a.H + 2 * a.pad - a.KH + 1;
 }
 
-// slices: as many as keep every resident workgroup slot busy once (3x3: three per CU, 5x5: two), never more than the caller's
-// workspace plan provides (wgrad_plan's S)
-static int launch_wgrad_halo(WgradArgs a, int s_plan, hipStream_t st, bool bias) {
+// Slices of the halo kernel for a [Cout][K] gradient: as many as keep every resident workgroup slot busy once (3x3: three per
+// CU, 5x5: two).  pd_conv2d_wgrad_workspace knows Cout and K only: the larger of the two filter sizes K is a multiple of.
+static int wgrad_halo_slices(int KS, int C, int Co) {
+    const int per_slice_wgs = KS * (C / 64) * (Co / 64);
+    const int S = (KS == 3 ? 768 : 512) / (per_slice_wgs > 0 ? per_slice_wgs : 1);
+    return S < 1 ? 1 : S;
+}
+static int wgrad_halo_slices_bound(int Co, int K) {
+    int best = 0;
+    if (Co % 64 != 0) return 0;
+    for (int KS : {3, 5})
+        if (K % (KS * KS * 64) == 0) { const int S = wgrad_halo_slices(KS, K / (KS * KS), Co); best = S > best ? S : best; }
+    return best;
+}
+
+// s_cap: slices the caller's workspace holds
+static int launch_wgrad_halo(WgradArgs a, int s_cap, hipStream_t st, bool bias) {
     WgradHaloArgs ha;
     ha.ncb = a.C / 64;
     a.ctiles = a.Co / 64;
@@ -225,14 +239,13 @@ static int launch_wgrad_halo(WgradArgs a, int s_plan, hipStream_t st, bool bias)
     ha.tiles_img = (a.Ho / wgh::TR) * ha.tiles_w;
     ha.ntiles_total = a.N * ha.tiles_img;
     const int per_slice_wgs = a.KH * ha.ncb * a.ctiles;
-    const int slots = (a.KH == 3 ? 768 : 512);
-    int S = slots / per_slice_wgs;
-    if (S < 1) S = 1;
-    if (S > s_plan) S = s_plan;
+    int S = wgrad_halo_slices(a.KH, a.C, a.Co);
+    if (S > s_cap) S = s_cap;
     if (S > ha.ntiles_total) S = ha.ntiles_total;
     ha.tiles_per_slice = (ha.ntiles_total + S - 1) / S;
     S = (ha.ntiles_total + ha.tiles_per_slice - 1) / ha.tiles_per_slice;
     a.S = S;
+    if (a.bpart) a.bpart = a.part + (size_t)S * a.Co * a.K;          // bias partials behind the S weight tiles
     ha.g = a;
     const long nwg = (long)per_slice_wgs * S;
     const dim3 grid((unsigned)((nwg + 7) / 8 * 8)), block(NT);
