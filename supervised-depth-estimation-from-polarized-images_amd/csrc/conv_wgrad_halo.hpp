@@ -9,7 +9,7 @@
 // gfx950's ds_read_b64_tr_b16 reads a 4 x 16 block of 16-bit elements per 16-lane group and hands each lane a COLUMN: from a
 // plain [pixel][channel] bf16 image a lane receives four consecutive pixels of its channel -- the operand layout, for free,
 // starting at ANY pixel.  So here a workgroup owns one filter row kh, 64 output and 64 input channels and walks 2 x 32-pixel
-// tiles of its slice:
+// tiles of its slice (4 x 16 / 8 x 8 where 32 does not divide the width):
 //   * dY tile (64 px x 64 co) and X row pair (2 x (32 + K - 1) px x 64 ci, shifted by kh) go global -> registers one tile
 //     ahead, are split ONCE into three bf16 planes [term][channel block][pixel][32 channels] and written to LDS;
 //   * wave (co block, ci block) reads its A fragments (dY) once per 16-pixel step and the B fragment of tap kw at pixel
@@ -17,10 +17,14 @@
 //   * nothing is gathered per tap, no pixel walker, no masks in the loop: ~2 vector instructions per MFMA (3x3), 1.3 (5x5);
 //     52 KB of LDS, three (3x3) or two (5x5: registers) workgroups per CU.
 // Partial tiles [slice][co][K] and the ordered reduction are those of the other weight-gradient kernels.  Zero padding,
-// stride 1, K = 3 | 5, C % 64 == 0, Cout % 64 == 0, Ho % 2 == 0, Wo % 32 == 0.
+// stride 1, K = 3 | 5, C % 64 == 0, Cout % 64 == 0, the output grid a whole number of 2 x 32, 4 x 16 or 8 x 8 tiles.
 namespace wgh {
-constexpr int TW = 32, TR = 2, NPX = TR * TW;
-template <int KS> struct Geo {
+constexpr int NPX = 64;                                                  // pixels per tile: TR rows x TW columns, 4 MFMA k-steps
+// TW = 32 | 16 | 8 (the widest that divides Wo): 2 x 32, 4 x 16 or 8 x 8 pixel tiles -- a 16-pixel step is then half a row,
+// a row or two rows; either way the step's pixels are the tile's row-major pixels 16 ks .. 16 ks + 15, in runs of four
+// consecutive columns (what one transposed read takes).
+template <int KS, int TW> struct Geo {
+    static constexpr int TR = NPX / TW;
     static constexpr int HW = TW + KS - 1;                               // X columns per tile row
     static constexpr int XPX = TR * HW;                                  // X pixels per tile (one filter row: no vertical halo)
     static constexpr int NIX = (XPX * 16 + NT - 1) / NT;                 // 16-byte X items per thread (64 channels = 16 quads per pixel)
@@ -46,11 +50,11 @@ struct WgradHaloArgs {
     int tiles_w, tiles_img, ntiles_total, tiles_per_slice;
 };
 
-template <int KS, bool BIAS>
+template <int KS, int TW, bool BIAS>
 __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel(const WgradHaloArgs ha) {
     using namespace wgh;
-    using G = Geo<KS>;
-    constexpr int HW = G::HW, XPX = G::XPX, NIX = G::NIX;
+    using G = Geo<KS, TW>;
+    constexpr int HW = G::HW, XPX = G::XPX, NIX = G::NIX, TR = G::TR;
     constexpr unsigned XP_BASE = G::XP_BASE;
     const WgradArgs& a = ha.g;
     __shared__ __attribute__((aligned(16))) float smem_all[G::LDS_BYTES / 4];
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
     unsigned d_voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int p = (tid >> 4) + 16 * i, r = p >> 5, c = p & 31;
+        const int p = (tid >> 4) + 16 * i, r = p / TW, c = p % TW;
         d_voff[i] = (unsigned)((r * a.Wo + c) * (int)a.ldd + co0 + 4 * quad) * 4u;
     }
     const unsigned d_dst = (unsigned)((((quad >> 3) * NPX + (tid >> 4)) * 64) + (quad & 7) * 8);            // + term * 2 * NPX * 64 + 1024 i
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
         const int ty = rem / ha.tiles_w, tx = rem - ty * ha.tiles_w;
         const int oy0 = ty * TR, ox0 = tx * TW;
         const long pix0 = ((long)n * a.Ho + oy0) * a.Wo + ox0;
-        const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dy + pix0 * a.ldd, (unsigned)(((long)a.Wo + TW) * a.ldd * 4));
+        const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dy + pix0 * a.ldd, (unsigned)(((long)(TR - 1) * a.Wo + TW) * a.ldd * 4));
 #pragma unroll
         for (int i = 0; i < 4; ++i) dv[i] = buf_ld4(rd, d_voff[i]);
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)n * a.sN, (unsigned)((long)a.sN * 4));
@@ -133,7 +137,9 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
     // ---- fragment addresses: lane -> (half h: pixels 8h..8h+7 of the step; group gq: channels 16 gq..; row q, unit p of the block)
     const int fh = lane >> 5, gq = (lane >> 4) & 1, fq = (lane & 15) >> 2, fp = lane & 3;
     lds_char* const lds_a = (lds_char*)lds_c + (unsigned)((((wave & 1) * NPX + 8 * fh + fq) * 64) + 32 * gq + 8 * fp);
-    lds_char* const lds_b = (lds_char*)lds_c + (XP_BASE + (unsigned)((((wave >> 1) * XPX + 8 * fh + fq) * 64) + 32 * gq + 8 * fp));
+    // X strip (row-major, HW columns): pixel 8 fh + 4 e + q of step ks sits at (row0(ks) + hrow, col0(ks) + hcol + 4 e + q + kw)
+    constexpr int HROW = TW >= 16 ? 0 : 1, HCOL = TW >= 16 ? 8 : 0;        // the upper half-wave: 8 columns on (TW >= 16) or the next row (TW = 8)
+    lds_char* const lds_b = (lds_char*)lds_c + (XP_BASE + (unsigned)((((wave >> 1) * XPX + fh * (HROW * HW + HCOL) + fq) * 64) + 32 * gq + 8 * fp));
 
     typedef float accv_t __attribute__((ext_vector_type(16)));
     accv_t acc[KS];
@@ -162,7 +168,8 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
             for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
                 for (int tm = 0; tm < 3; ++tm) {
-                    const unsigned o = (unsigned)(tm * 2 * XPX * 64 + ((ks >> 1) * HW + 16 * (ks & 1) + kw) * 64);
+                    const int row0 = TW == 32 ? (ks >> 1) : TW == 16 ? ks : 2 * ks, col0 = TW == 32 ? 16 * (ks & 1) : 0;
+                    const unsigned o = (unsigned)(tm * 2 * XPX * 64 + (row0 * HW + col0 + kw) * 64);
                     fb[kw][tm] = bf(tr_read(lds_b, o), tr_read(lds_b, o + 4 * 64));
                 }
             // products largest first, the taps interleaved so that consecutive MFMAs never share an accumulator
@@ -209,10 +216,14 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
 }
 
 // Shapes the halo weight-gradient kernel takes (the caller has established the 16-byte path: NHWC, aligned, no affine).
+// tile width: the widest of 32 | 16 | 8 whose 64-pixel tile (2 | 4 | 8 rows) divides the output grid; 0: none
+static int wgrad_halo_tw(int Ho, int Wo) {
+    return (Wo % 32 == 0 && Ho % 2 == 0) ? 32 : (Wo % 16 == 0 && Ho % 4 == 0) ? 16 : (Wo % 8 == 0 && Ho % 8 == 0) ? 8 : 0;
+}
 static bool wgrad_halo_eligible(const WgradArgs& a, bool vec) {
     return vec && a.mode == MODE_ZERO && a.stride == 1 && a.KH == a.KW && (a.KH == 3 || a.KH == 5) && a.pad < a.KH &&
-           a.C % 64 == 0 && a.Co % 64 == 0 && a.Ho % wgh::TR == 0 && a.Wo % wgh::TW == 0 && a.ldd % 4 == 0 &&
-           (long)a.sN * 4 < 0x7fffffffL && ((long)a.Wo + wgh::TW) * a.ldd * 4 < 0x7fffffffL && a.Ho <= a.H + 2 * a.pad - a.KH + 1;
+           a.C % 64 == 0 && a.Co % 64 == 0 && wgrad_halo_tw(a.Ho, a.Wo) != 0 && a.ldd % 4 == 0 &&
+           (long)a.sN * 4 < 0x7fffffffL && (8L * a.Wo + 32) * a.ldd * 4 < 0x7fffffffL && a.Ho <= a.H + 2 * a.pad - a.KH + 1;
 }
 
 // Slices of the halo kernel for a [Cout][K] gradient: as many as keep every resident workgroup slot busy once (3x3: three per
@@ -235,8 +246,9 @@ static int launch_wgrad_halo(WgradArgs a, int s_cap, hipStream_t st, bool bias) 
     WgradHaloArgs ha;
     ha.ncb = a.C / 64;
     a.ctiles = a.Co / 64;
-    ha.tiles_w = a.Wo / wgh::TW;
-    ha.tiles_img = (a.Ho / wgh::TR) * ha.tiles_w;
+    const int tw = wgrad_halo_tw(a.Ho, a.Wo);
+    ha.tiles_w = a.Wo / tw;
+    ha.tiles_img = (a.Ho / (wgh::NPX / tw)) * ha.tiles_w;
     ha.ntiles_total = a.N * ha.tiles_img;
     const int per_slice_wgs = a.KH * ha.ncb * a.ctiles;
     int S = wgrad_halo_slices(a.KH, a.C, a.Co);
@@ -249,12 +261,10 @@ static int launch_wgrad_halo(WgradArgs a, int s_cap, hipStream_t st, bool bias) 
     ha.g = a;
     const long nwg = (long)per_slice_wgs * S;
     const dim3 grid((unsigned)((nwg + 7) / 8 * 8)), block(NT);
-    if (a.KH == 3) {
-        if (bias) hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<3, true>), grid, block, 0, st, ha);
-        else hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<3, false>), grid, block, 0, st, ha);
-    } else {
-        if (bias) hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<5, true>), grid, block, 0, st, ha);
-        else hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<5, false>), grid, block, 0, st, ha);
-    }
+#define PD_WGH(KSV, TWV) do { if (bias) hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<KSV, TWV, true>), grid, block, 0, st, ha); \
+                           else hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<KSV, TWV, false>), grid, block, 0, st, ha); } while (0)
+    if (a.KH == 3) { if (tw == 32) PD_WGH(3, 32); else if (tw == 16) PD_WGH(3, 16); else PD_WGH(3, 8); }
+    else { if (tw == 32) PD_WGH(5, 32); else if (tw == 16) PD_WGH(5, 16); else PD_WGH(5, 8); }
+#undef PD_WGH
     return S;
 }

@@ -18,11 +18,14 @@
 // split and written between the MFMAs of the current group's LAST tap, behind a barrier that follows that tap's fragment
 // reads (the planes are free from there on): no serial split phase.  Epilogue (bias, ELU, addend, BatchNorm partial sums, LDS transposition
 // to full 128-byte lines) as there.  Zero padding or the stride-1 data gradient, K = 3 | 5, C % 16 == 0, Cout % 64 == 0,
-// Ho % 8 == 0, Wo % 32 == 0.
+// the output grid a whole number of 8 x 32, 16 x 16 or 32 x 8 tiles.
 namespace x3h {
-constexpr int TW = 32, TR = 8, CK = 16;
+constexpr int CK = 16;
 constexpr unsigned BS_BYTES = 64 * CK * 4, BP_BYTES = 64 * CK * 2;
-template <int KS, int NSB> struct Geo {
+// TW = 32 | 16 | 8: the 256-pixel output tile is 8 x 32, 16 x 16 or 32 x 8; an MFMA row block (32 pixels) is then one row,
+// two rows of 16 or four rows of 8 -- the widest tile that divides the output grid
+template <int KS, int NSB, int TW> struct Geo {
+    static constexpr int TR = 256 / TW, BR = 32 / TW;
     static constexpr int HW = TW + KS - 1, HH = TR + KS - 1, HP = HW * HH;
     static constexpr int NI = (HP * 4 + NT - 1) / NT;                 // 16-byte halo items per thread and channel group
     static constexpr unsigned AP_BYTES = 3 * 2 * HP * 16;             // A planes: [term][half][halo pixel] x 16 B
@@ -33,11 +36,11 @@ template <int KS, int NSB> struct Geo {
 
 // NSB = depth of the weight staging ring: 3 (requests three chunks ahead; two workgroups per CU) or 2 (as conv_igemm_x3_kernel;
 // with the 3x3 halo the workgroup then fits a CU three times -- 53 KB of LDS, <= 168 registers)
-template <int MODE, int KS, int NSB>
+template <int MODE, int KS, int NSB, int TW>
 __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x3_kernel(const ConvArgs a) {
     using namespace x3h;
-    using G = Geo<KS, NSB>;
-    constexpr int HW = G::HW, HP = G::HP, NI = G::NI, T = KS * KS;
+    using G = Geo<KS, NSB, TW>;
+    constexpr int HW = G::HW, HP = G::HP, NI = G::NI, T = KS * KS, TR = G::TR, BR = G::BR;
     constexpr unsigned BS_BASE = G::BS_BASE, BP_BASE = G::BP_BASE;
     static_assert(G::LDS_BYTES >= 4 * 64 * 32 * 4 + 4 * 64 * 2 * 4, "the epilogue's transposition tiles reuse the ring");
     __shared__ __attribute__((aligned(16))) float smem_all[G::LDS_BYTES / 4];
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
 
     // ---- fragment addresses
     const int frow = lane & 31, fh = lane >> 5;
-    const unsigned fa_base = (unsigned)((fh * HP + 2 * wave * HW + frow) * 16);     // + tap offset + (term * 2 * HP + i * HW) * 16
+    // row block 2 wave + i of the tile = BR output rows of TW pixels: lane -> (row frow / TW, column frow % TW) of the block
+    const unsigned fa_base = (unsigned)((fh * HP + (2 * wave * BR + frow / TW) * HW + frow % TW) * 16);   // + tap offset + (term * 2 * HP + i * BR * HW) * 16
     unsigned fb_off = BP_BASE + (unsigned)frow * (CK * 2) + 16u * (fh ^ ((frow >> 3) & 1));
     asm volatile("" : "+v"(fb_off));
     const int srow = tid >> 2, sls = (tid & 3) ^ ((srow >> 2) & 3);            // weight split: thread -> its 16 bytes of the staging tile
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int t = 0; t < 3; ++t)
-                av[i][t] = *reinterpret_cast<const u32x4*>(lds_c + fa + (unsigned)((t * 2 * HP + i * HW) * 16));
+                av[i][t] = *reinterpret_cast<const u32x4*>(lds_c + fa + (unsigned)((t * 2 * HP + i * BR * HW) * 16));
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -269,15 +273,18 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
         const long img_m = (long)img * a.Ho * a.Wo;
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + img_m * a.ldy, (unsigned)((long)a.Ho * a.Wo * a.ldy * 4));
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.add ? a.add + img_m * a.ld_add : a.y, a.add ? (unsigned)((long)a.Ho * a.Wo * a.ld_add * 4) : 0u);
-        // pixel index (inside the image) of row block i of this wave, row lane/8 of an 8-row store group
-        const int pix0 = (oy0 + 2 * wave) * a.Wo + ox0;
+        // pixel index (inside the image) of row (t & 3) * 8 + lane / 8 of row block t >> 2 of this wave (t: the 8-row store group)
+        auto pix_of = [&](int t) {
+            const int r = (t & 3) * 8 + (lane >> 3);
+            return (oy0 + (2 * wave + (t >> 2)) * BR + r / TW) * a.Wo + ox0 + r % TW;
+        };
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float4 addv[8];
             if (a.add) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int pix = pix0 + (t >> 2) * a.Wo + (t & 3) * 8 + (lane >> 3);
+                    const int pix = pix_of(t);
                     addv[t] = buf_ld4(ra, (unsigned)(pix * (int)a.ld_add + n0 + 32 * j + 4 * (lane & 7)) * 4u);
                 }
             }
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const int pix = pix0 + (t >> 2) * a.Wo + (t & 3) * 8 + (lane >> 3);
+                const int pix = pix_of(t);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[t]), ry,
                                                       (unsigned)(pix * (int)a.ldy + n0 + 32 * j + 4 * (lane & 7)) * 4u, 0, 0);
             }
@@ -316,12 +323,18 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
         }
         if (a.stats) {
             __syncthreads();
-            if (tid < 2 * 64) {
+            if (a.stats_rows == 128) {                         // two rows of `stats` per tile: waves 0-1 | 2-3
+                if (tid < 2 * 64) {
+                    const int row_l = tid >> 6, cl = tid & 63;
+                    const float t1 = red[2 * row_l][cl][0] + red[2 * row_l + 1][cl][0];
+                    const float t2 = red[2 * row_l][cl][1] + red[2 * row_l + 1][cl][1];
+                    float* o = a.stats + ((long)(mt * 2 + row_l) * a.Co + n0 + cl) * 2;
+                    o[0] = t1; o[1] = t2;
+                }
+            } else {                                           // M < 65536: one row per 64 output pixels = per wave
                 const int row_l = tid >> 6, cl = tid & 63;
-                const float t1 = red[2 * row_l][cl][0] + red[2 * row_l + 1][cl][0];
-                const float t2 = red[2 * row_l][cl][1] + red[2 * row_l + 1][cl][1];
-                float* o = a.stats + ((long)(mt * 2 + row_l) * a.Co + n0 + cl) * 2;
-                o[0] = t1; o[1] = t2;
+                float* o = a.stats + ((long)(mt * 4 + row_l) * a.Co + n0 + cl) * 2;
+                o[0] = red[row_l][cl][0]; o[1] = red[row_l][cl][1];
             }
         }
     }
@@ -330,15 +343,21 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
 // Shapes the halo kernel takes (the caller has established x3 eligibility: vector path, Cout % 64 == 0, alignment, no scale,
 // activation none | ELU): square 3x3 / 5x5 filter, stride 1, zero padding or the stride-1 data gradient, whole 16-channel
 // groups, whole 8 x 32 output tiles, 128-row BatchNorm statistics, an image within 32-bit byte offsets.
+// tile width: the widest of 32 | 16 | 8 whose 256-pixel tile (8 | 16 | 32 rows) divides the output grid; 0: none
+static int x3_halo_tw(int Ho, int Wo) {
+    return (Wo % 32 == 0 && Ho % 8 == 0) ? 32 : (Wo % 16 == 0 && Ho % 16 == 0) ? 16 : (Wo % 8 == 0 && Ho % 32 == 0) ? 8 : 0;
+}
 static bool x3_halo_eligible(const ConvArgs& a) {
+    // (at least 320 workgroups: below that the gather kernel's 128-row tiles fill the chip better)
     return (a.KH == 3 || a.KH == 5) && a.KW == a.KH && a.stride == 1 && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) &&
-           a.C % x3h::CK == 0 && a.Ho % x3h::TR == 0 && a.Wo % x3h::TW == 0 && a.stats_rows == 128 && a.sC == 1 &&
+           a.C % x3h::CK == 0 && x3_halo_tw(a.Ho, a.Wo) != 0 && (a.M / 256) * (a.Co / 64) >= 320 && (a.stats_rows == 128 || a.stats_rows == 64) && a.sC == 1 &&
            (long)a.sN * 4 < 0x7fffffffL && (long)a.Ho * a.Wo * a.ldy * 4 < 0x7fffffffL &&
            (!a.add || (long)a.Ho * a.Wo * a.ld_add * 4 < 0x7fffffffL);
 }
 
 static int launch_conv_x3_halo(ConvArgs& a, hipStream_t st) {
-    a.mtiles = a.N * (a.Ho / x3h::TR) * (a.Wo / x3h::TW);
+    const int tw = x3_halo_tw(a.Ho, a.Wo);
+    a.mtiles = a.N * (a.Ho / (256 / tw)) * (a.Wo / tw);
     a.ntiles = a.Co / 64;
     const long nblk = (long)a.mtiles * a.ntiles;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
@@ -351,12 +370,10 @@ static int launch_conv_x3_halo(ConvArgs& a, hipStream_t st) {
 #else
     constexpr int NSB3 = 2, NSB5 = 2;
 #endif
-    if (a.KH == 3) {
-        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, 3, NSB3>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, 3, NSB3>), grid, block, 0, st, a);
-    } else {
-        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, 5, NSB5>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, 5, NSB5>), grid, block, 0, st, a);
-    }
+#define PD_HALO(KSV, NSBV, TWV) do { if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, KSV, NSBV, TWV>), grid, block, 0, st, a); \
+                                     else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, KSV, NSBV, TWV>), grid, block, 0, st, a); } while (0)
+    if (a.KH == 3) { if (tw == 32) PD_HALO(3, NSB3, 32); else if (tw == 16) PD_HALO(3, NSB3, 16); else PD_HALO(3, NSB3, 8); }
+    else { if (tw == 32) PD_HALO(5, NSB5, 32); else if (tw == 16) PD_HALO(5, NSB5, 16); else PD_HALO(5, NSB5, 8); }
+#undef PD_HALO
     return pd::check_launch("pd_conv2d");
 }

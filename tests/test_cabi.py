@@ -214,7 +214,9 @@ def test_which_shapes_take_the_bf16_split_kernels():
     # M, Cout, C, KH, KW, stride, pad, mode, H, W, Ho, Wo
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 2          # halo-tile kernel (transposed LDS reads)
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, IM2COL) == 1        # ... unless the caller asks for the gather kernel
-    assert lib.pd_conv2d_wgrad_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 64, 80, 64, 80, AUTO) == 1   # Wo = 80: no whole 32-pixel tiles
+    assert lib.pd_conv2d_wgrad_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 64, 80, 64, 80, AUTO) == 2   # Wo = 80: 4 x 16 tiles
+    assert lib.pd_conv2d_wgrad_uses_x3(16 * 32 * 40, 256, 256, 3, 3, 1, 1, 0, 32, 40, 32, 40, AUTO) == 2   # 8 x 8 tiles
+    assert lib.pd_conv2d_wgrad_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 16, 20, 16, 20, AUTO) == 1   # Wo = 20: the gather kernel
     assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 1   # decoder: ReflectionPad2d(1) + Conv3x3
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 5, 5, 1, 2, 1, 256, 320, 256, 320, AUTO) == 0       # reflect 5x5: general kernel
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 0       # 32-wide co tile
@@ -222,7 +224,10 @@ def test_which_shapes_take_the_bf16_split_kernels():
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 256, 320, AUTO) == 3
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 2, 0, 0, 256, 320, AUTO) == 3            # stride-1 data gradient
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 256, 320, IM2COL) == 2          # ... unless the caller asks for the gather kernel
-    assert lib.pd_conv2d_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 0, 0, 64, 80, AUTO) == 2   # Wo = 80: no whole 32-column tiles
+    assert lib.pd_conv2d_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 0, 0, 64, 80, AUTO) == 3   # Wo = 80: 16 x 16 tiles
+    assert lib.pd_conv2d_uses_x3(16 * 32 * 40, 512, 256, 5, 5, 1, 2, 0, 0, 0, 32, 40, AUTO) == 3   # 32 x 40: 32 x 8 tiles, 640 workgroups
+    assert lib.pd_conv2d_uses_x3(16 * 32 * 40, 256, 256, 3, 3, 1, 1, 0, 0, 0, 32, 40, AUTO) == 3   # ... 80 x 4 = 320 workgroups: the lower bound
+    assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 0, 0, 16, 20, AUTO) == 1   # 16 x 20: no tile shape divides it
     assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 256, 320, AUTO) == 2            # 4x4 stem / partly empty channel group
     assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 2, 0, 256, 320, AUTO) == 2           # reflection padding
     # the caller's flags decide the arithmetic -- no environment variable is read by the library

@@ -82,7 +82,8 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
         want = 0
         if x3 == "1" and Cox % 64 == 0 and Cx % 4 == 0 and -(-Cx // 16) * 16 <= 2 * Cx:
             want = 2 if (Mx % 256 == 0 and (Mx // 256) * (Cox // 64) >= 512) else 1 if (Mx % 128 == 0 and (Mx // 128) * (Cox // 64) >= 320) else 0
-            if want and k in (3, 5) and sx == 1 and Cx % 16 == 0 and ho % 8 == 0 and wo % 32 == 0 and Mx >= 65536:
+            tiles = (wo % 32 == 0 and ho % 8 == 0) or (wo % 16 == 0 and ho % 16 == 0) or (wo % 8 == 0 and ho % 32 == 0)
+            if want and k in (3, 5) and sx == 1 and Cx % 16 == 0 and tiles and Mx >= 65536 and (Mx // 256) * (Cox // 64) >= 320:
                 want = 3                               # the halo-tile kernel
         assert rb == want, (rb, want)
         return ["conv_halo_x3_kernel<8x32,64>" if rb == 3 else f"conv_igemm_x3_kernel<{128 * rb},64>" if rb else "conv_igemm_uni_kernel<128,64>"]
@@ -113,7 +114,9 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
     # (the bf16-split kernel plans for its 512 resident workgroups: one round when that leaves >= 4 slices per tile)
     assert S >= (4 if x3 == "1" else 15), f"weight gradient not in the many-slice regime (S = {S})"
     dw, lab = _labels(lambda: ops.conv2d_wgrad(xd, dyd, w.shape, stride=s, pad=p))
-    halo_w = x3 == "1" and k in (3, 5) and s == 1 and C % 64 == 0 and Co % 64 == 0 and ref.shape[2] % 2 == 0 and ref.shape[3] % 32 == 0
+    ho_, wo_ = ref.shape[2], ref.shape[3]
+    halo_w = (x3 == "1" and k in (3, 5) and s == 1 and C % 64 == 0 and Co % 64 == 0 and
+              ((wo_ % 32 == 0 and ho_ % 2 == 0) or (wo_ % 16 == 0 and ho_ % 4 == 0) or (wo_ % 8 == 0 and ho_ % 8 == 0)))
     assert lab == (["conv_wgrad_halo_x3_kernel"] if halo_w else ["conv_wgrad_x3c_kernel"] if x3 == "1" else ["conv_wgrad_kernel"]), lab
     _close(dw.cpu(), wr.grad, what="wgrad")
 
