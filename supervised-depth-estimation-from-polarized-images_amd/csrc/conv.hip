@@ -870,6 +870,9 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hw = a.Ho * a.Wo;
 
+    // every other tile computes the negated convolution and negates back in the epilogue: the bf16 MFMA's truncation bias
+    // (toward -infinity, whatever the signs) then cancels in sums over outputs -- see conv_halo_x3_kernel
+    const unsigned wsign = (mt & 1) ? 0x80008000u : 0u;
     const int img0 = (int)(m0 / hw);
     // MODE_REFLECT (the decoder's ReflectionPad2d(1) + Conv3x3, same-size output): offsets as with zero padding; a tap that
     // leaves the image is moved two rows / columns inwards -- a per-row correction (hcor, wcor: +2 rows at the top row, -2
@@ -1006,9 +1009,9 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         uint2 h, m, l;
         split2(w4.x, w4.y, h.x, m.x, l.x);
         split2(w4.z, w4.w, h.y, m.y, l.y);
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 0) * BP_BYTES) = h;
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 1) * BP_BYTES) = m;
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 2) * BP_BYTES) = l;
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 0) * BP_BYTES) = uint2{h.x ^ wsign, h.y ^ wsign};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 1) * BP_BYTES) = uint2{m.x ^ wsign, m.y ^ wsign};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (SRC * 3 + 2) * BP_BYTES) = uint2{l.x ^ wsign, l.y ^ wsign};
     };
     auto bf = [](u32x4 v) { return __builtin_bit_cast(bf16x8, v); };
 
@@ -1068,9 +1071,9 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
             mm(t0, PD_I(0), PD_I(7)); x3::sp_l<1>(t0); x3::sp_m<1, true>(ws, tw); PD_SB
             mm(t0, PD_I(0), PD_I(8)); x3::sp_l<2>(t0); x3::sp_l<1, true>(tw); PD_SB
             mm(t0, PD_I(0), PD_I(9)); x3::sp_l<3>(t0); PD_SB
-            *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
-            *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
-            *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
+            *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0] ^ wsign, tw.h[1] ^ wsign};
+            *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0] ^ wsign, tw.m[1] ^ wsign};
+            *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0] ^ wsign, tw.l[1] ^ wsign};
             mm(t0, PD_I(0), PD_I(10)); mm(t0, PD_I(0), PD_I(11));
         } else {
         // row block 0: its mid terms behind MFMAs 0..3, the weights' first pair behind 4..5, its lo terms (and block 1's hi)
@@ -1094,9 +1097,9 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         mm(t1, PD_I(RB - 1), PD_I(3)); x3::sp_m<3>(x1, t1); PD_SB
         mm(t1, PD_I(RB - 1), PD_I(4)); x3::sp_l<1, true>(tw); PD_SB
         mm(t1, PD_I(RB - 1), PD_I(5));
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0] ^ wsign, tw.h[1] ^ wsign};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0] ^ wsign, tw.m[1] ^ wsign};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0] ^ wsign, tw.l[1] ^ wsign};
         PD_SB
         mm(t1, PD_I(RB - 1), PD_I(6)); x3::sp_l<0>(t1); PD_SB
         mm(t1, PD_I(RB - 1), PD_I(7)); x3::sp_l<1>(t1); PD_SB
@@ -1153,7 +1156,7 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = acc[i][j][r] + bv;
+                    const float v = (wsign ? -acc[i][j][r] : acc[i][j][r]) + bv;
                     // (ELU as torch evaluates it, exp(x) - 1, on the hardware exp2: see conv_epilogue)
                     T[(32 * i + (r & 3) + 8 * (r >> 2) + rbase) * 32 + col_l] =
                         elu ? (v > 0.f ? v : __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f) : v;

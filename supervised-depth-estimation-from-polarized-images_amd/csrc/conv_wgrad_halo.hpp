@@ -115,23 +115,27 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
             xv[i] = buf_ld4(rx, ok ? (unsigned)(iy * (int)a.sH + ix * (int)a.sW) * 4u + x_cq : OOB);
         }
     };
-    auto put3 = [&](const float4 v, unsigned off, unsigned plane_stride) {
+    // Odd slices accumulate the NEGATED gradient (dY planes with flipped sign bits) and negate their partial tile at the end:
+    // the bf16 MFMA's truncation bias (toward -infinity whatever the signs, ~2^-32 of the accumulator per instruction, thousands
+    // of instructions per slice) then points the other way in half of the slices and cancels in their sum.
+    const unsigned dsign = (s & 1) ? 0x80008000u : 0u;
+    auto put3 = [&](const float4 v, unsigned off, unsigned plane_stride, unsigned sg) {
         uint2 h, m, l;
         x3::split2(v.x, v.y, h.x, m.x, l.x);
         x3::split2(v.z, v.w, h.y, m.y, l.y);
-        *reinterpret_cast<uint2*>(lds_c + off) = h;
-        *reinterpret_cast<uint2*>(lds_c + off + plane_stride) = m;
-        *reinterpret_cast<uint2*>(lds_c + off + 2 * plane_stride) = l;
+        *reinterpret_cast<uint2*>(lds_c + off) = uint2{h.x ^ sg, h.y ^ sg};
+        *reinterpret_cast<uint2*>(lds_c + off + plane_stride) = uint2{m.x ^ sg, m.y ^ sg};
+        *reinterpret_cast<uint2*>(lds_c + off + 2 * plane_stride) = uint2{l.x ^ sg, l.y ^ sg};
     };
     auto tile_split = [&]() {                                          // registers -> bf16 planes
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            put3(dv[i], d_dst + 1024u * i, 2 * NPX * 64);
+            put3(dv[i], d_dst + 1024u * i, 2 * NPX * 64, dsign);
             if (do_bias) { bs4.x += dv[i].x; bs4.y += dv[i].y; bs4.z += dv[i].z; bs4.w += dv[i].w; }
         }
 #pragma unroll
         for (int i = 0; i < NIX; ++i)
-            if (i < NIX - 1 || x_last_ok) put3(xv[i], x_dst + 1024u * i, 2 * XPX * 64);
+            if (i < NIX - 1 || x_last_ok) put3(xv[i], x_dst + 1024u * i, 2 * XPX * 64, 0u);
     };
 
     // ---- fragment addresses: lane -> (half h: pixels 8h..8h+7 of the step; group gq: channels 16 gq..; row q, unit p of the block)
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                a.part[((long)s * a.Co + co) * a.K + k] = acc[kw][r];
+                a.part[((long)s * a.Co + co) * a.K + k] = dsign ? -acc[kw][r] : acc[kw][r];
             }
         }
     }

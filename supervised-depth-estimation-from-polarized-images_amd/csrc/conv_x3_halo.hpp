@@ -58,6 +58,11 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
     const int trem = mt - img * (tiles_h * tiles_w);
     const int ty = trem / tiles_w, tx = trem - ty * tiles_w;
     const int oy0 = ty * TR, ox0 = tx * TW;
+    // The bf16 MFMA truncates where it aligns its addends (about -2^-32 of the largest per instruction, toward -infinity whatever
+    // the signs): per output that is below one fp32 rounding, but it has ONE sign, and sums over many outputs -- BatchNorm
+    // statistics, weight gradients -- collect it.  Every other tile therefore computes the NEGATED convolution (weight planes with
+    // flipped sign bits, 6 v_xor per chunk) and negates back in the epilogue: its bias points the other way and the sums cancel.
+    const unsigned wsign = (mt & 1) ? 0x80008000u : 0u;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -140,9 +145,9 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
         uint2 h, m, l;
         x3::split2(w4.x, w4.y, h.x, m.x, l.x);
         x3::split2(w4.z, w4.w, h.y, m.y, l.y);
-        *reinterpret_cast<uint2*>(lds_c + sp_off + 0 * BP_BYTES) = h;
-        *reinterpret_cast<uint2*>(lds_c + sp_off + 1 * BP_BYTES) = m;
-        *reinterpret_cast<uint2*>(lds_c + sp_off + 2 * BP_BYTES) = l;
+        *reinterpret_cast<uint2*>(lds_c + sp_off + 0 * BP_BYTES) = uint2{h.x ^ wsign, h.y ^ wsign};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + 1 * BP_BYTES) = uint2{m.x ^ wsign, m.y ^ wsign};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + 2 * BP_BYTES) = uint2{l.x ^ wsign, l.y ^ wsign};
     };
     // one halo item: registers -> three plane slots (every element split once per tile)
     auto halo_item = [&](auto i_tag) {
@@ -215,9 +220,9 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
         mm(PD_I(1), PD_I(3)); x3::sp_l<1, true>(tw); PD_SB
         mm(PD_I(0), PD_I(4)); PD_SB
         mm(PD_I(0), PD_I(5));
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0], tw.h[1]};
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0], tw.m[1]};
-        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0], tw.l[1]};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0] ^ wsign, tw.h[1] ^ wsign};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = uint2{tw.m[0] ^ wsign, tw.m[1] ^ wsign};
+        *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0] ^ wsign, tw.l[1] ^ wsign};
         PD_SB
         // LAST: one halo item (18 vector instructions, 3 ds_write_b64) per two MFMAs
         mm(PD_I(1), PD_I(4)); mm(PD_I(1), PD_I(5)); if (LAST) halo_item(PD_I(0)); PD_SB
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = acc[i][j][r] + bv;
+                    const float v = (wsign ? -acc[i][j][r] : acc[i][j][r]) + bv;
                     Tt[(32 * i + (r & 3) + 8 * (r >> 2) + rbase) * 32 + col_l] =
                         elu ? (v > 0.f ? v : __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f) : v;
                     s1 += v;
@@ -348,9 +353,10 @@ static int x3_halo_tw(int Ho, int Wo) {
     return (Wo % 32 == 0 && Ho % 8 == 0) ? 32 : (Wo % 16 == 0 && Ho % 16 == 0) ? 16 : (Wo % 8 == 0 && Ho % 32 == 0) ? 8 : 0;
 }
 static bool x3_halo_eligible(const ConvArgs& a) {
-    // (at least 320 workgroups: below that the gather kernel's 128-row tiles fill the chip better)
+    // (at least 512 workgroups, two per CU: with 320 the gather kernel's 128-row tiles fill the chip better -- 3x3x256 @32x40
+    //  151 vs 132 TF, the data gradient of 5x5 256 -> 512 @32x40 165 vs 151)
     return (a.KH == 3 || a.KH == 5) && a.KW == a.KH && a.stride == 1 && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) &&
-           a.C % x3h::CK == 0 && x3_halo_tw(a.Ho, a.Wo) != 0 && (a.M / 256) * (a.Co / 64) >= 320 && (a.stats_rows == 128 || a.stats_rows == 64) && a.sC == 1 &&
+           a.C % x3h::CK == 0 && x3_halo_tw(a.Ho, a.Wo) != 0 && (a.M / 256) * (a.Co / 64) >= 512 && (a.stats_rows == 128 || a.stats_rows == 64) && a.sC == 1 &&
            (long)a.sN * 4 < 0x7fffffffL && (long)a.Ho * a.Wo * a.ldy * 4 < 0x7fffffffL &&
            (!a.add || (long)a.Ho * a.Wo * a.ld_add * 4 < 0x7fffffffL);
 }

@@ -83,7 +83,7 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
         if x3 == "1" and Cox % 64 == 0 and Cx % 4 == 0 and -(-Cx // 16) * 16 <= 2 * Cx:
             want = 2 if (Mx % 256 == 0 and (Mx // 256) * (Cox // 64) >= 512) else 1 if (Mx % 128 == 0 and (Mx // 128) * (Cox // 64) >= 320) else 0
             tiles = (wo % 32 == 0 and ho % 8 == 0) or (wo % 16 == 0 and ho % 16 == 0) or (wo % 8 == 0 and ho % 32 == 0)
-            if want and k in (3, 5) and sx == 1 and Cx % 16 == 0 and tiles and Mx >= 65536 and (Mx // 256) * (Cox // 64) >= 320:
+            if want and k in (3, 5) and sx == 1 and Cx % 16 == 0 and tiles and Mx >= 65536 and (Mx // 256) * (Cox // 64) >= 512:
                 want = 3                               # the halo-tile kernel
         assert rb == want, (rb, want)
         return ["conv_halo_x3_kernel<8x32,64>" if rb == 3 else f"conv_igemm_x3_kernel<{128 * rb},64>" if rb else "conv_igemm_uni_kernel<128,64>"]
