@@ -16,11 +16,11 @@
 //     offset kw -- two ds_read_b64_tr_b16 per term -- and issues 6 MFMAs per (step, kw) into the accumulator tile of kw;
 //   * nothing is gathered per tap, no pixel walker, no masks in the loop: ~2 vector instructions per MFMA (3x3), 1.3 (5x5);
 //     52 KB of LDS, three (3x3) or two (5x5: registers) workgroups per CU.
-// Partial tiles [slice][co][K] and the ordered reduction are those of the other weight-gradient kernels.  Zero padding,
+// Partial tiles [slice][co][K] and the ordered reduction are those of the other weight-gradient kernels.  Zero or reflection padding,
 // stride 1, K = 3 | 5, C % 64 == 0, Cout % 64 == 0, the output grid a whole number of 2 x 32, 4 x 16 or 8 x 8 tiles.
 namespace wgh {
-constexpr int NPX = 64;                                                  // pixels per tile: TR rows x TW columns, 4 MFMA k-steps
-// TW = 32 | 16 | 8 (the widest that divides Wo): 2 x 32, 4 x 16 or 8 x 8 pixel tiles -- a 16-pixel step is then half a row,
+constexpr int NPX = 32;                                                  // pixels per tile: TR rows x TW columns, 2 MFMA k-steps
+// TW = 32 | 16 | 8 (the widest that divides Wo): 1 x 32, 2 x 16 or 4 x 8 pixel tiles -- a 16-pixel step is then half a row,
 // a row or two rows; either way the step's pixels are the tile's row-major pixels 16 ks .. 16 ks + 15, in runs of four
 // consecutive columns (what one transposed read takes).
 template <int KS, int TW> struct Geo {
@@ -28,10 +28,10 @@ template <int KS, int TW> struct Geo {
     static constexpr int HW = TW + KS - 1;                               // X columns per tile row
     static constexpr int XPX = TR * HW;                                  // X pixels per tile (one filter row: no vertical halo)
     static constexpr int NIX = (XPX * 16 + NT - 1) / NT;                 // 16-byte X items per thread (64 channels = 16 quads per pixel)
-    static constexpr unsigned DP_BYTES = 3 * 2 * NPX * 64;               // dY planes: [term][co block][pixel][32 ch x 2 B]
-    static constexpr unsigned XP_BASE = DP_BYTES;
-    static constexpr unsigned XP_BYTES = 3 * 2 * XPX * 64;               // X planes: [term][ci block][pixel][32 ch x 2 B]
-    static constexpr unsigned LDS_BYTES = XP_BASE + XP_BYTES;
+    static constexpr unsigned DP_BYTES = 3 * 2 * NPX * 64;               // dY planes of one tile: [term][co block][pixel][32 ch x 2 B]
+    static constexpr unsigned XP_BYTES = 3 * 2 * XPX * 64;               // X planes of one tile: [term][ci block][pixel][32 ch x 2 B]
+    static constexpr unsigned BUF_BYTES = DP_BYTES + XP_BYTES;           // two tiles live in LDS: the one multiplied, the one being written
+    static constexpr unsigned LDS_BYTES = 2 * BUF_BYTES;
 };
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -47,7 +47,7 @@ __device__ __forceinline__ uint2 tr_read(lds_char* base, unsigned imm) {
 struct WgradHaloArgs {
     WgradArgs g;
     int ncb;              // 64-channel input blocks
-    int tiles_w, tiles_img, ntiles_total, tiles_per_slice;
+    int tiles_w, tiles_h, ntiles_total, tiles_per_slice;
 };
 
 template <int KS, int TW, bool BIAS>
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
     using namespace wgh;
     using G = Geo<KS, TW>;
     constexpr int HW = G::HW, XPX = G::XPX, NIX = G::NIX, TR = G::TR;
-    constexpr unsigned XP_BASE = G::XP_BASE;
+    constexpr unsigned DP_BYTES = G::DP_BYTES, BUF_BYTES = G::BUF_BYTES;
+    static_assert(NIX <= 3 && 16 * (NIX - 1) < XPX, "X items per thread");
     const WgradArgs& a = ha.g;
     __shared__ __attribute__((aligned(16))) float smem_all[G::LDS_BYTES / 4];
     char* lds_c = reinterpret_cast<char*>(smem_all);
@@ -73,52 +74,66 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
     const int t_beg = s * ha.tiles_per_slice;
     const int t_end = min(t_beg + ha.tiles_per_slice, ha.ntiles_total);
 
-    // ---- items of this thread (tile-invariant part)
+    // ---- items of this thread (tile-invariant part): a tile is 2 dY items and NIX (<= 3) X items of 16 bytes per thread
     const int quad = tid & 15;                                          // 4 channels: block quad >> 3, unit quad & 7
-    // dY: item i = pixel (tid >> 4) + 16 i of the 2 x 32 tile
-    unsigned d_voff[4];
+    unsigned d_voff[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = (tid >> 4) + 16 * i, r = p / TW, c = p % TW;
+    for (int i = 0; i < 2; ++i) {
+        const int p = (tid >> 4) + 16 * i, r = p / TW, c = p % TW;      // pixel p of the TR x TW tile
         d_voff[i] = (unsigned)((r * a.Wo + c) * (int)a.ldd + co0 + 4 * quad) * 4u;
     }
-    const unsigned d_dst = (unsigned)((((quad >> 3) * NPX + (tid >> 4)) * 64) + (quad & 7) * 8);            // + term * 2 * NPX * 64 + 1024 i
-    // X: item i = pixel (tid >> 4) + 16 i of the 2 x HW strip: row hr, column hx
+    const unsigned d_dst = (unsigned)((((quad >> 3) * NPX + (tid >> 4)) * 64) + (quad & 7) * 8);                       // + buf, term, 1024 i
     int x_hr[NIX], x_hx[NIX];
 #pragma unroll
     for (int i = 0; i < NIX; ++i) {
-        const int p = (tid >> 4) + 16 * i;
+        const int p = (tid >> 4) + 16 * i;                              // pixel p of the TR x HW strip
         x_hr[i] = p / HW; x_hx[i] = p - x_hr[i] * HW;
     }
     const bool x_last_ok = (tid >> 4) + 16 * (NIX - 1) < XPX;
-    static_assert(16 * (NIX - 1) < XPX, "only the last X item of a thread may be empty");
-    const unsigned x_dst = XP_BASE + (unsigned)((((quad >> 3) * XPX + (tid >> 4)) * 64) + (quad & 7) * 8);   // + term * 2 * XPX * 64 + 1024 i
+    const unsigned x_dst = DP_BYTES + (unsigned)((((quad >> 3) * XPX + (tid >> 4)) * 64) + (quad & 7) * 8);          // + buf, term, 1024 i
     const unsigned x_cq = (unsigned)(ci0 + 4 * quad) * 4u;
 
-    float4 dv[4], xv[NIX];
-    float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool do_bias = BIAS && a.bpart != nullptr && kh == 0 && cb == 0;
-    auto tile_load = [&](int t) {                                      // global -> registers (t < t_end: uniform)
-        const int n = t / ha.tiles_img, rem = t - n * ha.tiles_img;
-        const int ty = rem / ha.tiles_w, tx = rem - ty * ha.tiles_w;
-        const int oy0 = ty * TR, ox0 = tx * TW;
-        const long pix0 = ((long)n * a.Ho + oy0) * a.Wo + ox0;
-        const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dy + pix0 * a.ldd, (unsigned)(((long)(TR - 1) * a.Wo + TW) * a.ldd * 4));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dv[i] = buf_ld4(rd, d_voff[i]);
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)n * a.sN, (unsigned)((long)a.sN * 4));
-        const int iy0 = oy0 - a.pad + kh, ix0 = ox0 - a.pad;
-#pragma unroll
-        for (int i = 0; i < NIX; ++i) {
-            const int iy = iy0 + x_hr[i], ix = ix0 + x_hx[i];
-            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && (i < NIX - 1 || x_last_ok);
-            xv[i] = buf_ld4(rx, ok ? (unsigned)(iy * (int)a.sH + ix * (int)a.sW) * 4u + x_cq : OOB);
+    // ---- the tile being loaded (two ahead of the one multiplied): walked incrementally, no divisions in the loop
+    int l_t = t_beg, l_n, l_ty, l_tx;
+    {
+        const int per_img = ha.tiles_h * ha.tiles_w;
+        l_n = t_beg / per_img;
+        const int rem = t_beg - l_n * per_img;
+        l_ty = rem / ha.tiles_w; l_tx = rem - l_ty * ha.tiles_w;
+        l_n = __builtin_amdgcn_readfirstlane(l_n); l_ty = __builtin_amdgcn_readfirstlane(l_ty); l_tx = __builtin_amdgcn_readfirstlane(l_tx);
+    }
+    __amdgpu_buffer_rsrc_t rd, rx;
+    int l_iy0 = 0, l_ix0 = 0;
+    auto tile_begin = [&]() {                                          // descriptors / origin of tile l_t (scalar)
+        const int oy0 = l_ty * TR, ox0 = l_tx * TW;
+        const long pix0 = ((long)l_n * a.Ho + oy0) * a.Wo + ox0;
+        const bool live = l_t < t_end;                                   // past the slice: empty descriptors, every load returns zero
+        rd = make_rsrc(a.dy + pix0 * a.ldd, live ? (unsigned)(((long)(TR - 1) * a.Wo + TW) * a.ldd * 4) : 0u);
+        rx = make_rsrc(a.x + (long)l_n * a.sN, live ? (unsigned)((long)a.sN * 4) : 0u);
+        l_iy0 = oy0 - a.pad + kh; l_ix0 = ox0 - a.pad;
+    };
+    auto tile_next = [&]() {
+        ++l_t;
+        if (++l_tx == ha.tiles_w) { l_tx = 0; if (++l_ty == ha.tiles_h) { l_ty = 0; ++l_n; } }
+    };
+    float4 dv[2], xv[NIX];
+    auto load_d = [&](auto i_tag) { constexpr int I = decltype(i_tag)::value; dv[I] = buf_ld4(rd, d_voff[I]); };
+    auto load_x = [&](auto i_tag) {
+        constexpr int I = decltype(i_tag)::value;
+        int iy = l_iy0 + x_hr[I], ix = l_ix0 + x_hx[I];
+        if (a.mode == MODE_REFLECT) {                   // (uniform) ReflectionPad2d: the strip holds the mirrored pixels
+            iy = iy < 0 ? -iy : iy; iy = iy >= a.H ? 2 * a.H - 2 - iy : iy;
+            ix = ix < 0 ? -ix : ix; ix = ix >= a.W ? 2 * a.W - 2 - ix : ix;
         }
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && (I < NIX - 1 || x_last_ok);
+        xv[I] = buf_ld4(rx, ok ? (unsigned)(iy * (int)a.sH + ix * (int)a.sW) * 4u + x_cq : OOB);
     };
     // Odd slices accumulate the NEGATED gradient (dY planes with flipped sign bits) and negate their partial tile at the end:
     // the bf16 MFMA's truncation bias (toward -infinity whatever the signs, ~2^-32 of the accumulator per instruction, thousands
     // of instructions per slice) then points the other way in half of the slices and cancels in their sum.
     const unsigned dsign = (s & 1) ? 0x80008000u : 0u;
+    float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_bias = BIAS && a.bpart != nullptr && kh == 0 && cb == 0;
     auto put3 = [&](const float4 v, unsigned off, unsigned plane_stride, unsigned sg) {
         uint2 h, m, l;
         x3::split2(v.x, v.y, h.x, m.x, l.x);
@@ -127,15 +142,20 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
         *reinterpret_cast<uint2*>(lds_c + off + plane_stride) = uint2{m.x ^ sg, m.y ^ sg};
         *reinterpret_cast<uint2*>(lds_c + off + 2 * plane_stride) = uint2{l.x ^ sg, l.y ^ sg};
     };
-    auto tile_split = [&]() {                                          // registers -> bf16 planes
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            put3(dv[i], d_dst + 1024u * i, 2 * NPX * 64, dsign);
-            if (do_bias) { bs4.x += dv[i].x; bs4.y += dv[i].y; bs4.z += dv[i].z; bs4.w += dv[i].w; }
+    // item K (0, 1: dY; 2 .. 2 + NIX - 1: X) of the tile in the registers -> planes of buffer DST; its registers then take the
+    // same item of the tile two ahead
+    auto item = [&](auto dst_tag, auto k_tag) {
+        constexpr unsigned DST = decltype(dst_tag)::value;
+        constexpr int K = decltype(k_tag)::value;
+        if constexpr (K < 2) {
+            put3(dv[K], DST * BUF_BYTES + d_dst + 1024u * K, 2 * NPX * 64, dsign);
+            if constexpr (BIAS) { if (do_bias) { bs4.x += dv[K].x; bs4.y += dv[K].y; bs4.z += dv[K].z; bs4.w += dv[K].w; } }
+            load_d(k_tag);
+        } else if constexpr (K - 2 < NIX) {
+            constexpr int I = K - 2;
+            if (I < NIX - 1 || x_last_ok) put3(xv[I], DST * BUF_BYTES + x_dst + 1024u * I, 2 * XPX * 64, 0u);
+            load_x(std::integral_constant<int, I>{});
         }
-#pragma unroll
-        for (int i = 0; i < NIX; ++i)
-            if (i < NIX - 1 || x_last_ok) put3(xv[i], x_dst + 1024u * i, 2 * XPX * 64, 0u);
     };
 
     // ---- fragment addresses: lane -> (half h: pixels 8h..8h+7 of the step; group gq: channels 16 gq..; row q, unit p of the block)
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
     lds_char* const lds_a = (lds_char*)lds_c + (unsigned)((((wave & 1) * NPX + 8 * fh + fq) * 64) + 32 * gq + 8 * fp);
     // X strip (row-major, HW columns): pixel 8 fh + 4 e + q of step ks sits at (row0(ks) + hrow, col0(ks) + hcol + 4 e + q + kw)
     constexpr int HROW = TW >= 16 ? 0 : 1, HCOL = TW >= 16 ? 8 : 0;        // the upper half-wave: 8 columns on (TW >= 16) or the next row (TW = 8)
-    lds_char* const lds_b = (lds_char*)lds_c + (XP_BASE + (unsigned)((((wave >> 1) * XPX + fh * (HROW * HW + HCOL) + fq) * 64) + 32 * gq + 8 * fp));
+    lds_char* const lds_b = (lds_char*)lds_c + (DP_BYTES + (unsigned)((((wave >> 1) * XPX + fh * (HROW * HW + HCOL) + fq) * 64) + 32 * gq + 8 * fp));
 
     typedef float accv_t __attribute__((ext_vector_type(16)));
     accv_t acc[KS];
@@ -153,30 +173,39 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     auto bf = [](uint2 lo, uint2 hi) { return __builtin_bit_cast(x3::bf16x8, u32x4{lo.x, lo.y, hi.x, hi.y}); };
 
-    if (t_beg < t_end) {
-        tile_load(t_beg);
-        tile_split();
-    }
+#define PD_I(n) std::integral_constant<int, n>{}
+#define PD_U(n) std::integral_constant<unsigned, n>{}
+    // ---- prologue: tile t_beg -> planes 0, tile t_beg + 1 -> registers
+    tile_begin();
+    load_d(PD_I(0)); load_d(PD_I(1)); load_x(PD_I(0)); load_x(PD_I(1)); load_x(PD_I(2));
+    tile_next(); tile_begin();
+    item(PD_U(0), PD_I(0)); item(PD_U(0), PD_I(1)); item(PD_U(0), PD_I(2)); item(PD_U(0), PD_I(3)); item(PD_U(0), PD_I(4));
+    tile_next(); tile_begin();
     __syncthreads();
-    for (int t = t_beg; t < t_end; ++t) {
-        if (t + 1 < t_end) tile_load(t + 1);                            // (uniform) flies under this tile's MFMAs
+
+    // One tile: 2 steps x KS taps x 6 MFMAs on buffer BUF; between them the tile in the registers (t + 1) is split into buffer
+    // BUF ^ 1 item by item, and each item's registers are refilled from tile t + 2 (l_*: its descriptors).
+    auto tile = [&](auto buf_tag) {
+        constexpr unsigned BUF = decltype(buf_tag)::value;
+        const std::integral_constant<unsigned, BUF ^ 1> nxt{};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
             x3::bf16x8 fa[3];
 #pragma unroll
             for (int tm = 0; tm < 3; ++tm)
-                fa[tm] = bf(tr_read(lds_a, (unsigned)(tm * 2 * NPX * 64 + ks * 16 * 64)),
-                            tr_read(lds_a, (unsigned)(tm * 2 * NPX * 64 + ks * 16 * 64 + 4 * 64)));
+                fa[tm] = bf(tr_read(lds_a, BUF * BUF_BYTES + (unsigned)(tm * 2 * NPX * 64 + ks * 16 * 64)),
+                            tr_read(lds_a, BUF * BUF_BYTES + (unsigned)(tm * 2 * NPX * 64 + ks * 16 * 64 + 4 * 64)));
             x3::bf16x8 fb[KS][3];
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
                 for (int tm = 0; tm < 3; ++tm) {
-                    const int row0 = TW == 32 ? (ks >> 1) : TW == 16 ? ks : 2 * ks, col0 = TW == 32 ? 16 * (ks & 1) : 0;
-                    const unsigned o = (unsigned)(tm * 2 * XPX * 64 + (row0 * HW + col0 + kw) * 64);
+                    const int row0 = TW == 32 ? 0 : TW == 16 ? ks : 2 * ks, col0 = TW == 32 ? 16 * ks : 0;
+                    const unsigned o = BUF * BUF_BYTES + (unsigned)(tm * 2 * XPX * 64 + (row0 * HW + col0 + kw) * 64);
                     fb[kw][tm] = bf(tr_read(lds_b, o), tr_read(lds_b, o + 4 * 64));
                 }
-            // products largest first, the taps interleaved so that consecutive MFMAs never share an accumulator
+            // products largest first, the taps interleaved so that consecutive MFMAs never share an accumulator; one item of
+            // the next tile behind every second group of KS MFMAs
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr) {
                 const int ta = pr == 0 ? 0 : pr == 1 ? 0 : pr == 2 ? 1 : pr == 3 ? 0 : pr == 4 ? 1 : 2;
@@ -184,12 +213,23 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
 #pragma unroll
                 for (int kw = 0; kw < KS; ++kw)
                     acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ta], fb[kw][tb], acc[kw], 0, 0, 0);
+                const int g = 6 * ks + pr;                                  // MFMA group 0 .. 11 of the tile
+                if (g == 1) item(nxt, PD_I(0));
+                else if (g == 3) item(nxt, PD_I(1));
+                else if (g == 5) item(nxt, PD_I(2));
+                else if (g == 7) item(nxt, PD_I(3));
+                else if (g == 9) item(nxt, PD_I(4));
             }
         }
-        __syncthreads();                                                // every wave is done with the planes of tile t
-        if (t + 1 < t_end) tile_split();
-        __syncthreads();
+        tile_next(); tile_begin();
+        __syncthreads();                        // buffer BUF ^ 1 is complete, buffer BUF is free
+    };
+    for (int t = t_beg; t < t_end; t += 2) {
+        tile(PD_U(0));
+        if (t + 1 < t_end) tile(PD_U(1));
     }
+#undef PD_I
+#undef PD_U
 
     // ---- partial tile of this slice: C/D layout col = lane % 32 -> ci, row -> co: (r&3) + 8*(r>>2) + 4*(lane>>5)
     {
@@ -219,13 +259,13 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
     }
 }
 
-// Shapes the halo weight-gradient kernel takes (the caller has established the 16-byte path: NHWC, aligned, no affine).
-// tile width: the widest of 32 | 16 | 8 whose 64-pixel tile (2 | 4 | 8 rows) divides the output grid; 0: none
+// tile width: the widest of 32 | 16 | 8 whose 32-pixel tile (1 | 2 | 4 rows) divides the output grid; 0: none
 static int wgrad_halo_tw(int Ho, int Wo) {
-    return (Wo % 32 == 0 && Ho % 2 == 0) ? 32 : (Wo % 16 == 0 && Ho % 4 == 0) ? 16 : (Wo % 8 == 0 && Ho % 8 == 0) ? 8 : 0;
+    return Wo % 32 == 0 ? 32 : (Wo % 16 == 0 && Ho % 2 == 0) ? 16 : (Wo % 8 == 0 && Ho % 4 == 0) ? 8 : 0;
 }
 static bool wgrad_halo_eligible(const WgradArgs& a, bool vec) {
-    return vec && a.mode == MODE_ZERO && a.stride == 1 && a.KH == a.KW && (a.KH == 3 || a.KH == 5) && a.pad < a.KH &&
+    return vec && (a.mode == MODE_ZERO || (a.mode == MODE_REFLECT && a.pad < a.H && a.pad < a.W)) && a.stride == 1 && a.KH == a.KW &&
+           (a.KH == 3 || a.KH == 5) && a.pad < a.KH &&
            a.C % 64 == 0 && a.Co % 64 == 0 && wgrad_halo_tw(a.Ho, a.Wo) != 0 && a.ldd % 4 == 0 &&
            (long)a.sN * 4 < 0x7fffffffL && (8L * a.Wo + 32) * a.ldd * 4 < 0x7fffffffL && a.Ho <= a.H + 2 * a.pad - a.KH + 1;
 }
@@ -252,8 +292,8 @@ static int launch_wgrad_halo(WgradArgs a, int s_cap, hipStream_t st, bool bias) 
     a.ctiles = a.Co / 64;
     const int tw = wgrad_halo_tw(a.Ho, a.Wo);
     ha.tiles_w = a.Wo / tw;
-    ha.tiles_img = (a.Ho / (wgh::NPX / tw)) * ha.tiles_w;
-    ha.ntiles_total = a.N * ha.tiles_img;
+    ha.tiles_h = a.Ho / (wgh::NPX / tw);
+    ha.ntiles_total = a.N * ha.tiles_h * ha.tiles_w;
     const int per_slice_wgs = a.KH * ha.ncb * a.ctiles;
     int S = wgrad_halo_slices(a.KH, a.C, a.Co);
     if (S > s_cap) S = s_cap;

@@ -86,7 +86,11 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
     for (int i = 0; i < NI; ++i) {
         const int p = (tid >> 2) + 64 * i;
         const int hy = p / HW, hx = p - hy * HW;
-        const int iy = oy0 - padh + hy, ix = ox0 - padw + hx;
+        int iy = oy0 - padh + hy, ix = ox0 - padw + hx;
+        if constexpr (MODE == MODE_REFLECT) {        // ReflectionPad2d: the halo holds the mirrored pixels, every tap is in range
+            iy = iy < 0 ? -iy : iy; iy = iy >= a.H ? 2 * a.H - 2 - iy : iy;
+            ix = ix < 0 ? -ix : ix; ix = ix >= a.W ? 2 * a.W - 2 - ix : ix;
+        }
         const bool ok = p < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         hoff[i] = ok ? (unsigned)(iy * (int)a.sH + ix * (int)a.sW + hquad * 4) * 4u : OOB;
     }
@@ -355,7 +359,8 @@ static int x3_halo_tw(int Ho, int Wo) {
 static bool x3_halo_eligible(const ConvArgs& a) {
     // (at least 512 workgroups, two per CU: with 320 the gather kernel's 128-row tiles fill the chip better -- 3x3x256 @32x40
     //  151 vs 132 TF, the data gradient of 5x5 256 -> 512 @32x40 165 vs 151)
-    return (a.KH == 3 || a.KH == 5) && a.KW == a.KH && a.stride == 1 && (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0)) &&
+    return (a.KH == 3 || a.KH == 5) && a.KW == a.KH && a.stride == 1 &&
+           (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0) || (a.mode == MODE_REFLECT && a.pad < a.H && a.pad_w < a.W)) &&
            a.C % x3h::CK == 0 && x3_halo_tw(a.Ho, a.Wo) != 0 && (a.M / 256) * (a.Co / 64) >= 512 && (a.stats_rows == 128 || a.stats_rows == 64) && a.sC == 1 &&
            (long)a.sN * 4 < 0x7fffffffL && (long)a.Ho * a.Wo * a.ldy * 4 < 0x7fffffffL &&
            (!a.add || (long)a.Ho * a.Wo * a.ld_add * 4 < 0x7fffffffL);
@@ -377,6 +382,7 @@ static int launch_conv_x3_halo(ConvArgs& a, hipStream_t st) {
     constexpr int NSB3 = 2, NSB5 = 2;
 #endif
 #define PD_HALO(KSV, NSBV, TWV) do { if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, KSV, NSBV, TWV>), grid, block, 0, st, a); \
+                                     else if (a.mode == MODE_REFLECT) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_REFLECT, KSV, NSBV, TWV>), grid, block, 0, st, a); \
                                      else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, KSV, NSBV, TWV>), grid, block, 0, st, a); } while (0)
     if (a.KH == 3) { if (tw == 32) PD_HALO(3, NSB3, 32); else if (tw == 16) PD_HALO(3, NSB3, 16); else PD_HALO(3, NSB3, 8); }
     else { if (tw == 32) PD_HALO(5, NSB5, 32); else if (tw == 16) PD_HALO(5, NSB5, 16); else PD_HALO(5, NSB5, 8); }

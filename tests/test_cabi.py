@@ -217,7 +217,8 @@ def test_which_shapes_take_the_bf16_split_kernels():
     assert lib.pd_conv2d_wgrad_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 64, 80, 64, 80, AUTO) == 2   # Wo = 80: 4 x 16 tiles
     assert lib.pd_conv2d_wgrad_uses_x3(16 * 32 * 40, 256, 256, 3, 3, 1, 1, 0, 32, 40, 32, 40, AUTO) == 2   # 8 x 8 tiles
     assert lib.pd_conv2d_wgrad_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 16, 20, 16, 20, AUTO) == 1   # Wo = 20: the gather kernel
-    assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 1   # decoder: ReflectionPad2d(1) + Conv3x3
+    assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 2   # decoder: ReflectionPad2d(1) + Conv3x3 (mirrored strip)
+    assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 96, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 1    # ... 96 input channels: the gather kernel
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 5, 5, 1, 2, 1, 256, 320, 256, 320, AUTO) == 0       # reflect 5x5: general kernel
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 0       # 32-wide co tile
     # with the output grid known, the halo-tile kernel takes the 3x3 / 5x5 stride-1 layers with whole 8 x 32 tiles
@@ -229,7 +230,7 @@ def test_which_shapes_take_the_bf16_split_kernels():
     assert lib.pd_conv2d_uses_x3(16 * 32 * 40, 256, 256, 3, 3, 1, 1, 0, 0, 0, 32, 40, AUTO) == 1   # ... 80 x 4 = 320 workgroups: the gather kernel's 128-row tiles
     assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 0, 0, 16, 20, AUTO) == 1   # 16 x 20: no tile shape divides it
     assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 256, 320, AUTO) == 2            # 4x4 stem / partly empty channel group
-    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 2, 0, 256, 320, AUTO) == 2           # reflection padding
+    assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 2, 0, 256, 320, AUTO) == 3           # reflection padding: mirrored halo
     # the caller's flags decide the arithmetic -- no environment variable is read by the library
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 0, 0, FP32) == 0
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, FP32) == 0

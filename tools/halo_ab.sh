@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 OUT=$1; shift
 : > $OUT
 run() {
-  for only in "enc.ResBlock1 3x3" "enc.Conv2 5x5" "ResBlock2 3x3" "enc.Conv3" "rgb.layer2" "joint.ResBlock1" "joint.Conv1" "joint.ResBlock3" "joint.Conv2"; do
+  for only in "enc.ResBlock1 3x3" "enc.Conv2 5x5" "ResBlock2 3x3" "enc.Conv3" "joint.ResBlock1" "joint.Conv1" "joint.ResBlock3" "joint.Conv2" "dec.upconv(2,1)" "dec.upconv(3,1)"; do
     ONLY="$only" timeout -k 10 120 python3 tools/bench_conv.py 2>/dev/null | grep layer | python3 -c '
 import sys, json
 for l in sys.stdin:
