@@ -373,7 +373,7 @@ def main():
     # HBM traffic per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, gfx950
     # FETCH_SIZE x2 correction) cannot run inside this process -- the committed summary of those passes is quoted
     traffic, traffic_src = None, None
-    for pmc_name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for pmc_name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc):
             with open(pmc) as f:

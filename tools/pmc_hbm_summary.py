@@ -26,6 +26,10 @@ def short(name):
     m = re.match(r"conv_igemm_x3_kernel<\d+, (\d+)>", name)
     if m:                      # forward and data gradient of the bf16-split kernel: one label per tile height
         return f"conv_igemm_x3_kernel<{128 * int(m.group(1))},64>"
+    if name.startswith("conv_halo_x3_kernel"):       # halo-tile forward / data gradient: one label (bench.py)
+        return "conv_halo_x3_kernel<8x32,64>"
+    if name.startswith("conv_wgrad_halo_x3"):
+        return "conv_wgrad_halo_x3_kernel"
     if name.startswith("conv_wgrad_x3c"):
         return "conv_wgrad_x3c_kernel"
     if name.startswith("conv_wgrad"):                # bench.py times the other weight-gradient kernels under one label
@@ -55,7 +59,7 @@ if __name__ == "__main__":
                       "hbm_bytes_per_launch": int((2 * f + w) * 1024), "launches": n}
     conv = {k: v for k, v in kernels.items() if k.startswith("conv_")}
     dom = max(conv.items(), key=lambda kv: kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[0] if conv else None
-    for pref in ("conv_igemm_uni_kernel<128,64>", "conv_igemm_kernel<128,64,vec>"):   # bench.py's dominant label
+    for pref in ("conv_halo_x3_kernel<8x32,64>", "conv_igemm_uni_kernel<128,64>", "conv_igemm_kernel<128,64,vec>"):   # bench.py's dominant label
         if pref in kernels:
             dom = pref
             break
