@@ -12,9 +12,10 @@
 //     tap), no gather, no masks, no per-tap split: the loop is 24 MFMAs, 12 ds_read_b128, the weight chunk's split
 //     (0.75 vector instructions per MFMA instead of 3.75) and one barrier;
 //   * an input element crosses L2 -> CU 1.33x (3x3) / 1.69x (5x5) per tile instead of 9x / 25x.
-// The weight chunk (64 x 16 per tap) keeps the pipeline of conv_igemm_x3_kernel, one chunk deeper: LDS-DMA THREE chunks ahead
-// (a chunk is 24 MFMAs ~ 0.5 us, less than an L2 round trip under load: the wait at a chunk's end is for the load issued a
-// chunk earlier), split once per workgroup one chunk ahead into three bf16 planes.  The halo of the next channel group is
+// The weight chunk (64 x 16 per tap) is staged through REGISTERS as well: every thread splits its 16 bytes of chunk q + 1
+// between the first MFMAs of chunk q, requests chunk q + 2 into the same registers behind them (16 MFMAs x the waves sharing
+// the SIMD to land) and writes the three bf16 planes -- no fp32 staging ring in LDS, no LDS-DMA, no hand-counted vmcnt: 45 KB (3x3) / 52.5 KB (5x5) of LDS, both
+// filter sizes fit a CU three times.  The halo of the next channel group is
 // split and written between the MFMAs of the current group's LAST tap, behind a barrier that follows that tap's fragment
 // reads (the planes are free from there on): no serial split phase.  Epilogue (bias, ELU, addend, BatchNorm partial sums, LDS transposition
 // to full 128-byte lines) as there.  Zero padding or the stride-1 data gradient, K = 3 | 5, C % 16 == 0, Cout % 64 == 0,
@@ -24,24 +25,22 @@ constexpr int CK = 16;
 constexpr unsigned BS_BYTES = 64 * CK * 4, BP_BYTES = 64 * CK * 2;
 // TW = 32 | 16 | 8: the 256-pixel output tile is 8 x 32, 16 x 16 or 32 x 8; an MFMA row block (32 pixels) is then one row,
 // two rows of 16 or four rows of 8 -- the widest tile that divides the output grid
-template <int KS, int NSB, int TW> struct Geo {
+template <int KS, int TW> struct Geo {
     static constexpr int TR = 256 / TW, BR = 32 / TW;
     static constexpr int HW = TW + KS - 1, HH = TR + KS - 1, HP = HW * HH;
     static constexpr int NI = (HP * 4 + NT - 1) / NT;                 // 16-byte halo items per thread and channel group
     static constexpr unsigned AP_BYTES = 3 * 2 * HP * 16;             // A planes: [term][half][halo pixel] x 16 B
-    static constexpr unsigned BS_BASE = AP_BYTES, BP_BASE = BS_BASE + NSB * BS_BYTES;    // weight staging: a ring of NSB chunks
+    static constexpr unsigned BP_BASE = AP_BYTES;                     // weight planes: [buffer][term] x 64 x 16 bf16
     static constexpr unsigned LDS_BYTES = BP_BASE + 2 * 3 * BP_BYTES;
 };
 }  // namespace x3h
 
-// NSB = depth of the weight staging ring: 3 (requests three chunks ahead; two workgroups per CU) or 2 (as conv_igemm_x3_kernel;
-// with the 3x3 halo the workgroup then fits a CU three times -- 53 KB of LDS, <= 168 registers)
-template <int MODE, int KS, int NSB, int TW>
-__global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x3_kernel(const ConvArgs a) {
+template <int MODE, int KS, int TW>
+__global__ __launch_bounds__(NT, 3) void conv_halo_x3_kernel(const ConvArgs a) {
     using namespace x3h;
-    using G = Geo<KS, NSB, TW>;
+    using G = Geo<KS, TW>;
     constexpr int HW = G::HW, HP = G::HP, NI = G::NI, T = KS * KS, TR = G::TR, BR = G::BR;
-    constexpr unsigned BS_BASE = G::BS_BASE, BP_BASE = G::BP_BASE;
+    constexpr unsigned BP_BASE = G::BP_BASE;
     static_assert(G::LDS_BYTES >= 4 * 64 * 32 * 4 + 4 * 64 * 2 * 4, "the epilogue's transposition tiles reuse the ring");
     __shared__ __attribute__((aligned(16))) float smem_all[G::LDS_BYTES / 4];
 
@@ -69,47 +68,50 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int padh = MODE == MODE_TRANSPOSED ? KS - 1 - a.pad : a.pad, padw = MODE == MODE_TRANSPOSED ? KS - 1 - a.pad_w : a.pad_w;
 
-    const long img_bytes = (long)a.sN * 4;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img * a.sN, (unsigned)img_bytes);
+    // The input descriptor starts at the halo's first pixel (which may lie above / left of the image: only addresses of valid
+    // items are ever formed) and ends 4 MB - 64 B behind it or at the image's end: a halo item's offset is then a 16-bit count
+    // of 64-byte units, two items per register, and the count 0xffff -- an item outside the image (zero padding) or beyond
+    // the halo -- is out of the descriptor's range by construction: the hardware returns zeros.
+    const int by = oy0 - padh, bx = ox0 - padw;
+    const long base_f = (long)by * a.sH + (long)bx * a.sW;
+    const long left_bytes = ((long)a.sN - base_f) * 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)img * a.sN + base_f, (unsigned)(left_bytes < 0x3fffc0L ? left_bytes : 0x3fffc0L));
     const __amdgpu_buffer_rsrc_t rw_ = make_rsrc(a.w, a.w_bytes);
 
-    // ---- halo items of this thread: item = pixel * 4 + channel quad; byte offset inside the image (without the channel
-    // group), OOB where the pixel lies outside the image (zero padding) or beyond the halo
+    // ---- halo items of this thread: item = pixel * 4 + channel quad
     // (item i of a thread is pixel (tid >> 2) + 64 i, quad tid & 3: its plane slot is hdst0 + 1024 i, and only the LAST item
     //  of a thread can lie beyond the halo)
-    unsigned hoff[NI];
+    unsigned hpk[(NI + 1) / 2];
     const int hquad = tid & 3;
     const unsigned hdst0 = (unsigned)(((hquad >> 1) * HP + (tid >> 2)) * 16 + (hquad & 1) * 8);        // + term * 2 * HP * 16 + 1024 * i
     const bool hlast_ok = (tid >> 2) + 64 * (NI - 1) < HP;
     static_assert(64 * (NI - 1) < HP, "only the last halo item of a thread may be empty");
+    const int sH16 = (int)a.sH >> 4, sW16 = (int)a.sW >> 4;      // (eligibility: both strides are whole 64-byte units)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int p = (tid >> 2) + 64 * i;
         const int hy = p / HW, hx = p - hy * HW;
-        int iy = oy0 - padh + hy, ix = ox0 - padw + hx;
+        int iy = by + hy, ix = bx + hx;
         if constexpr (MODE == MODE_REFLECT) {        // ReflectionPad2d: the halo holds the mirrored pixels, every tap is in range
             iy = iy < 0 ? -iy : iy; iy = iy >= a.H ? 2 * a.H - 2 - iy : iy;
             ix = ix < 0 ? -ix : ix; ix = ix >= a.W ? 2 * a.W - 2 - ix : ix;
         }
         const bool ok = p < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        hoff[i] = ok ? (unsigned)(iy * (int)a.sH + ix * (int)a.sW + hquad * 4) * 4u : OOB;
+        const unsigned u = ok ? (unsigned)((iy - by) * sH16 + (ix - bx) * sW16) : 0xffffu;
+        if (i & 1) hpk[i >> 1] |= u << 16; else hpk[i >> 1] = u;
     }
-    // weights: wave w stages rows 16w .. 16w+15 of the 64 x 16 chunk (lane -> row lane/4, physical slot lane%4 holding the
-    // LOGICAL slot (lane%4) ^ ((row/4)%4)), as conv_igemm_x3_kernel
-    const int prow = lane >> 2;
-    const unsigned col4 = 16u * ((lane & 3) ^ ((lane >> 4) & 3));
-    const unsigned vb = (unsigned)((n0 + 16 * wave + prow) * a.K) * 4u + col4;
+    const unsigned hq16 = 16u * (unsigned)hquad;
+    // weights: thread -> row tid / 4 of the 64 x 16 chunk, 16-byte slot tid % 4
+    const int srow = tid >> 2, sls = tid & 3;
+    const unsigned vb = (unsigned)((n0 + srow) * a.K) * 4u + 16u * (unsigned)sls;
 
     const int ngroups = a.C / CK;
     const int nchunks = ngroups * T;
     int s_qb = 0, sb_tap = 0;
     unsigned s_boff = 0, sb_c4 = 0;
-    unsigned s_ld = 0, s_rd = 1;                                  // staging slots (mod NSB): next load, next split
-    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
-    const unsigned m0_b = lds0 + BS_BASE + 1024u * (unsigned)wave;
-    auto load_b = [&]() {                                         // chunk s_qb into slot s_ld (past the end: chunk 0 again, never used)
-        dma16s(rw_, m0_b + s_ld * BS_BYTES, vb, s_qb < nchunks ? s_boff : 0u);
-        s_ld = s_ld == NSB - 1 ? 0u : s_ld + 1;
+    float4 wq;                                                    // this thread's 16 bytes of the chunk in flight
+    auto load_b = [&]() {                                         // chunk s_qb (past the end: chunk 0 again, never used)
+        wq = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_, vb, s_qb < nchunks ? s_boff : 0u, 0));
         ++s_qb;
         s_boff += (unsigned)a.C * 4u;                             // next tap of the same channel group
         if (++sb_tap == T) { sb_tap = 0; sb_c4 += CK * 4; s_boff = sb_c4; }
@@ -121,8 +123,6 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
     const unsigned fa_base = (unsigned)((fh * HP + (2 * wave * BR + frow / TW) * HW + frow % TW) * 16);   // + tap offset + (term * 2 * HP + i * BR * HW) * 16
     unsigned fb_off = BP_BASE + (unsigned)frow * (CK * 2) + 16u * (fh ^ ((frow >> 3) & 1));
     asm volatile("" : "+v"(fb_off));
-    const int srow = tid >> 2, sls = (tid & 3) ^ ((srow >> 2) & 3);            // weight split: thread -> its 16 bytes of the staging tile
-    const unsigned ss_off = BS_BASE + 16u * (unsigned)tid;
     const unsigned sp_off = BP_BASE + (unsigned)srow * (CK * 2) + 16u * ((sls >> 1) ^ ((srow >> 3) & 1)) + 8u * (sls & 1);
     char* lds_c = reinterpret_cast<char*>(smem_all);
 
@@ -141,11 +141,12 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
     auto halo_load = [&](int g) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            hv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, hoff[i], g * (CK * 4), 0));
+            hv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                rx, (((i & 1) ? hpk[i >> 1] >> 16 : hpk[i >> 1] & 0xffffu) << 6) + hq16, g * (CK * 4), 0));
     };
 
-    auto split_b0 = [&]() {                     // staging slot 0 -> planes 0 (prologue only; the loop threads it)
-        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off);
+    auto split_b0 = [&]() {                     // chunk 0 -> planes 0 (prologue only; the loop threads it)
+        const float4 w4 = wq;
         uint2 h, m, l;
         x3::split2(w4.x, w4.y, h.x, m.x, l.x);
         x3::split2(w4.z, w4.w, h.y, m.y, l.y);
@@ -184,8 +185,11 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
         constexpr unsigned BUF = decltype(buf_tag)::value, NXT = BUF ^ 1;
         const bool LAST = s_kh == KS - 1 && s_kw == KS - 1 && s_g + 1 < ngroups;
         const bool halo_issue = (s_kh | s_kw) == 0 && s_g + 1 < ngroups;    // (uniform) first tap of a group that has a successor
-        const bool halo_near = s_kh == 0 && s_kw == 1 && s_g + 1 < ngroups; // ... and the tap behind it: the halo loads may still fly
-        load_b();
+        // next chunk's weights (fp32), requested during the previous chunk: the ONLY vmcnt wait of the loop is taken here, in
+        // front of the halo requests (vmcnt counts in order: behind them it would wait for the halo as well; and a branch in
+        // the middle of the chunk lets LLVM sink the whole split below it)
+        asm volatile("" : "+v"(wq.x), "+v"(wq.y), "+v"(wq.z), "+v"(wq.w));
+        const float ws[4] = {wq.x, wq.y, wq.z, wq.w};
         if (halo_issue) halo_load(s_g + 1);
         const int ey = MODE == MODE_TRANSPOSED ? KS - 1 - s_kh : s_kh, ex = MODE == MODE_TRANSPOSED ? KS - 1 - s_kw : s_kw;
         const unsigned fa = fa_base + (unsigned)((ey * HW + ex) * 16);
@@ -195,20 +199,15 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 av[i][t] = *reinterpret_cast<const u32x4*>(lds_c + fa + (unsigned)((t * 2 * HP + i * BR * HW) * 16));
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                fb[j][t] = *reinterpret_cast<const u32x4*>(lds_c + fb_off + ((BUF * 3 + t) * BP_BYTES + (unsigned)j * 32 * CK * 2));
-        const float4 w4 = *reinterpret_cast<const float4*>(lds_c + ss_off + s_rd * BS_BYTES);     // next chunk's weights (fp32)
-        s_rd = s_rd == NSB - 1 ? 0u : s_rd + 1;
+        // (the weights' lo planes are read behind the last use of the activations' lo fragments, into their registers)
+        auto load_fb = [&](int j, int t) { fb[j][t] = *reinterpret_cast<const u32x4*>(lds_c + fb_off + ((BUF * 3 + t) * BP_BYTES + (unsigned)j * 32 * CK * 2)); };
+        load_fb(0, 0); load_fb(0, 1); load_fb(1, 0); load_fb(1, 1);
         if (LAST) __syncthreads();                  // every wave holds its fragments of this group's last tap: the planes are free
-        const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
         x3::Terms tw;
-        // MFMA N (0..11) of row block I: products largest first -- hi*hi, hi*mid, hi*lo, mid*hi, mid*mid, lo*hi; column block N % 2
+        // MFMA N (0..11) of row block I: products hi*hi, hi*mid, lo*hi, mid*hi, mid*mid, hi*lo; column block N % 2
         auto mm = [&](auto i_tag, auto n_tag) {
             constexpr int I = decltype(i_tag)::value, N = decltype(n_tag)::value, TT = N / 2, J = N % 2;
-            constexpr int TA = TT < 3 ? 0 : TT < 5 ? 1 : 2, TB = TT == 0 ? 0 : TT == 1 ? 1 : TT == 2 ? 2 : TT == 3 ? 0 : TT == 4 ? 1 : 0;
+            constexpr int TA = TT < 2 ? 0 : TT == 2 ? 2 : TT < 5 ? 1 : 0, TB = TT == 0 ? 0 : TT == 1 ? 1 : TT == 2 ? 0 : TT == 3 ? 0 : TT == 4 ? 1 : 2;
             acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(av[I][TA]), bf(fb[J][TB]), acc[I][J], 0, 0, 0);
         };
 #define PD_I(n) std::integral_constant<int, n>{}
@@ -222,6 +221,7 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
         mm(PD_I(0), PD_I(3)); PD_SB
         mm(PD_I(1), PD_I(2)); x3::sp_l<0, true>(tw); PD_SB
         mm(PD_I(1), PD_I(3)); x3::sp_l<1, true>(tw); PD_SB
+        load_b();                                   // chunk q + 2's weights: their registers are free, two thirds of a chunk (x 3 waves per SIMD) to land
         mm(PD_I(0), PD_I(4)); PD_SB
         mm(PD_I(0), PD_I(5));
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0] ^ wsign, tw.h[1] ^ wsign};
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 2) * BP_BYTES) = uint2{tw.l[0] ^ wsign, tw.l[1] ^ wsign};
         PD_SB
         // LAST: one halo item (18 vector instructions, 3 ds_write_b64) per two MFMAs
-        mm(PD_I(1), PD_I(4)); mm(PD_I(1), PD_I(5)); if (LAST) halo_item(PD_I(0)); PD_SB
+        mm(PD_I(1), PD_I(4)); mm(PD_I(1), PD_I(5)); load_fb(0, 2); load_fb(1, 2); if (LAST) halo_item(PD_I(0)); PD_SB
         mm(PD_I(0), PD_I(6)); mm(PD_I(0), PD_I(7)); if (LAST) halo_item(PD_I(1)); PD_SB
         mm(PD_I(1), PD_I(6)); mm(PD_I(1), PD_I(7)); if (LAST) halo_item(PD_I(2)); PD_SB
         mm(PD_I(0), PD_I(8)); mm(PD_I(0), PD_I(9)); if (LAST) halo_item(PD_I(3)); PD_SB
@@ -240,37 +240,23 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
 #undef PD_SB
 #undef PD_I
         if (++s_kw == KS) { s_kw = 0; if (++s_kh == KS) { s_kh = 0; ++s_g; } }
-        // The weights the NEXT chunk splits were requested a chunk ago: all but this chunk's own request must have landed
-        // (vmcnt counts in order; the halo loads of a group's first tap were issued behind that chunk's request and may fly on
-        // until the end of the group's second tap).
-        if constexpr (NSB == 3) {
-            if (halo_issue || halo_near) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI + 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        } else {                                 // two slots: this chunk's own request feeds the next chunk's split
-            if (halo_issue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
+        __syncthreads();                            // the next chunk's weight planes (and, behind LAST, the next halo) are written
     };
 
-    // ---- prologue: halo of group 0, weights of chunks 0, 1, 2 (slots 0, 1, 2); planes of the halo and of chunk 0
+    // ---- prologue: halo of group 0, weights of chunks 0 and 1 (register sets 0, 1); planes of the halo and of chunk 0
     {
         halo_load(0);
         load_b();
-        load_b();
-        if constexpr (NSB == 3) load_b();
         halo_split();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         split_b0();
+        load_b();
         __syncthreads();
     }
     for (int q = 0; q < nchunks; q += 2) {
         chunk(std::integral_constant<unsigned, 0>{});
         if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (run-out weight requests still target the staging ring)
-    __syncthreads();
+    __syncthreads();                                              // (the epilogue's transposition tiles reuse the planes)
 
     // ---- epilogue: per column block the wave transposes its 64 x 32 block (two output rows of 32 pixels) through LDS and
     // leaves with full 128-byte lines; BatchNorm partial sums: one row of `stats` per 128 output pixels (waves 0-1 | 2-3)
@@ -356,12 +342,20 @@ __global__ __launch_bounds__(NT, (NSB == 2 && KS == 3) ? 3 : 2) void conv_halo_x
 static int x3_halo_tw(int Ho, int Wo) {
     return (Wo % 32 == 0 && Ho % 8 == 0) ? 32 : (Wo % 16 == 0 && Ho % 16 == 0) ? 16 : (Wo % 8 == 0 && Ho % 32 == 0) ? 8 : 0;
 }
+// halo offsets are 16-bit counts of 64-byte units from the halo's first pixel (two per register)
+static bool x3_halo_span_ok(const ConvArgs& a) {
+    const int tw = x3_halo_tw(a.Ho, a.Wo);
+    if (tw == 0 || a.sH % 16 != 0 || a.sW % 16 != 0) return false;
+    const long hh = 256 / tw + a.KH - 1, hw = tw + a.KW - 1;
+    return (hh + 1) * (a.sH / 16) + (hw + 1) * (a.sW / 16) < 0xffffL;
+}
 static bool x3_halo_eligible(const ConvArgs& a) {
     // (at least 512 workgroups, two per CU: with 320 the gather kernel's 128-row tiles fill the chip better -- 3x3x256 @32x40
     //  151 vs 132 TF, the data gradient of 5x5 256 -> 512 @32x40 165 vs 151)
     return (a.KH == 3 || a.KH == 5) && a.KW == a.KH && a.stride == 1 &&
            (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0) || (a.mode == MODE_REFLECT && a.pad < a.H && a.pad_w < a.W)) &&
            a.C % x3h::CK == 0 && x3_halo_tw(a.Ho, a.Wo) != 0 && (a.M / 256) * (a.Co / 64) >= 512 && (a.stats_rows == 128 || a.stats_rows == 64) && a.sC == 1 &&
+           x3_halo_span_ok(a) &&
            (long)a.sN * 4 < 0x7fffffffL && (long)a.Ho * a.Wo * a.ldy * 4 < 0x7fffffffL &&
            (!a.add || (long)a.Ho * a.Wo * a.ld_add * 4 < 0x7fffffffL);
 }
@@ -372,20 +366,14 @@ static int launch_conv_x3_halo(ConvArgs& a, hipStream_t st) {
     a.ntiles = a.Co / 64;
     const long nblk = (long)a.mtiles * a.ntiles;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
-    // Weight ring of two chunks for both filter sizes (round 4, same box): with it the 3x3 workgroup fits a CU three times
-    // (53 KB, 166 registers) -- 3x3x64 @256x320 forward 154 -> 185 TF, data gradient 185 -> 200, @128x160 180 -> 194 / 168 ->
-    // 189 against the three-chunk ring at two workgroups per CU; for 5x5 (62 KB: two per CU either way) the two rings are
-    // equal (185 / 222 TF).  PD_HALO_NSB3 (tools/build_probe.sh) builds the three-chunk ring for A/B runs.
-#ifdef PD_HALO_NSB3
-    constexpr int NSB3 = 3, NSB5 = 3;
-#else
-    constexpr int NSB3 = 2, NSB5 = 2;
-#endif
-#define PD_HALO(KSV, NSBV, TWV) do { if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, KSV, NSBV, TWV>), grid, block, 0, st, a); \
-                                     else if (a.mode == MODE_REFLECT) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_REFLECT, KSV, NSBV, TWV>), grid, block, 0, st, a); \
-                                     else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, KSV, NSBV, TWV>), grid, block, 0, st, a); } while (0)
-    if (a.KH == 3) { if (tw == 32) PD_HALO(3, NSB3, 32); else if (tw == 16) PD_HALO(3, NSB3, 16); else PD_HALO(3, NSB3, 8); }
-    else { if (tw == 32) PD_HALO(5, NSB5, 32); else if (tw == 16) PD_HALO(5, NSB5, 16); else PD_HALO(5, NSB5, 8); }
+    // Occupancy history (round 4, same box): a three-chunk LDS-DMA weight ring at two workgroups per CU -> a two-chunk ring at
+    // three (3x3 only: 53 KB, 166 registers; 3x3x64 @256x320 forward 154 -> 185 TF, data gradient 185 -> 200) -> weights staged
+    // through registers, no ring: 45 KB / 52.5 KB, three workgroups per CU for 5x5 as well.
+#define PD_HALO(KSV, TWV) do { if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_ZERO, KSV, TWV>), grid, block, 0, st, a); \
+                               else if (a.mode == MODE_REFLECT) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_REFLECT, KSV, TWV>), grid, block, 0, st, a); \
+                               else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, KSV, TWV>), grid, block, 0, st, a); } while (0)
+    if (a.KH == 3) { if (tw == 32) PD_HALO(3, 32); else if (tw == 16) PD_HALO(3, 16); else PD_HALO(3, 8); }
+    else { if (tw == 32) PD_HALO(5, 32); else if (tw == 16) PD_HALO(5, 16); else PD_HALO(5, 8); }
 #undef PD_HALO
     return pd::check_launch("pd_conv2d");
 }
