@@ -1208,16 +1208,20 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
 constexpr long X3_MIN_WG = 512, X3_MIN_WG1 = 320;
 
 // 0: not for the bf16-split kernel; 2 | 1: its row blocks per wave (256- | 128-row tiles)
+// what every bf16-split forward / data-gradient kernel needs of a launch (tile shapes and channel counts are the kernels' own)
+static bool x3_common_ok(const ConvArgs& a, bool vec) {
+    const bool on = !(a.flags & PD_CONV_FP32_MFMA);
+    return on && vec && a.KH * a.KW <= 31 && a.pad < a.KH && a.pad_w < a.KW &&
+           (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0) ||
+            (a.mode == MODE_REFLECT && a.KH == 3 && a.KW == 3 && a.pad == 1 && a.pad_w == 1 && a.stride == 1 && a.Ho == a.H &&
+             a.Wo == a.W && a.H >= 3 && a.W >= 3)) &&
+           !a.oscale && (a.act == ACT_NONE || a.act == ACT_ELU) && (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
+           (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0)) && (long)a.Co * a.K * 4 < 0x7fffffffL;
+}
 static int x3_eligible(const ConvArgs& a, bool vec) {
-    const bool on = !(a.flags & PD_CONV_FP32_MFMA), force = (a.flags & PD_CONV_BF16X3) != 0;
+    const bool force = (a.flags & PD_CONV_BF16X3) != 0;
     // (C % 4 == 0 is part of `vec`; a partly empty last channel group may at most double the contraction: C >= 8)
-    if (!(on && vec && (a.C + x3::CK - 1) / x3::CK * x3::CK <= 2 * a.C && a.Co % x3::BN == 0 && a.M % 128 == 0 && a.KH * a.KW <= 31 &&
-          a.pad < a.KH && a.pad_w < a.KW &&
-          (a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0) ||
-           (a.mode == MODE_REFLECT && a.KH == 3 && a.KW == 3 && a.pad == 1 && a.pad_w == 1 && a.stride == 1 && a.Ho == a.H &&
-            a.Wo == a.W && a.H >= 3 && a.W >= 3)) &&
-          !a.oscale && (a.act == ACT_NONE || a.act == ACT_ELU) && (a.ldy & 3) == 0 && ((size_t)a.y & 15) == 0 &&
-          (!a.add || ((a.ld_add & 3) == 0 && ((size_t)a.add & 15) == 0)) && (long)a.Co * a.K * 4 < 0x7fffffffL))
+    if (!(x3_common_ok(a, vec) && (a.C + x3::CK - 1) / x3::CK * x3::CK <= 2 * a.C && a.Co % x3::BN == 0 && a.M % 128 == 0))
         return 0;
     const long ct = a.Co / x3::BN;
     if (a.M % 256 == 0 && (a.M / 256) * ct >= X3_MIN_WG) return 2;
@@ -1310,8 +1314,8 @@ extern "C" int pd_conv2d_uses_x3(long M, int Co, int C, int KH, int KW, int stri
     a.oscale = has_out_scale ? reinterpret_cast<const float*>(16) : nullptr;
     while ((1 << a.sshift) < stride) ++a.sshift;
     a.stats_rows = pd_conv2d_tile_m(M, Co);
-    const int rb = x3_eligible(a, true);
-    return rb && !(flags & PD_CONV_X3_IM2COL) && Ho > 0 && Wo > 0 && x3_halo_eligible(a) ? 3 : rb;
+    if (x3_common_ok(a, true) && !(flags & PD_CONV_X3_IM2COL) && Ho > 0 && Wo > 0 && x3_halo_eligible(a)) return 3;
+    return x3_eligible(a, true);
 }
 
 extern "C" int pd_conv2d_tile_m(long M, int Co) {
@@ -1414,11 +1418,9 @@ static int conv2d_impl(const void* x, const void* w, const void* bias, const voi
     const int bm = pd_conv2d_tile_m(a.M, Co);
     // 96 output columns (the data gradient of the decoder's 96 -> 32 layer): three 32-wide column tiles instead of a full and a
     // half-empty 64-wide one (a quarter of the matrix work of that launch was padding)
-    if (const int rb = x3_eligible(a, vec)) {
-        // the halo-tile kernel (every activation element staged and split once per tile) where its tiling fits
-        if (!(flags & PD_CONV_X3_IM2COL) && x3_halo_eligible(a)) return launch_conv_x3_halo(a, st);
-        return launch_conv_x3(a, rb, st);
-    }
+    // the halo-tile kernel (every activation element staged and split once per tile) where its tiling fits
+    if (x3_common_ok(a, vec) && !(flags & PD_CONV_X3_IM2COL) && x3_halo_eligible(a)) return launch_conv_x3_halo(a, st);
+    if (const int rb = x3_eligible(a, vec)) return launch_conv_x3(a, rb, st);
     if (Co == 96 && bm == 128) return launch_conv<128, 32, 32, 32>(a, vec, st);
     if (Co > 32) return bm == 128 ? launch_conv<128, 64, 64, 32>(a, vec, st) : launch_conv<64, 64, 32, 32>(a, vec, st);
     if (Co > 16) return launch_conv<128, 32, 32, 32>(a, vec, st);

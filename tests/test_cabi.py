@@ -229,7 +229,13 @@ def test_which_shapes_take_the_bf16_split_kernels():
     assert lib.pd_conv2d_uses_x3(16 * 32 * 40, 512, 256, 5, 5, 1, 2, 0, 0, 0, 32, 40, AUTO) == 3   # 32 x 40: 32 x 8 tiles, 640 workgroups
     assert lib.pd_conv2d_uses_x3(16 * 32 * 40, 256, 256, 3, 3, 1, 1, 0, 0, 0, 32, 40, AUTO) == 1   # ... 80 x 4 = 320 workgroups: the gather kernel's 128-row tiles
     assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 0, 0, 16, 20, AUTO) == 1   # 16 x 20: no tile shape divides it
-    assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 256, 320, AUTO) == 2            # 4x4 stem / partly empty channel group
+    assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 256, 320, AUTO) == 3            # 4x4 space-to-depth stem: the halo kernel's row-window form
+    assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 256, 320, IM2COL) == 2          # ... or the gather kernel with a partly empty channel group
+    assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 250, 320, AUTO) == 2            # ... as does a grid no 8 x 32 tile divides
+    assert lib.pd_conv2d_uses_x3(M16, 32, 96, 3, 3, 1, 1, 1, 2, 0, 256, 320, AUTO) == 3            # 32 output channels: 32-column workgroups (decoder 96 -> 32)
+    assert lib.pd_conv2d_uses_x3(M16, 96, 32, 3, 3, 1, 1, 2, 0, 0, 256, 320, AUTO) == 3            # ... and its data gradient: three 32-column tiles
+    assert lib.pd_conv2d_uses_x3(M16 // 4, 32, 64, 3, 3, 1, 1, 1, 2, 0, 128, 160, AUTO) == 3       # 64 -> 32 @128x160
+    assert lib.pd_conv2d_uses_x3(M16, 32, 96, 5, 5, 1, 2, 0, 0, 0, 256, 320, AUTO) == 0            # (5x5 with 32 columns: not instantiated)
     assert lib.pd_conv2d_uses_x3(M16, 64, 128, 3, 3, 1, 1, 1, 2, 0, 256, 320, AUTO) == 3           # reflection padding: mirrored halo
     # the caller's flags decide the arithmetic -- no environment variable is read by the library
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 0, 0, FP32) == 0

@@ -429,6 +429,9 @@ X3_CASES = [
     (4, 64, 64, 80, 256, 3, 1, 1),         # ... with 64-row statistics tiles (M = 20480)
     (2, 36, 256, 320, 64, 3, 1, 1),        # 36 channels (the space-to-depth normals stem): a partly empty third channel group
     (2, 8, 256, 320, 64, 3, 1, 1),         # 8 channels (XOLP stem): one half-empty group
+    (2, 96, 256, 320, 32, 3, 1, 1),        # 32 output channels (decoder 96 -> 32): the halo kernel's 32-column workgroups;
+                                           # its data gradient has 96 output columns = three of them
+    (8, 64, 128, 160, 32, 3, 1, 1),        # ... 64 -> 32 @128x160
 ]
 
 
@@ -495,7 +498,37 @@ def test_bf16x3_kernel_keeps_fp32_accuracy(case, monkeypatch):
     assert dbe["1"] <= 2e-5 and dbe["0"] <= 2e-5, dbe
 
 
-@pytest.mark.parametrize("case", [(8, 128, 128, 160, 64), (16, 256, 64, 80, 128), (16, 512, 32, 40, 256), (4, 48, 128, 160, 64)])
+@pytest.mark.parametrize("C", [36, 12, 8])
+def test_row_window_form_of_the_space_to_depth_stems(C, monkeypatch):
+    """The 4x4 / pad (2, 1) convolution over the space-to-depth stem input (C = 36 / 12 / 8) on the halo kernel's row-window
+    form: a filter row of 4 C contiguous floats read as whole 16-channel groups, windows that leave the image row masked in
+    the first / last tile of a row.  vs an fp64 convolution, next to the fp32-MFMA kernel and the gather kernel (which
+    leaves the last channel group partly empty); BatchNorm partial sums included."""
+    N, H, W, Co = 2, 256, 320, 64
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(N, C, H, W, generator=g)
+    x[:, :, :, :3] *= 11.0                                      # (the masked columns carry weight)
+    x[:, :, :, -3:] *= 7.0
+    w = torch.randn(Co, C, 4, 4, generator=g) / (C * 16) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=1, padding=2)[:, :, :H, :W]
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    errs, sums = {}, {}
+    for name, fl, code in (("halo", ops.CONV_AUTO, 3), ("gather", ops.CONV_X3_IM2COL, 2), ("fp32", ops.CONV_FP32_MFMA, 0)):
+        monkeypatch.setattr(ops, "CONV_FLAGS", fl)
+        assert ops.lib.pd_conv2d_uses_x3(N * H * W, Co, C, 4, 4, 1, 2, 0, 0, 0, H, W, fl) == code
+        y, st = ops.conv2d_fwd(xd, wd, b.cuda(), stride=1, pad=2, out_hw=(H, W), want_stats=True)
+        errs[name] = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        sums[name] = st.double().sum(0).cpu()
+    assert errs["halo"] <= 5e-6 and errs["halo"] <= 1.5 * errs["fp32"] + 1e-8, errs
+    _close(sums["halo"][:, 1], (ref ** 2).sum((0, 2, 3)), 1e-5)
+    M = N * H * W
+    assert (sums["halo"][:, 0] - ref.sum((0, 2, 3))).abs().max().item() / M <= 2.5e-7 * ref.pow(2).mean().sqrt().item()
+
+
+@pytest.mark.parametrize("case", [(8, 128, 128, 160, 64), (16, 256, 64, 80, 128), (16, 512, 32, 40, 256), (4, 48, 128, 160, 64),
+                                  (2, 96, 256, 320, 32), (8, 64, 128, 160, 32)])
 def test_bf16x3_kernel_reflection_padding_bias_elu(case, monkeypatch):
     """The decoder's ConvBlock (ReflectionPad2d(1) + Conv3x3 + bias + ELU) on the bf16-split kernel (256- and 128-row tiles, a
     partly empty channel group) vs an fp64 reference, next to the fp32-MFMA kernel."""

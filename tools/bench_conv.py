@@ -24,6 +24,11 @@ SHAPES = [  # name, C, H, W, Co, k, s, p, mode
     ("dec.upconv(1,1) as zero-pad 96->32 @256x320 (dgrad)", 96, 256, 320, 32, 3, 1, 1, 0),
     ("dec.upconv(0,1) 16->16 @512x640 refl", 16, 512, 640, 16, 3, 1, 1, 1),
     ("stem normals 7x7s2 9->64 @512x640", 9, 512, 640, 64, 7, 2, 3, 0),
+    # the stems as they run in the step: 4x4 / pad (2, 1) over the space-to-depth input (FLOPs counted for the executed 4x4x4C)
+    ("stem s2d normals 4x4 36->64 @256x320", 36, 256, 320, 64, 4, 1, 2, 0),
+    ("stem s2d rgb 4x4 12->64 @256x320", 12, 256, 320, 64, 4, 1, 2, 0),
+    ("stem s2d xolp 4x4 8->64 @256x320", 8, 256, 320, 64, 4, 1, 2, 0),
+    ("dec.upconv(2,1)b 64->32 @128x160 refl", 64, 128, 160, 32, 3, 1, 1, 1),
 ]
 
 
@@ -42,13 +47,14 @@ for name, C, H, W, Co, k, s, p, mode in SHAPES:
     if ONLY and ONLY not in name:
         continue
     x = torch.randn(B, C, H, W, device="cuda")
-    if C >= 16:
+    if C >= 16 or k == 4:
         x = x.contiguous(memory_format=torch.channels_last)
+    okw = dict(out_hw=(H, W)) if k == 4 else {}
     w = (torch.randn(Co, C, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
-    y = ops.conv2d_fwd(x, w, None, stride=s, pad=p, mode=mode)
+    y = ops.conv2d_fwd(x, w, None, stride=s, pad=p, mode=mode, **okw)
     Ho, Wo = y.shape[2:]
     flops = 2.0 * B * Ho * Wo * Co * C * k * k
-    t_f = timeit(lambda: ops.conv2d_fwd(x, w, None, stride=s, pad=p, mode=mode, out=y))
+    t_f = timeit(lambda: ops.conv2d_fwd(x, w, None, stride=s, pad=p, mode=mode, out=y, **okw))
     dy = torch.randn_like(y)
     t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, w.shape, stride=s, pad=p, mode=mode))
     res = {"layer": name, "GF": round(flops / 1e9, 2), "fwd_ms": round(t_f, 3), "fwd_TF": round(flops / t_f / 1e9, 1),
