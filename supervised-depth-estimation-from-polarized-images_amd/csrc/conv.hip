@@ -2509,7 +2509,8 @@ extern "C" int pd_conv2d_wgrad_uses_x3(long M, int Co, int C, int KH, int KW, in
     const int nb = (pad + stride - 1) / stride, nbw = (nb + 1) / 2;
     const bool x3c = uni_on && wgrad_x3c_enabled(flags) && wgrad_tco(Co) == 64 && C % 4 == 0 && Co % 4 == 0 && Wo % 2 == 0 && Ho >= 2 * nb &&
            Wo >= 4 * nbw && Wo >= 14 && (2 * nb + 1) * (2 * nbw + 1) <= 31 && mper % WG_MC == 0 && M % 4 == 0 && KH * KW * C >= 4;
-    if (x3c && !(flags & PD_CONV_X3_IM2COL)) {      // 2: the halo-tile kernel (both operands split once per tile, transposed LDS reads)
+    if (wgrad_x3c_enabled(flags) && !(flags & (PD_CONV_GENERAL_KERNELS | PD_CONV_X3_IM2COL)) && C % 4 == 0) {
+        // 2: the halo-tile kernel (both operands split once per tile, transposed LDS reads) -- the same test as pd_conv2d_wgrad's
         WgradArgs a{};
         a.mode = mode; a.stride = stride; a.KH = KH; a.KW = KW; a.pad = pad; a.C = C; a.Co = Co; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
         a.ldd = Co; a.sN = (long)H * W * C;

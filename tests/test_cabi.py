@@ -220,7 +220,11 @@ def test_which_shapes_take_the_bf16_split_kernels():
     assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 2   # decoder: ReflectionPad2d(1) + Conv3x3 (mirrored strip)
     assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 96, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 1    # ... 96 input channels: the gather kernel
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 5, 5, 1, 2, 1, 256, 320, 256, 320, AUTO) == 0       # reflect 5x5: general kernel
-    assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 0       # 32-wide co tile
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 2       # 32 output channels: the halo kernel's 32-channel workgroups
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 1, 256, 320, 256, 320, AUTO) == 2       # ... the decoder's 96 -> 32 (reflection padding)
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 256, 320, 256, 320, IM2COL) == 0     # ... otherwise the fp32 kernel's 32-wide tile
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 5, 5, 1, 2, 0, 256, 320, 256, 320, AUTO) == 0       # (5x5 with 32 channels: not instantiated)
+    assert lib.pd_conv2d_wgrad_workspace(M16, 32, 864, AUTO) >= 2 * (768 // 6) * (32 * 864 + 32) * 4   # two partial rows per slice
     # with the output grid known, the halo-tile kernel takes the 3x3 / 5x5 stride-1 layers with whole 8 x 32 tiles
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 256, 320, AUTO) == 3
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 2, 0, 0, 256, 320, AUTO) == 3            # stride-1 data gradient

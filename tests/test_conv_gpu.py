@@ -547,6 +547,19 @@ def test_bf16x3_kernel_reflection_padding_bias_elu(case, monkeypatch):
         y = ops.conv2d_fwd(xd, wd, b.cuda(), stride=1, pad=1, mode=ops.MODE_REFLECT, act=ops.ACT_ELU)
         errs[knob] = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert errs["1"] <= 5e-6 and errs["1"] <= 1.5 * errs["0"] + 1e-7, errs
+    # ... and the weight / bias gradient of the same layer (mirrored strips in the halo kernel; 32 output channels: its
+    # 32-channel workgroups with two partial slices per tile)
+    dy = torch.randn(ref.shape, generator=g)
+    wv = w.double().requires_grad_(True)
+    ref_dw = torch.autograd.grad(F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), wv), wv, dy.double())[0]
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    dwe = {}
+    for knob in ("1", "0"):
+        monkeypatch.setattr(ops, "WGRAD_FLAGS", ops.CONV_AUTO if knob == "1" else ops.CONV_FP32_MFMA)
+        dw, db = ops.conv2d_wgrad(xd, dyd, w.shape, stride=1, pad=1, mode=ops.MODE_REFLECT, want_bias=True)
+        dwe[knob] = (dw.cpu().double() - ref_dw).abs().max().item() / ref_dw.abs().max().item()
+        _close(db.cpu(), dy.double().sum((0, 2, 3)).float(), 2e-5)
+    assert dwe["1"] <= 2e-5 and dwe["1"] <= 1.5 * dwe["0"] + 2e-7, dwe
 
 
 # ------------------------------------------------------------------ the bf16-split kernels on inputs that are not `randn`
