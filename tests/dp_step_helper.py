@@ -89,7 +89,14 @@ def main(out_path):
             "buckets": 0 if tr.reducer is None else len(tr.reducer.buckets),
             "global_norm": tr.loss_cfg.global_norm}
     torch.save(info, out_path)
+    # teardown in dependency order: the captured graph (it may hold RCCL nodes), then the process group, then the interpreter
+    del gs
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
     if dist.is_initialized():
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

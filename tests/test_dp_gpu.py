@@ -4,6 +4,7 @@ everything an N-rank run does except having peers.  Its parameters after two ste
 single-process run (an all-reduce over one rank is the identity), also with the global mask normalisation of the
 loss switched on (the exchanged sums of one rank are its own)."""
 import os
+import socket
 import subprocess
 import sys
 
@@ -18,9 +19,11 @@ def _run(tmp_path, name, **env):
     out = tmp_path / f"{name}.pt"
     e = dict(os.environ)
     e.update({k: str(v) for k, v in env.items()})
-    e["MASTER_PORT"] = str(29500 + (os.getpid() + len(name)) % 400)
+    with socket.socket() as sk:                                   # a port nobody holds (the child binds it a moment later)
+        sk.bind(("127.0.0.1", 0))
+        e["MASTER_PORT"] = str(sk.getsockname()[1])
     r = subprocess.run([sys.executable, HELPER, str(out)], env=e, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-6000:])
     return torch.load(out)
 
 
