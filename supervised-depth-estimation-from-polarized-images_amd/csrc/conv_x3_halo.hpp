@@ -411,7 +411,8 @@ __global__ __launch_bounds__(NT, 3) void conv_halo_x3_kernel(const ConvArgs a) {
 // a whole number of 8 x 32, 16 x 16 or 32 x 8 tiles, at least 512 workgroups (two per CU: with 320 the gather kernel's
 // 128-row tiles fill the chip better -- 3x3x256 @32x40 151 vs 132 TF, the data gradient of 5x5 256 -> 512 @32x40 165 vs 151), and
 //   * a square 3x3 / 5x5 filter, zero padding | the stride-1 data gradient | reflection padding, whole 16-channel groups,
-//     Cout % 64 == 0 -- or, 3x3 on 8 x 32 tiles only, Cout % 32 == 0 (32-column workgroups); or
+//     Cout % 64 == 0 with 64-column workgroups -- or, where those would be fewer than 512 or Cout % 64 == 32, 32-column
+//     workgroups (3x3 on every tile shape, 5x5 on 32 x 8 tiles); or
 //   * a 4x4 zero-padded filter over contiguous pixels (sW == C: the space-to-depth stems) with 4 C % 16 == 0, Cout % 64 == 0,
 //     8 x 32 tiles: the row-window form.
 // tile width: the widest of 32 | 16 | 8 whose 256-pixel tile (8 | 16 | 32 rows) divides the output grid; 0: none
@@ -422,7 +423,8 @@ struct HaloPlan { int tw, ncb; bool rowwin; };
 static bool x3_halo_plan(const ConvArgs& a, HaloPlan& p) {
     p.tw = x3_halo_tw(a.Ho, a.Wo);
     p.rowwin = a.KH == 4 && a.KW == 4;
-    p.ncb = a.Co % 64 == 0 ? 2 : 1;
+    // 64-column workgroups where they are at least 512; otherwise 32-column ones (3x3x256 @32x40: 320 -> 640 workgroups)
+    p.ncb = (a.Co % 64 == 0 && (a.M / 256) * (a.Co / 64) >= 512) ? 2 : 1;
     if (p.tw == 0 || a.stride != 1 || a.sC != 1 || !(a.stats_rows == 128 || a.stats_rows == 64) || a.Co % 32 != 0) return false;
     if (!((long)a.sN * 4 < 0x7fffffffL && (long)a.Ho * a.Wo * a.ldy * 4 < 0x7fffffffL && (!a.add || (long)a.Ho * a.Wo * a.ld_add * 4 < 0x7fffffffL)))
         return false;
@@ -435,7 +437,10 @@ static bool x3_halo_plan(const ConvArgs& a, HaloPlan& p) {
         return a.mode == MODE_ZERO && a.sW == a.C && (a.KW * a.C) % x3h::CK == 0 && p.ncb == 2 && p.tw == 32 && a.pad < a.KH && a.pad_w < a.KW;
     if (!((a.KH == 3 || a.KH == 5) && a.KW == a.KH && a.C % x3h::CK == 0)) return false;
     if (!(a.mode == MODE_ZERO || (a.mode == MODE_TRANSPOSED && a.sshift == 0) || (a.mode == MODE_REFLECT && a.pad < a.H && a.pad_w < a.W))) return false;
-    return p.ncb == 2 || (a.KH == 3 && p.tw == 32);
+    // 32-column workgroups: 3x3 on 8 x 32 / 16 x 16 tiles, 5x5 on the 32 x 8 tiles of the 32x40 planes (same box, vs the gather
+    // kernel's 128-row tiles: 64 -> 64 @64x80 127 vs 122 TF, the data gradient of 5x5 256 -> 512 @32x40 176 vs 161; 3x3x256 @32x40
+    // 146 vs 150: not taken)
+    return p.ncb == 2 || (a.KH == 3 && p.tw != 8) || (a.KH == 5 && p.tw == 8);
 }
 static bool x3_halo_eligible(const ConvArgs& a) { HaloPlan p; return x3_halo_plan(a, p); }
 
@@ -456,7 +461,8 @@ static int launch_conv_x3_halo(ConvArgs& a, hipStream_t st) {
             if (a.mode == MODE_REFLECT) hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_REFLECT, KHV, KWV, TWV, NCBV, false>), grid, block, 0, st, a); \
             else hipLaunchKernelGGL((conv_halo_x3_kernel<MODE_TRANSPOSED, KHV, KWV, TWV, NCBV, false>), grid, block, 0, st, a); } } while (0)
     if (p.rowwin) PD_HALO(4, 1, 32, 2, true);
-    else if (p.ncb == 1) PD_HALO(3, 3, 32, 1, false);
+    else if (p.ncb == 1 && a.KH == 3) { if (tw == 32) PD_HALO(3, 3, 32, 1, false); else PD_HALO(3, 3, 16, 1, false); }
+    else if (p.ncb == 1) PD_HALO(5, 5, 8, 1, false);
     else if (a.KH == 3) { if (tw == 32) PD_HALO(3, 3, 32, 2, false); else if (tw == 16) PD_HALO(3, 3, 16, 2, false); else PD_HALO(3, 3, 8, 2, false); }
     else { if (tw == 32) PD_HALO(5, 5, 32, 2, false); else if (tw == 16) PD_HALO(5, 5, 16, 2, false); else PD_HALO(5, 5, 8, 2, false); }
 #undef PD_HALO

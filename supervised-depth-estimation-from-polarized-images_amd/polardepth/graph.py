@@ -65,7 +65,10 @@ class GraphedTrainStep:
         if self.segmented:
             red.deferred = True
         try:
-            with torch.cuda.graph(self.graph):
+            # capture_error_mode: under torch.distributed the process group's watchdog / heartbeat threads query events
+            # while this thread captures; in the default "global" mode such a query invalidates the capture or throws on
+            # THEIR thread (std::terminate: an intermittent SIGABRT of the rank).  Only this thread's calls are policed.
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.outputs, self.losses = self._fwd_bwd()
                 if self.segmented:
                     PF.sync_wgrad_stream()                  # every forked stream rejoins the capture stream

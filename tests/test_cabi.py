@@ -232,6 +232,8 @@ def test_which_shapes_take_the_bf16_split_kernels():
     assert lib.pd_conv2d_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 0, 0, 64, 80, AUTO) == 3   # Wo = 80: 16 x 16 tiles
     assert lib.pd_conv2d_uses_x3(16 * 32 * 40, 512, 256, 5, 5, 1, 2, 0, 0, 0, 32, 40, AUTO) == 3   # 32 x 40: 32 x 8 tiles, 640 workgroups
     assert lib.pd_conv2d_uses_x3(16 * 32 * 40, 256, 256, 3, 3, 1, 1, 0, 0, 0, 32, 40, AUTO) == 1   # ... 80 x 4 = 320 workgroups: the gather kernel's 128-row tiles
+    assert lib.pd_conv2d_uses_x3(16 * 32 * 40, 256, 512, 5, 5, 1, 2, 2, 0, 0, 32, 40, AUTO) == 3   # ... 5x5 there: 640 halo workgroups of 32 columns
+    assert lib.pd_conv2d_uses_x3(16 * 64 * 80, 64, 64, 3, 3, 1, 1, 0, 0, 0, 64, 80, AUTO) == 3     # 64 -> 64 @64x80: 320 -> 640 workgroups of 32 columns
     assert lib.pd_conv2d_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 0, 0, 16, 20, AUTO) == 1   # 16 x 20: no tile shape divides it
     assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 256, 320, AUTO) == 3            # 4x4 space-to-depth stem: the halo kernel's row-window form
     assert lib.pd_conv2d_uses_x3(M16, 64, 36, 4, 4, 1, 2, 0, 0, 0, 256, 320, IM2COL) == 2          # ... or the gather kernel with a partly empty channel group

@@ -23,6 +23,11 @@ def _run(tmp_path, name, **env):
         sk.bind(("127.0.0.1", 0))
         e["MASTER_PORT"] = str(sk.getsockname()[1])
     r = subprocess.run([sys.executable, HELPER, str(out)], env=e, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and os.environ.get("GRAFT_REPO_ROOT"):          # keep the child's whole stderr where gpurun collects it
+        d = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"dp_child_{name}.err"), "w") as f:
+            f.write(r.stderr)
     assert r.returncode == 0, (r.returncode, r.stderr[-6000:])
     return torch.load(out)
 
