@@ -158,7 +158,9 @@ int pd_polar_theta(const void* rho, void* theta_d, void* theta_s1, void* theta_s
 #define PD_CONV_GENERAL_KERNELS 8u
 #define PD_CONV_X3_IM2COL 16u   /* bf16-split forward / data gradient through the per-tap gather kernel (conv_igemm_x3_kernel)
                                  * also where the halo-tile kernel (conv_halo_x3_kernel) fits: A/B measurement and tests */
-#define PD_CONV_FLAGS_ALL 31u
+#define PD_CONV_WGRAD_ROW_WORKGROUPS 32u /* bf16-split 3x3 weight gradient with one filter row per workgroup (conv_wgrad_halo_x3_kernel)
+                                         * also where the rolling-row kernel (conv_wgrad_roll_x3_kernel) fits: A/B measurement and tests */
+#define PD_CONV_FLAGS_ALL 63u
 int pd_conv2d_tile_m(long M, int Cout);
 long pd_conv2d_stats_rows(long M, int Cout);
 /* Non-zero (3: the halo-tile kernel conv_halo_x3_kernel -- 3x3 / 5x5, stride 1, zero padding or the stride-1 data gradient,

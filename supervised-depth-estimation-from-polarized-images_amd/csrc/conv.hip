@@ -2381,6 +2381,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_x3c_kernel(const WgradUniArg
 }
 
 #include "conv_wgrad_halo.hpp"
+#include "conv_wgrad_roll.hpp"
 
 // out[i] (+)= sum_s part[s][i]: 64 columns x 4 slice lanes per workgroup; every lane keeps four independent
 // loads in flight; the lane partials are combined in a fixed order (deterministic).
@@ -2487,7 +2488,7 @@ extern "C" size_t pd_conv2d_wgrad_workspace(long M, int Co, int K, unsigned flag
     wgrad_plan(M, Co, K, flags, &S, &mper);
     // (the halo-tile kernel cuts its own slices; Cout and K bound their number)
     if (wgrad_x3c_enabled(flags) && !(flags & (PD_CONV_GENERAL_KERNELS | PD_CONV_X3_IM2COL))) {
-        const int sh = wgrad_halo_slices_bound(Co, K);
+        const int sh = std::max(wgrad_halo_slices_bound(Co, K), wgrad_roll_slices_bound(Co, K));
         const long cap = (M + 63) / 64;
         S = S > (sh < cap ? sh : (int)cap) ? S : (sh < cap ? sh : (int)cap);
     }
@@ -2514,7 +2515,14 @@ extern "C" int pd_conv2d_wgrad_uses_x3(long M, int Co, int C, int KH, int KW, in
         WgradArgs a{};
         a.mode = mode; a.stride = stride; a.KH = KH; a.KW = KW; a.pad = pad; a.C = C; a.Co = Co; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
         a.ldd = Co; a.sN = (long)H * W * C;
-        if (wgrad_halo_eligible(a, true)) return 2;
+        if (wgrad_halo_eligible(a, true)) {
+            // 3: the rolling-row kernel (all three filter rows per workgroup) -- with the workspace pd_conv2d_wgrad_workspace asks for
+            a.N = (int)(M / ((long)Ho * Wo)); a.M = M; a.K = KH * KW * C;
+            const size_t per_slice = ((size_t)Co * a.K + Co) * sizeof(float);
+            const int s_cap = (int)std::min<size_t>(pd_conv2d_wgrad_workspace(M, Co, a.K, flags) / per_slice, 1 << 20);
+            WgradRollPlan rp;
+            return !(flags & PD_CONV_WGRAD_ROW_WORKGROUPS) && wgrad_roll_eligible(a, true, s_cap, rp) ? 3 : 2;
+        }
     }
     return x3c;
 }
@@ -2552,7 +2560,11 @@ extern "C" int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* db
     if (wgrad_x3c_enabled(flags) && !(flags & (PD_CONV_GENERAL_KERNELS | PD_CONV_X3_IM2COL)) && wgrad_halo_eligible(a, vec)) {
         // halo-tile kernel: its slice count never exceeds what the workspace holds
         const size_t per_slice = ((size_t)Co * a.K + Co) * sizeof(float);
-        const int S = launch_wgrad_halo(a, (int)std::min<size_t>(ws_bytes / per_slice, 1 << 20), st, dbias != nullptr);
+        const int s_cap = (int)std::min<size_t>(ws_bytes / per_slice, 1 << 20);
+        WgradRollPlan rp;
+        // 3x3 with long tile columns: all three filter rows per workgroup, input rows rolling through LDS
+        const int S = !(flags & PD_CONV_WGRAD_ROW_WORKGROUPS) && wgrad_roll_eligible(a, vec, s_cap, rp) ? launch_wgrad_roll(a, rp, st, dbias != nullptr)
+                                                                                             : launch_wgrad_halo(a, s_cap, st, dbias != nullptr);
         a.bpart = dbias ? a.part + (size_t)S * Co * a.K : nullptr;
         int rc = pd::check_launch("pd_conv2d_wgrad");
         if (rc) return rc;

@@ -19,12 +19,15 @@ PROFILE = None      # bench.py sets this to a list: (kernel label, algorithmic f
 # The library reads no environment variable; this module owns the knobs and reads them ONCE, at import:
 #   PD_CONV_X3=0    forward / data gradient on the fp32 MFMA only      PD_WGRAD_X3C=0   weight gradients likewise
 #   PD_CONV_HALO=0  bf16-split forward / data gradient through conv_igemm_x3_kernel also where the halo-tile kernel fits
+#   PD_WGRAD_ROLL=0 3x3 weight gradients with one filter row per workgroup also where the rolling-row kernel fits
 # Tests and bench.py switch families in-process by assigning CONV_FLAGS / WGRAD_FLAGS (or `with conv_flags(...)`).
 CONV_AUTO, CONV_FP32_MFMA, CONV_BF16X3, CONV_WGRAD_SPLIT_IN_REGS, CONV_GENERAL_KERNELS, CONV_X3_IM2COL = 0, 1, 2, 4, 8, 16
+CONV_WGRAD_ROW_WORKGROUPS = 32        # one filter row per workgroup also where the rolling-row weight-gradient kernel fits (A/B, tests)
 CONV_FLAGS = (CONV_FP32_MFMA if os.environ.get("PD_CONV_X3", "1") == "0" else       # pd_conv2d, _add, _rect
               CONV_X3_IM2COL if os.environ.get("PD_CONV_HALO", "1") == "0" else CONV_AUTO)   # PD_CONV_HALO=0: the per-tap gather kernel everywhere
 WGRAD_FLAGS = (CONV_FP32_MFMA if os.environ.get("PD_WGRAD_X3C", "1") == "0" else     # pd_conv2d_wgrad
-               CONV_X3_IM2COL if os.environ.get("PD_CONV_HALO", "1") == "0" else CONV_AUTO)
+               CONV_X3_IM2COL if os.environ.get("PD_CONV_HALO", "1") == "0" else
+               CONV_WGRAD_ROW_WORKGROUPS if os.environ.get("PD_WGRAD_ROLL", "1") == "0" else CONV_AUTO)   # PD_WGRAD_ROLL=0: one filter row per workgroup
 
 
 class conv_flags:
@@ -287,7 +290,7 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, mode=MODE_ZERO, affine=None, d
     sN, sC, sH, sW = x.stride()
     x3c = (lib.pd_conv2d_wgrad_uses_x3(M, Co, C, KH, KW, stride, pad, mode, H, W, Ho, Wo, WGRAD_FLAGS)
            if (affine is None and sC == 1 and sN % 4 == 0 and sH % 4 == 0 and sW % 4 == 0 and dy.stride(3) % 4 == 0) else 0)
-    _profiled("conv_wgrad_halo_x3_kernel" if x3c == 2 else "conv_wgrad_x3c_kernel" if x3c else "conv_wgrad_kernel",
+    _profiled("conv_wgrad_roll_x3_kernel" if x3c == 3 else "conv_wgrad_halo_x3_kernel" if x3c == 2 else "conv_wgrad_x3c_kernel" if x3c else "conv_wgrad_kernel",
               2.0 * M * Co * (alg_k if alg_k is not None else K),
               lambda: check(lib.pd_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), ws.numel(), N, H, W, C,
                                                 sN, sH, sW, sC, Ho, Wo, Co, KH, KW, stride, pad, mode,

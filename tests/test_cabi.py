@@ -194,7 +194,7 @@ def test_which_shapes_take_the_bf16_split_kernels():
     """pd_conv2d_uses_x3 / pd_conv2d_wgrad_uses_x3 (host logic, no GPU): the routing rule the profiler labels, bench.py's
     roofline object and the production-size tests rely on.  Arguments: M, Cout, C, KH, KW, stride, pad, mode, act, scale."""
     lib = _lib.lib
-    AUTO, FP32, X3, REGS, GEN, IM2COL = 0, 1, 2, 4, 8, 16     # PD_CONV_* flags (include/polardepth.h), the last argument of every query
+    AUTO, FP32, X3, REGS, GEN, IM2COL, ROWWG = 0, 1, 2, 4, 8, 16, 32     # PD_CONV_* flags (include/polardepth.h), the last argument of every query
     M16 = 16 * 256 * 320
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 0, 0, 0, 0, AUTO) == 2            # encoder 5x5 at batch 16: 256-row tiles
     assert lib.pd_conv2d_uses_x3(M16, 64, 64, 3, 3, 1, 1, 2, 0, 0, 0, 0, AUTO) == 2            # its stride-1 data gradient
@@ -212,12 +212,16 @@ def test_which_shapes_take_the_bf16_split_kernels():
     assert lib.pd_conv2d_uses_x3(4 * M16, 64, 128, 3, 3, 2, 1, 2, 0, 0, 0, 0, AUTO) == 0       # stride-2 data gradient (parity launches)
     assert lib.pd_conv2d_uses_x3(M16 // 4, 128, 64, 3, 3, 2, 1, 0, 0, 0, 0, 0, AUTO) == 2      # stride-2 forward
     # M, Cout, C, KH, KW, stride, pad, mode, H, W, Ho, Wo
-    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 2          # halo-tile kernel (transposed LDS reads)
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 3          # rolling-row kernel: 3 filter rows per workgroup, 160 columns x 3 slices
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, ROWWG) == 2         # ... or one filter row per workgroup (halo-tile kernel, transposed LDS reads)
+    assert lib.pd_conv2d_wgrad_uses_x3(M16 // 8, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 2     # two images: 20 columns, slices too short to roll
+    assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 5, 5, 1, 2, 0, 256, 320, 256, 320, AUTO) == 2          # 5x5: 25 accumulator tiles do not fit
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, IM2COL) == 1        # ... unless the caller asks for the gather kernel
     assert lib.pd_conv2d_wgrad_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 64, 80, 64, 80, AUTO) == 2   # Wo = 80: 4 x 16 tiles
     assert lib.pd_conv2d_wgrad_uses_x3(16 * 32 * 40, 256, 256, 3, 3, 1, 1, 0, 32, 40, 32, 40, AUTO) == 2   # 8 x 8 tiles
     assert lib.pd_conv2d_wgrad_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 16, 20, 16, 20, AUTO) == 1   # Wo = 20: the gather kernel
-    assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 2   # decoder: ReflectionPad2d(1) + Conv3x3 (mirrored strip)
+    assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 3   # decoder: ReflectionPad2d(1) + Conv3x3 (mirrored rows / columns), 80 columns x 3 slices
+    assert lib.pd_conv2d_wgrad_uses_x3(M16 // 16, 128, 256, 3, 3, 1, 1, 1, 64, 80, 64, 80, AUTO) == 2    # ... 256 -> 128 @64x80: 80 columns > 64 slices: one filter row per workgroup
     assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 96, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 1    # ... 96 input channels: the gather kernel
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 5, 5, 1, 2, 1, 256, 320, 256, 320, AUTO) == 0       # reflect 5x5: general kernel
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 32, 96, 3, 3, 1, 1, 0, 256, 320, 256, 320, AUTO) == 2       # 32 output channels: the halo kernel's 32-channel workgroups
@@ -258,7 +262,7 @@ def test_conv_flags_are_validated():
     """Unknown bits, or fp32-MFMA and bf16-split requested together: PD_EINVAL before anything is launched (null tensors
     would be the next complaint)."""
     lib = _lib.lib
-    for bad in (32, 1 | 2, 0x80000000):
+    for bad in (64, 1 | 2, 0x80000000):
         rc = lib.pd_conv2d(8, 8, None, None, 8, None, 1, 4, 4, 4, 64, 16, 4, 1, 4, 4, 4, 1, 1, 1, 0, 0, 0, 0, 0.0, 1.0, 4, bad, None)
         assert rc == -22 and b"flags" in lib.pd_last_error(), bad
         rc = lib.pd_conv2d_wgrad(8, 8, 8, None, 8, 1 << 20, 1, 4, 4, 4, 64, 16, 4, 1, 4, 4, 4, 1, 1, 1, 0, 0, 0, 0.0, 1.0, 4, 0, bad, None)

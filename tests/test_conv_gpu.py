@@ -563,6 +563,33 @@ def test_bf16x3_kernel_reflection_padding_bias_elu(case, monkeypatch):
     assert dwe["1"] <= 2e-5 and dwe["1"] <= 1.5 * dwe["0"] + 2e-7, dwe
 
 
+@pytest.mark.parametrize("case", [(4, 64, 256, 320, 64, ops.MODE_ZERO), (8, 128, 128, 160, 64, ops.MODE_REFLECT), (32, 64, 128, 48, 128, ops.MODE_ZERO)])
+def test_rolling_row_weight_gradient(case, monkeypatch):
+    """conv_wgrad_roll_x3_kernel: all three filter rows of a 3x3 weight gradient in one workgroup, the input row groups rolling
+    through a ring in LDS (1 x 32 tiles; 2 x 16 tiles for Wo = 48; zero and reflection padding; bias): vs an fp64 reference,
+    next to the one-filter-row-per-workgroup kernel and the fp32-MFMA kernel on the same input."""
+    N, C, H, W, Co, mode = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g)
+    x[:, :, :3] *= 5.0                                       # (first / last rows and columns carry weight: the padding matters)
+    x[:, :, :, -2:] *= 3.0
+    dy = torch.randn(N, Co, H, W, generator=g)
+    wv = torch.zeros(Co, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    xp = F.pad(x.double(), (1, 1, 1, 1), mode="reflect" if mode == ops.MODE_REFLECT else "constant")
+    ref_dw = torch.autograd.grad(F.conv2d(xp, wv), wv, dy.double())[0]
+    ref_db = dy.double().sum((0, 2, 3))
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    err = {}
+    for name, fl, code in (("roll", ops.CONV_AUTO, 3), ("rows", ops.CONV_WGRAD_ROW_WORKGROUPS, 2), ("fp32", ops.CONV_FP32_MFMA, 0)):
+        monkeypatch.setattr(ops, "WGRAD_FLAGS", fl)
+        assert ops.lib.pd_conv2d_wgrad_uses_x3(N * H * W, Co, C, 3, 3, 1, 1, mode, H, W, H, W, fl) == code
+        dw, db = ops.conv2d_wgrad(xd, dyd, (Co, C, 3, 3), stride=1, pad=1, mode=mode, want_bias=True)
+        err[name] = (dw.cpu().double() - ref_dw).abs().max().item() / ref_dw.abs().max().item()
+        assert (db.cpu().double() - ref_db).abs().max().item() / ref_db.abs().max().item() <= 2e-5
+    assert err["roll"] <= 2e-5 and err["roll"] <= 1.5 * err["fp32"] + 2e-7 and err["rows"] <= 1.5 * err["fp32"] + 2e-7, err
+
+
 # ------------------------------------------------------------------ the bf16-split kernels on inputs that are not `randn`
 def _field(mask_shape, n, h, w, k):
     """Boolean [N,1,H,W] mask of the output pixels whose k x k window (pad k//2, stride 1) contains input pixel (n, h, w)."""

@@ -28,6 +28,8 @@ def short(name):
         return f"conv_igemm_x3_kernel<{128 * int(m.group(1))},64>"
     if name.startswith("conv_halo_x3_kernel"):       # halo-tile forward / data gradient: one label (bench.py)
         return "conv_halo_x3_kernel<8x32,64>"
+    if name.startswith("conv_wgrad_roll_x3"):
+        return "conv_wgrad_roll_x3_kernel"
     if name.startswith("conv_wgrad_halo_x3"):
         return "conv_wgrad_halo_x3_kernel"
     if name.startswith("conv_wgrad_x3c"):
