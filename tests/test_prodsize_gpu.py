@@ -82,9 +82,11 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
         want = 0
         if x3 == "1" and Cox % 64 == 0 and Cx % 4 == 0 and -(-Cx // 16) * 16 <= 2 * Cx:
             want = 2 if (Mx % 256 == 0 and (Mx // 256) * (Cox // 64) >= 512) else 1 if (Mx % 128 == 0 and (Mx // 128) * (Cox // 64) >= 320) else 0
-            tiles = (wo % 32 == 0 and ho % 8 == 0) or (wo % 16 == 0 and ho % 16 == 0) or (wo % 8 == 0 and ho % 32 == 0)
-            if want and k in (3, 5) and sx == 1 and Cx % 16 == 0 and tiles and Mx >= 65536 and (Mx // 256) * (Cox // 64) >= 512:
-                want = 3                               # the halo-tile kernel
+            tw = 32 if (wo % 32 == 0 and ho % 8 == 0) else 16 if (wo % 16 == 0 and ho % 16 == 0) else 8 if (wo % 8 == 0 and ho % 32 == 0) else 0
+            # the halo-tile kernel: 64-column workgroups where they are >= 512, else 32-column ones (3x3 off the 32 x 8 tiles; 5x5 on them)
+            if k in (3, 5) and sx == 1 and Cx % 16 == 0 and tw and Mx >= 65536:
+                if (Mx // 256) * (Cox // 64) >= 512 or ((Mx // 256) * (Cox // 32) >= 512 and ((k == 3 and tw != 8) or (k == 5 and tw == 8))):
+                    want = 3
         assert rb == want, (rb, want)
         return ["conv_halo_x3_kernel<8x32,64>" if rb == 3 else f"conv_igemm_x3_kernel<{128 * rb},64>" if rb else "conv_igemm_uni_kernel<128,64>"]
 
@@ -162,7 +164,7 @@ def test_production_tile_reflection_padded_conv(case, x3, monkeypatch):
         return y
     y, lab = _labels(run)
     # (forward on the REFLECT instantiation; the pad-1 data gradient is a zero-padding launch: fp32 or bf16-split kernel)
-    assert sum(l.startswith(("conv_igemm_uni_kernel<128,64>", "conv_igemm_x3_kernel", "conv_halo_x3_kernel")) for l in lab) == 2 and (({"conv_wgrad_x3c_kernel", "conv_wgrad_halo_x3_kernel"} & set(lab)) if x3 == "1" else "conv_wgrad_kernel" in lab), lab
+    assert sum(l.startswith(("conv_igemm_uni_kernel<128,64>", "conv_igemm_x3_kernel", "conv_halo_x3_kernel")) for l in lab) == 2 and (({"conv_wgrad_x3c_kernel", "conv_wgrad_halo_x3_kernel", "conv_wgrad_roll_x3_kernel"} & set(lab)) if x3 == "1" else "conv_wgrad_kernel" in lab), lab
     _close(y.detach().cpu(), ref.detach(), 3e-5, "fwd")
     _close(xc.grad.cpu(), xr.grad, 3e-5, "dgrad")
     _close(conv.weight.grad.cpu(), wr.grad, 3e-5, "wgrad")
@@ -334,7 +336,8 @@ def test_full_resolution_training_step_matches_oracle(B, tmp_path, monkeypatch):
         assert n_prod >= 30, f"production tiles not exercised: {n_prod}"
         assert any(l.startswith(("conv_igemm_x3_kernel", "conv_halo_x3_kernel")) for l in lab) == (knob == "1")
         if B == 16 and knob == "1":          # the launch labels of bench.py's step: both split tile sizes and the split weight gradient
-            assert {"conv_halo_x3_kernel<8x32,64>", "conv_igemm_x3_kernel<256,64>", "conv_igemm_x3_kernel<128,64>", "conv_wgrad_x3c_kernel", "conv_wgrad_halo_x3_kernel"} <= set(lab), sorted(set(lab))
+            assert {"conv_halo_x3_kernel<8x32,64>", "conv_igemm_x3_kernel<128,64>", "conv_wgrad_x3c_kernel", "conv_wgrad_halo_x3_kernel",
+                    "conv_wgrad_roll_x3_kernel"} <= set(lab), sorted(set(lab))
         gpu_grads = {f"{mn}.{k}": v.grad.detach().cpu().clone() for mn in tr.models for k, v in tr.models[mn].named_parameters()
                      if v.grad is not None}
         for s in range(4):
