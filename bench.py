@@ -456,11 +456,13 @@ def main():
                                     "GBps": round(k1_bytes / k1_ms / 1e6, 1), "frac": round(k1_bytes / k1_ms / 1e6 / 8000.0, 4),
                                     "cache_resident_GBps": round(k1_bytes / k1_ms_warm / 1e6, 1)},
                    "batch_128": k1_big,
-                   "streaming_ceiling_note": "same access shape with trivial compute at this size (B=16, 240 MB, after a "
-                                             "cache-replacing predecessor, i.e. the state the step leaves behind): 43-50 us = "
-                                             "4.8-5.6 TB/s for the best read schedule (tools/membench3.hip, "
-                                             "profiles/r03_membench3_read_schedules.log); the kernel's own issue phase ends "
-                                             "after ~36 us, the rest is launch + HBM write drain (profiles/r03_k1_timeline.log)"}
+                   "streaming_ceiling_note": "K1's byte mix (4 B in, 44 B out per pixel as eleven planar fp32 planes, nontemporal "
+                                             "stores) with TRIVIAL compute streams at 5.3-5.7 TB/s at B=128 and takes 37-41 us at B=16 "
+                                             "back to back on this pool; a float4 copy 5.3-5.9, pure reads 6.1-6.3, pure nontemporal "
+                                             "writes 4.8-5.8 TB/s; every other layout of the 48 B/px (float3 planes, 36 B / 44 B records) "
+                                             "0.4-3.4 TB/s (tools/membench5.hip, profiles/r04_membench5_k1_ceiling.log).  At B=16 the "
+                                             "kernel's issue phase ends after ~36 us; the rest is launch, table prologue and HBM write "
+                                             "drain (profiles/r03_k1_timeline.log)"}
     del pols, k1_outs
 
     attention = None
@@ -507,15 +509,18 @@ def main():
         "eager": eager, "graph": graph_info,
         "roofline": roofline, "xolp_kernel": xolp_kernel,
         "precision": {"accumulate": "f32",
-                      "conv_products": "fp32 MFMA; the 64-column layers with >= 512 tiles (forward with zero or 3x3 reflection padding, "
-                                       "stride-1 data gradient) and the weight gradients with >= 33 output channels form each fp32 product from a "
-                                       "three-way bf16 split of both operands (six bf16 MFMAs, dropped terms <= 2^-23 of the "
-                                       "product)" if _ops.CONV_FLAGS == _ops.CONV_AUTO else "fp32 MFMA",
-                      "evidence": "tests/test_conv_gpu.py::test_bf16x3_kernel_keeps_fp32_accuracy (forward / data gradient error vs an fp64 "
-                                  "convolution <= 1.5x the fp32-MFMA kernel's on the same input; weight gradient <= 3x: the bf16 MFMA's "
-                                  "truncation bias grows with the slice length) and tests/test_prodsize_gpu.py::"
-                                  "test_full_resolution_training_step_matches_oracle (512x640 step vs the fp32 and fp64 oracle: disparities "
-                                  "2e-5, losses 1e-4, every gradient tensor within 2x the fp32 oracle's own distance from fp64)",
+                      "conv_products": "fp32 MFMA; the layers with >= 32 output channels and enough tiles to fill the chip (forward with zero "
+                                       "or 3x3 reflection padding, stride-1 data gradient, the 4x4 space-to-depth stems, weight gradients) form "
+                                       "each fp32 product from a three-way bf16 split of both operands (six bf16 MFMAs, dropped terms <= 2^-23 "
+                                       "of the product; odd tiles / slices accumulate the negated result so that the bf16 MFMA's truncation "
+                                       "bias cancels in sums)" if _ops.CONV_FLAGS == _ops.CONV_AUTO else "fp32 MFMA",
+                      "evidence": "tests/test_conv_gpu.py::test_bf16x3_kernel_keeps_fp32_accuracy, test_rolling_row_weight_gradient, "
+                                  "test_row_window_form_of_the_space_to_depth_stems (forward / data gradient / weight gradient error vs an "
+                                  "fp64 convolution <= 1.5x the fp32-MFMA kernel's on the same input), test_bf16x3_kernels_nonfinite_and_"
+                                  "extreme_inputs, _denormal_range, _cancellation_heavy_contraction, and tests/test_prodsize_gpu.py::"
+                                  "test_full_resolution_training_step_matches_oracle at B = 4 and B = 16 (512x640 step vs the fp32 and fp64 "
+                                  "oracle: disparities 2e-5, losses 1e-4, every gradient tensor within 2x the fp32 oracle's own distance "
+                                  "from fp64)",
                       "fp32_mfma_only": fp32_only},
     }
     if dp_info is not None:

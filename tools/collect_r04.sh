@@ -22,9 +22,12 @@ python3 $R/tools/profile_layers.py > $O/r04_conv_layers.log 2>&1 || exit 4
 cd $R
 OP=fwd KS=5 bash tools/sq_prof_k.sh conv_halo_x3 halo_run.py > $O/r04_halo_fwd5_sq_counters.txt 2>&1
 OP=fwd KS=3 bash tools/sq_prof_k.sh conv_halo_x3 halo_run.py > $O/r04_halo_fwd3_sq_counters.txt 2>&1
-OP=wgrad KS=3 bash tools/sq_prof_k.sh conv_wgrad_halo_x3 halo_run.py > $O/r04_wgrad_halo3_sq_counters.txt 2>&1
+OP=wgrad KS=3 bash tools/sq_prof_k.sh conv_wgrad_roll_x3 halo_run.py > $O/r04_wgrad_roll3_sq_counters.txt 2>&1
+PD_WGRAD_ROLL=0 OP=wgrad KS=3 bash tools/sq_prof_k.sh conv_wgrad_halo_x3 halo_run.py > $O/r04_wgrad_halo3_sq_counters.txt 2>&1
 OP=wgrad KS=5 bash tools/sq_prof_k.sh conv_wgrad_halo_x3 halo_run.py > $O/r04_wgrad_halo5_sq_counters.txt 2>&1
 python3 tools/bench_polar.py --quick > $O/r04_polar_kernel_gbps.log 2>&1
 bash tools/k1_variants.sh > $O/r04_polar_kernel_nt_loads.log 2>&1
 tools/halo_ab.sh $O/r04_halo_vs_gather_layers.log
+tools/tail_ab.sh $O/r04_conv_tail_layers.log
+tools/ab_roll.sh > $O/r04_wgrad_roll_vs_rows.log 2>&1
 echo done b
