@@ -23,9 +23,9 @@
 // the upper 32-channel block of the last 64-channel input block may be empty (its wave idles, its loads are masked).
 namespace wgh {
 constexpr int NPX = 32;                                                  // pixels per tile: TR rows x TW columns, 2 MFMA k-steps
-// TW = 32 | 16 | 8 (the widest that divides Wo): 1 x 32, 2 x 16 or 4 x 8 pixel tiles -- a 16-pixel step is then half a row,
-// a row or two rows; either way the step's pixels are the tile's row-major pixels 16 ks .. 16 ks + 15, in runs of four
-// consecutive columns (what one transposed read takes).
+// TW = 32 | 16 | 8 | 4 (the widest that divides Wo): 1 x 32, 2 x 16, 4 x 8 or 8 x 4 pixel tiles -- a 16-pixel step is then half a
+// row, a row, two or four rows; either way the step's pixels are the tile's row-major pixels 16 ks .. 16 ks + 15, in runs of four
+// consecutive columns (what one transposed read takes).  (8 x 4: the 16x20 planes of the 512-channel layers.)
 template <int KS, int TW, bool CO32> struct Geo {
     static constexpr int TR = NPX / TW;
     static constexpr int HW = TW + KS - 1;                               // X columns per tile row
@@ -171,9 +171,11 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
     const int fh = lane >> 5, gq = (lane >> 4) & 1, fq = (lane & 15) >> 2, fp = lane & 3;
     lds_char* const lds_a = (lds_char*)lds_c + (unsigned)(((w_cob * NPX + 16 * w_ks + 8 * fh + fq) * 64) + 32 * gq + 8 * fp);
     // X strip (row-major, HW columns): pixel 8 fh + 4 e + q of step ks sits at (row0(ks) + hrow, col0(ks) + hcol + 4 e + q + kw)
-    constexpr int HROW = TW >= 16 ? 0 : 1, HCOL = TW >= 16 ? 8 : 0;        // the upper half-wave: 8 columns on (TW >= 16) or the next row (TW = 8)
+    // the upper half-wave (pixels 8 .. 15 of a step): 8 columns on (TW >= 16), the next row (TW = 8) or two rows down (TW = 4);
+    // a lane's second run of four pixels: 4 columns on, or (TW = 4) the next row
+    constexpr int HROW = TW >= 16 ? 0 : TW == 8 ? 1 : 2, HCOL = TW >= 16 ? 8 : 0, RUN2 = TW == 4 ? HW : 4;
     // (CO32: the wave's own step w_ks -- row / column origin of its 16 pixels -- is part of the base)
-    const int ks_row = TW == 32 ? 0 : TW == 16 ? w_ks : 2 * w_ks, ks_col = TW == 32 ? 16 * w_ks : 0;
+    const int ks_row = TW == 32 ? 0 : TW == 16 ? w_ks : TW == 8 ? 2 * w_ks : 4 * w_ks, ks_col = TW == 32 ? 16 * w_ks : 0;
     lds_char* const lds_b = (lds_char*)lds_c + (DP_BYTES + (unsigned)(((w_cib * XPX + ks_row * HW + ks_col + fh * (HROW * HW + HCOL) + fq) * 64) + 32 * gq + 8 * fp));
 
     typedef float accv_t __attribute__((ext_vector_type(16)));
@@ -212,9 +214,9 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
             for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
                 for (int tm = 0; tm < 3; ++tm) {
-                    const int row0 = TW == 32 ? 0 : TW == 16 ? ks : 2 * ks, col0 = TW == 32 ? 16 * ks : 0;
+                    const int row0 = TW == 32 ? 0 : TW == 16 ? ks : TW == 8 ? 2 * ks : 4 * ks, col0 = TW == 32 ? 16 * ks : 0;
                     const unsigned o = BUF * BUF_BYTES + (unsigned)(tm * 2 * XPX * 64 + (row0 * HW + col0 + kw) * 64);
-                    fb[kw][tm] = bf(tr_read(lds_b, o), tr_read(lds_b, o + 4 * 64));
+                    fb[kw][tm] = bf(tr_read(lds_b, o), tr_read(lds_b, o + RUN2 * 64));
                 }
             // products largest first, the taps interleaved so that consecutive MFMAs never share an accumulator; one item of
             // the next tile behind every second group of KS MFMAs
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(NT, KS == 3 ? 3 : 2) void conv_wgrad_halo_x3_kernel
 
 // tile width: the widest of 32 | 16 | 8 whose 32-pixel tile (1 | 2 | 4 rows) divides the output grid; 0: none
 static int wgrad_halo_tw(int Ho, int Wo) {
-    return Wo % 32 == 0 ? 32 : (Wo % 16 == 0 && Ho % 2 == 0) ? 16 : (Wo % 8 == 0 && Ho % 4 == 0) ? 8 : 0;
+    return Wo % 32 == 0 ? 32 : (Wo % 16 == 0 && Ho % 2 == 0) ? 16 : (Wo % 8 == 0 && Ho % 4 == 0) ? 8 : (Wo % 4 == 0 && Ho % 8 == 0) ? 4 : 0;
 }
 static bool wgrad_halo_co32(const WgradArgs& a) { return a.Co % 64 != 0; }
 static bool wgrad_halo_eligible(const WgradArgs& a, bool vec) {
@@ -292,7 +294,7 @@ static bool wgrad_halo_eligible(const WgradArgs& a, bool vec) {
           (a.KH == 3 || a.KH == 5) && a.pad < a.KH && wgrad_halo_tw(a.Ho, a.Wo) != 0 && a.ldd % 4 == 0 &&
           (long)a.sN * 4 < 0x7fffffffL && (8L * a.Wo + 32) * a.ldd * 4 < 0x7fffffffL && a.Ho <= a.H + 2 * a.pad - a.KH + 1))
         return false;
-    if (a.Co % 64 == 0) return a.C % 64 == 0;
+    if (a.Co % 64 == 0) return a.C % 64 == 0 && (wgrad_halo_tw(a.Ho, a.Wo) != 4 || a.KH == 3);       // (8 x 4 tiles: 3x3 only)
     // 32 output channels per workgroup: 3x3 on 1 x 32 tiles, whole 32-channel input blocks
     return a.Co % 32 == 0 && a.C % 32 == 0 && a.KH == 3 && wgrad_halo_tw(a.Ho, a.Wo) == 32;
 }
@@ -339,7 +341,7 @@ static int launch_wgrad_halo(WgradArgs a, int s_cap, hipStream_t st, bool bias) 
 #define PD_WGH(KSV, TWV, C32) do { if (bias) hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<KSV, TWV, true, C32>), grid, block, 0, st, ha); \
                                 else hipLaunchKernelGGL((conv_wgrad_halo_x3_kernel<KSV, TWV, false, C32>), grid, block, 0, st, ha); } while (0)
     if (co32) PD_WGH(3, 32, true);
-    else if (a.KH == 3) { if (tw == 32) PD_WGH(3, 32, false); else if (tw == 16) PD_WGH(3, 16, false); else PD_WGH(3, 8, false); }
+    else if (a.KH == 3) { if (tw == 32) PD_WGH(3, 32, false); else if (tw == 16) PD_WGH(3, 16, false); else if (tw == 8) PD_WGH(3, 8, false); else PD_WGH(3, 4, false); }
     else { if (tw == 32) PD_WGH(5, 32, false); else if (tw == 16) PD_WGH(5, 16, false); else PD_WGH(5, 8, false); }
 #undef PD_WGH
     return S * rows_per_slice;

@@ -219,7 +219,9 @@ def test_which_shapes_take_the_bf16_split_kernels():
     assert lib.pd_conv2d_wgrad_uses_x3(M16, 64, 64, 3, 3, 1, 1, 0, 256, 320, 256, 320, IM2COL) == 1        # ... unless the caller asks for the gather kernel
     assert lib.pd_conv2d_wgrad_uses_x3(16 * 64 * 80, 128, 128, 3, 3, 1, 1, 0, 64, 80, 64, 80, AUTO) == 2   # Wo = 80: 4 x 16 tiles
     assert lib.pd_conv2d_wgrad_uses_x3(16 * 32 * 40, 256, 256, 3, 3, 1, 1, 0, 32, 40, 32, 40, AUTO) == 2   # 8 x 8 tiles
-    assert lib.pd_conv2d_wgrad_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 16, 20, 16, 20, AUTO) == 1   # Wo = 20: the gather kernel
+    assert lib.pd_conv2d_wgrad_uses_x3(16 * 16 * 20, 512, 512, 3, 3, 1, 1, 0, 16, 20, 16, 20, AUTO) == 2   # Wo = 20: 8 x 4 tiles
+    assert lib.pd_conv2d_wgrad_uses_x3(16 * 16 * 20, 512, 512, 5, 5, 1, 2, 0, 16, 20, 16, 20, AUTO) == 1   # ... 3x3 only: the gather kernel
+    assert lib.pd_conv2d_wgrad_uses_x3(16 * 18 * 22, 512, 512, 3, 3, 1, 1, 0, 18, 22, 18, 22, AUTO) == 1   # Wo = 22: no tile shape
     assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 128, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 3   # decoder: ReflectionPad2d(1) + Conv3x3 (mirrored rows / columns), 80 columns x 3 slices
     assert lib.pd_conv2d_wgrad_uses_x3(M16 // 16, 128, 256, 3, 3, 1, 1, 1, 64, 80, 64, 80, AUTO) == 2    # ... 256 -> 128 @64x80: 80 columns > 64 slices: one filter row per workgroup
     assert lib.pd_conv2d_wgrad_uses_x3(M16 // 4, 64, 96, 3, 3, 1, 1, 1, 128, 160, 128, 160, AUTO) == 1    # ... 96 input channels: the gather kernel

@@ -432,6 +432,7 @@ X3_CASES = [
     (2, 96, 256, 320, 32, 3, 1, 1),        # 32 output channels (decoder 96 -> 32): the halo kernel's 32-column workgroups;
                                            # its data gradient has 96 output columns = three of them
     (8, 64, 128, 160, 32, 3, 1, 1),        # ... 64 -> 32 @128x160
+    (16, 128, 16, 20, 128, 3, 1, 1),       # a 16x20 plane (the 512-channel layers): weight gradient on 8 x 4 pixel tiles
     (8, 64, 32, 40, 512, 5, 1, 2),         # 5x5 on a 32x40 plane, 320 tiles of 64 columns: 640 halo workgroups of 32 columns (32 x 8 tiles)
 ]
 
