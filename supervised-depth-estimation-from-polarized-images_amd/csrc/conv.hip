@@ -62,6 +62,7 @@ struct ConvArgs {
     unsigned mg_hw, sh_hw, mg_wo, sh_wo;   // n / (Ho*Wo) and n / Wo as mulhi + shift (n < 2^31), see magic_div()
     unsigned flags;          // PD_CONV_* kernel-family selection of the caller (include/polardepth.h)
     int stats_rows;          // output rows per row of `stats` = pd_conv2d_tile_m(M, Co): the one rule host and kernels share
+    int nmajor;              // bf16-split kernels: consecutive workgroups (one XCD's L2) walk the row tiles of ONE column tile
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -849,28 +850,28 @@ template <int P, bool W = false> __device__ __forceinline__ void sp_l(Terms& t) 
 
 // RB = row blocks (of 32) per wave: 2 -> 256-row tiles (52 KB of LDS, three workgroups per CU); 1 -> 128-row tiles (36 KB,
 // four per CU) for the layers whose 256-row tiles would not fill the chip twice.
-// KSPL = 2 (round 4, the 512-channel layers on 16x20 planes: 320 tiles, K = 4608): EIGHT waves per workgroup -- two sets of four,
-// each a complete copy of the pipeline below on its own half of LDS, taking every other 16-channel group; set 1 hands its
-// accumulators to set 0 through LDS at the end.  Same tiles, twice the waves per CU for the latency of a long, thin contraction.
-template <int MODE, int RB = 2, int KSPL = 1>
-__global__ __launch_bounds__(NT * KSPL, KSPL == 2 ? 2 : RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(const ConvArgs a) {
+// (Round 4, measured and dropped: EIGHT waves per workgroup -- two sets of four, each a complete copy of the pipeline on its own
+//  half of LDS, taking every other 16-channel group and meeting in LDS at the end -- for the 320-tile 3x3x512 @16x20 layers:
+//  no change, 113 TF either way; the two sets wait at the same barriers for the same loads.  What those layers lacked was L2
+//  locality: x3_nmajor below.)
+template <int MODE, int RB = 2>
+__global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(const ConvArgs a) {
     using namespace x3;
     constexpr int BM = 128 * RB;
     constexpr unsigned A_BYTES = BM * CK * 4, BS_BASE = 2 * A_BYTES, BP_BASE = BS_BASE + 2 * BS_BYTES;
     constexpr unsigned LDS_BYTES = BP_BASE + 2 * 3 * BP_BYTES;
-    __shared__ __attribute__((aligned(16))) float smem_both[KSPL * LDS_BYTES / 4];
-    const int kset = KSPL == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);     // (uniform) wave set 0 | 1
-    float* const smem_all = smem_both + kset * (LDS_BYTES / 4);
+    __shared__ __attribute__((aligned(16))) float smem_all[LDS_BYTES / 4];
 
     const int nblk = a.mtiles * a.ntiles;
     const int per_xcd = (int)gridDim.x >> 3;
     const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (logical >= nblk) return;
-    const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
+    // (a.nmajor: column tile outside -- an XCD then streams one 64-column slice of a multi-megabyte filter instead of all of them)
+    const int mt = a.nmajor ? logical % a.mtiles : logical / a.ntiles, nt = a.nmajor ? logical / a.mtiles : logical - mt * a.ntiles;
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
 
-    const int tid = threadIdx.x & (NT - 1);
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hw = a.Ho * a.Wo;
@@ -935,7 +936,7 @@ __global__ __launch_bounds__(NT * KSPL, KSPL == 2 ? 2 : RB == 2 ? 3 : 4) void co
     // (a channel count that is no multiple of 16 -- the space-to-depth stems: 8, 12, 36 -- gets a last, partly empty channel
     //  group: the lanes whose 16-byte slot lies beyond C fetch nothing)
     const int ngroups = (a.C + CK - 1) / CK;
-    const int nchunks = ngroups / KSPL * a.KH * a.KW;               // (KSPL = 2: an even number of whole groups, the host checks)
+    const int nchunks = ngroups * a.KH * a.KW;
     const int c_lim = a.C - 4 * ((lane & 3) ^ ((lane >> 4) & 3));      // this lane's slot is valid while s_c < c_lim
     // Chunk order: the 16-channel group is the OUTER loop, the taps the inner one.  With the taps outside (the order of
     // the fp32 kernels) every input row is fetched once per filter row: the workgroups resident on an XCD hold ~25 000
@@ -944,10 +945,10 @@ __global__ __launch_bounds__(NT * KSPL, KSPL == 2 ? 2 : RB == 2 ? 3 : 4) void co
     // group outside, all KH*KW taps of a 64-byte segment follow each other and the footprint between reuses is a quarter.
     const int ntaps = a.KH * a.KW;
     const unsigned aoff0 = MODE != MODE_TRANSPOSED ? 0u : (unsigned)(((a.KH - 1) * (int)a.sH + (a.KW - 1) * (int)a.sW) * 4);
-    int s_q = 0, s_tap = 0, s_kw = 0, s_kh = 0, s_c = kset * CK;     // wave set k: channel groups k, k + KSPL, ...
-    unsigned s_aoff = aoff0 + (unsigned)s_c * 4u;
+    int s_q = 0, s_tap = 0, s_kw = 0, s_kh = 0, s_c = 0;
+    unsigned s_aoff = aoff0;
     int s_qb = 0, sb_tap = 0;
-    unsigned sb_c4 = (unsigned)(kset * CK * 4), s_boff = sb_c4;
+    unsigned s_boff = 0, sb_c4 = 0;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t*)smem_all;
     const unsigned m0_a = lds0 + 2048u * RB * (unsigned)wave, m0_b = lds0 + BS_BASE + 1024u * (unsigned)wave;
 
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(NT * KSPL, KSPL == 2 ? 2 : RB == 2 ? 3 : 4) void co
         ++s_q;
         ++s_tap; s_aoff += (unsigned)dW4;
         if (++s_kw == a.KW) { s_kw = 0; ++s_kh; s_aoff += (unsigned)(dH4 - a.KW * dW4); }
-        if (s_tap == ntaps) { s_tap = 0; s_kh = 0; s_c += KSPL * CK; s_aoff = aoff0 + (unsigned)s_c * 4u; }
+        if (s_tap == ntaps) { s_tap = 0; s_kh = 0; s_c += CK; s_aoff = aoff0 + (unsigned)s_c * 4u; }
         if (s_q >= nchunks) { s_tap = 31; s_aoff = 0; }          // run-out: every mask drops tap 31
     };
     // (in a partly empty channel group the staged weight columns beyond C are the next tap's -- finite values that meet
@@ -978,7 +979,7 @@ __global__ __launch_bounds__(NT * KSPL, KSPL == 2 ? 2 : RB == 2 ? 3 : 4) void co
         dma16s(rw_, m0_b + DST * BS_BYTES, vb, s_qb < nchunks ? s_boff : 0u);
         ++s_qb;
         s_boff += (unsigned)a.C * 4u;                             // next tap of the same channel group
-        if (++sb_tap == ntaps) { sb_tap = 0; sb_c4 += KSPL * CK * 4; s_boff = sb_c4; }
+        if (++sb_tap == ntaps) { sb_tap = 0; sb_c4 += CK * 4; s_boff = sb_c4; }
     };
 
     // ---- fragment addresses (bytes from the start of LDS)
@@ -1136,32 +1137,10 @@ __global__ __launch_bounds__(NT * KSPL, KSPL == 2 ? 2 : RB == 2 ? 3 : 4) void co
         if (q + 1 < nchunks) chunk(std::integral_constant<unsigned, 1>{});
     }
 
-    if constexpr (KSPL == 2) {              // wave set 1 -> LDS (its ring is dead) -> wave set 0: acc += partner's
-        float* ex = smem_both + LDS_BYTES / 4 + wave * (RB * 2 * 16 * 64) + lane;
-        if (kset == 1) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ex[((i * 2 + j) * 16 + r) * 64] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (kset == 0) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[((i * 2 + j) * 16 + r) * 64];
-        }
-        static_assert(KSPL == 1 || 4 * RB * 2 * 16 * 64 * 4 <= LDS_BYTES, "exchange area");
-    }
-
     // ---- epilogue (full tiles, no scale, activation none | ELU: the host routes nothing else here): per column block the
     // wave transposes its 64 x 32 block through LDS and leaves with full 128-byte lines; BatchNorm partial sums per
-    // 128-row half of the tile.  (KSPL = 2: wave set 0; set 1 only keeps the barrier company.)
-    if (kset == 0) {
+    // 128-row half of the tile
+    {
         constexpr int RW = 32 * RB;                                    // rows of the wave
         float* T = smem_all + wave * (RW * 32);                        // 4 | 8 KB per wave; the ring is dead
         float (*red)[BN][2] = reinterpret_cast<float (*)[BN][2]>(smem_all + 4 * RW * 32);
@@ -1213,19 +1192,17 @@ __global__ __launch_bounds__(NT * KSPL, KSPL == 2 ? 2 : RB == 2 ? 3 : 4) void co
                 if (lane < 32) { red[wave][32 * j + col_l][0] = s1; red[wave][32 * j + col_l][1] = s2; }
             }
         }
-    }
-    if (a.stats) {
-        // one row of `stats` per a.stats_rows output pixels (128, or 64 when M < 65536: pd_conv2d_tile_m): WPS waves each
-        constexpr int RW = 32 * RB;
-        float (*red)[BN][2] = reinterpret_cast<float (*)[BN][2]>(smem_both + 4 * RW * 32);
-        const int sgr = a.stats_rows, wps = sgr / RW, nrow = BM / sgr;
-        __syncthreads();
-        if (kset == 0 && tid < nrow * BN) {
-            const int row_l = tid >> 6, cl = tid & 63;
-            float t1 = 0.f, t2 = 0.f;
-            for (int w = 0; w < wps; ++w) { t1 += red[row_l * wps + w][cl][0]; t2 += red[row_l * wps + w][cl][1]; }
-            float* o = a.stats + ((long)(mt * nrow + row_l) * a.Co + n0 + cl) * 2;
-            o[0] = t1; o[1] = t2;
+        if (a.stats) {
+            // one row of `stats` per a.stats_rows output pixels (128, or 64 when M < 65536: pd_conv2d_tile_m): WPS waves each
+            const int sgr = a.stats_rows, wps = sgr / RW, nrow = BM / sgr;
+            __syncthreads();
+            if (tid < nrow * BN) {
+                const int row_l = tid >> 6, cl = tid & 63;
+                float t1 = 0.f, t2 = 0.f;
+                for (int w = 0; w < wps; ++w) { t1 += red[row_l * wps + w][cl][0]; t2 += red[row_l * wps + w][cl][1]; }
+                float* o = a.stats + ((long)(mt * nrow + row_l) * a.Co + n0 + cl) * 2;
+                o[0] = t1; o[1] = t2;
+            }
         }
     }
 }
@@ -1259,26 +1236,24 @@ static int x3_eligible(const ConvArgs& a, bool vec) {
     return (force || (a.M / 128) * ct >= X3_MIN_WG1) ? 1 : 0;
 }
 
+// Tile order of the bf16-split kernels.  Default: row tiles outside -- the workgroups that share an XCD's 4 MB L2 work on
+// neighbouring pixels and all column tiles (a 64-channel filter is 150 KB).  A filter of several megabytes (3x3x512x512: 9.4 MB,
+// 5x5x256x512: 13 MB) would then be streamed through every L2 by every row tile -- 1.1 GB per launch from the Infinity Cache
+// for 3x3x512 @16x20, which bounds it (twice the waves per CU changed nothing) -- so with >= 8 column tiles the COLUMN tile goes
+// outside: an XCD keeps its slice of the filter and streams the (smaller) activations once.
+static int x3_nmajor(const ConvArgs& a) { return (long)a.Co * a.K * 4 > (3L << 20) && a.ntiles >= 8 && a.ntiles % 8 == 0; }
 #include "conv_x3_halo.hpp"
 
-// 128-row tiles with two wave sets per workgroup (conv_igemm_x3_kernel<MODE, 1, 2>): fewer than 512 tiles, at least 16 whole
-// channel groups in an even number
-static bool x3_ksplit(const ConvArgs& a, long nblk) { return nblk < 512 && a.C % (2 * x3::CK) == 0 && a.C >= 16 * x3::CK; }
 static int launch_conv_x3(ConvArgs& a, int rb, hipStream_t st) {
     a.mtiles = (int)(a.M / (128 * rb));
     a.ntiles = a.Co / x3::BN;
+    a.nmajor = x3_nmajor(a);
     const long nblk = (long)a.mtiles * a.ntiles;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
     if (rb == 2) {
         if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_ZERO, 2>), grid, block, 0, st, a);
         else if (a.mode == MODE_REFLECT) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_REFLECT, 2>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_TRANSPOSED, 2>), grid, block, 0, st, a);
-    } else if (x3_ksplit(a, nblk)) {
-        // few tiles, long contraction (3x3x512 @16x20: 320 tiles, K = 4608): two wave sets per workgroup share the channel groups
-        const dim3 block2(2 * NT);
-        if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_ZERO, 1, 2>), grid, block2, 0, st, a);
-        else if (a.mode == MODE_REFLECT) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_REFLECT, 1, 2>), grid, block2, 0, st, a);
-        else hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_TRANSPOSED, 1, 2>), grid, block2, 0, st, a);
     } else {
         if (a.mode == MODE_ZERO) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_ZERO, 1>), grid, block, 0, st, a);
         else if (a.mode == MODE_REFLECT) hipLaunchKernelGGL((conv_igemm_x3_kernel<MODE_REFLECT, 1>), grid, block, 0, st, a);

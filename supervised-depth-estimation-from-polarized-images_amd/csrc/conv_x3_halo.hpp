@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NT, 3) void conv_halo_x3_kernel(const ConvArgs a) {
     const int per_xcd = (int)gridDim.x >> 3;
     const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (logical >= nblk) return;
-    const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
+    const int mt = a.nmajor ? logical % ntile_m : logical / a.ntiles, nt = a.nmajor ? logical / ntile_m : logical - mt * a.ntiles;
     const int n0 = nt * BNW;
     const int img = mt / (tiles_h * tiles_w);
     const int trem = mt - img * (tiles_h * tiles_w);
@@ -450,6 +450,7 @@ static int launch_conv_x3_halo(ConvArgs& a, hipStream_t st) {
     const int tw = p.tw;
     a.mtiles = a.N * (a.Ho / (256 / tw)) * (a.Wo / tw);
     a.ntiles = a.Co / (32 * p.ncb);
+    a.nmajor = x3_nmajor(a);
     const long nblk = (long)a.mtiles * a.ntiles;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(NT);
     // Occupancy history (round 4, same box): a three-chunk LDS-DMA weight ring at two workgroups per CU -> a two-chunk ring at
