@@ -192,8 +192,12 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_graph", action="store_true",
-                    help="time the eager step only (default on one GPU: the step is also captured into a hipGraph and "
-                         "`value` is the faster of the two; both are reported)")
+                    help="time the eager step only (default on one GPU: the step is also captured into a hipGraph and reported "
+                         "beside the eager loop; `value` is always the eager loop)")
+    ap.add_argument("--dp_graph", action="store_true",
+                    help="with --gpus N > 1: also time the captured step under the gradient reducer (polardepth/graph.py, "
+                         "segmented mode).  Off by default at N > 1: the scaling run's line must not depend on a capture "
+                         "beside a live process group, which only world-1 tests have exercised on this pool")
     ap.add_argument("--attention", action="store_true",
                     help="BASELINE configs[4] variant (single-head attention at the joint-encoder merge, fp32); "
                          "not the headline workload")
@@ -281,7 +285,10 @@ def main():
             fp32_only = {"images_per_s": round(args.batch * n_ref / dt_ref, 3), "ms_per_step": round(dt_ref / n_ref * 1e3, 3),
                          "steps": n_ref, "launch": "eager"}
     graph_info = None
-    if not args.no_graph:           # (data-parallel: graph of zero_grad..backward + bucketed all-reduce + eager Adam, polardepth/graph.py)
+    if world > 1 and not args.dp_graph and not args.no_graph:
+        graph_info = {"skipped": "N > 1: pass --dp_graph to time the captured step under the gradient reducer "
+                                 "(tests/test_dp_gpu.py covers it bit for bit on a world-1 RCCL group)"}
+    elif not args.no_graph:         # (data-parallel: graph of zero_grad..backward + bucketed all-reduce + eager Adam, polardepth/graph.py)
         # the same step replayed from a hipGraph (polardepth/graph.py).  A second trainer with the same seed, so that both
         # loops run the same number of steps from the same initial weights: final_loss must agree bit for bit.
         try:
