@@ -163,9 +163,11 @@ int pd_polar_theta(const void* rho, void* theta_d, void* theta_s1, void* theta_s
 #define PD_CONV_FLAGS_ALL 63u
 int pd_conv2d_tile_m(long M, int Cout);
 long pd_conv2d_stats_rows(long M, int Cout);
-/* Non-zero (3: the halo-tile kernel conv_halo_x3_kernel -- 3x3 / 5x5, stride 1, zero padding or the stride-1 data gradient,
- * C % 16 == 0, Ho % 8 == 0, Wo % 32 == 0, given the output grid Ho x Wo (0 x 0: unknown, never 3) --; 2 | 1: the per-tap
- * gather kernel with 256- | 128-row tiles) when pd_conv2d / pd_conv2d_add send this shape (16-byte aligned NHWC operands assumed) to the kernel that forms the fp32
+/* Non-zero (3: the halo-tile kernel conv_halo_x3_kernel -- stride 1, the output grid Ho x Wo (0 x 0: unknown, never 3) a whole
+ * number of 8 x 32, 16 x 16 or 32 x 8 tiles, at least 512 workgroups; 3x3 / 5x5 with zero padding, the stride-1 data gradient or
+ * reflection padding, C % 16 == 0, Cout % 32 == 0 (64-column workgroups, or 32-column ones where those would be fewer than 512
+ * or Cout % 64 == 32), or the 4x4 zero-padded space-to-depth stems (contiguous pixels, 4 C % 16 == 0, Cout % 64 == 0) in their
+ * row-window form --; 2 | 1: the per-tap gather kernel with 256- | 128-row tiles) when pd_conv2d / pd_conv2d_add send this shape (16-byte aligned NHWC operands assumed) to the kernel that forms the fp32
  * products on the bf16 matrix cores (conv_igemm_x3_kernel: x = hi + mid + lo in bf16, six MFMAs per 32x32x16 block, fp32
  * accumulation; PD_CONV_FP32_MFMA in `flags` keeps every layer on the fp32 MFMA): zero padding, the stride-1 data gradient or 3x3 reflection padding (a same-size layer is assumed), C % 4 == 0 and >= 8 (16-channel groups, the last may be partly empty),
  * Cout % 64 == 0, at least 512 tiles of 256 x 64 (M % 256 == 0) or 320 of 128 x 64 (M % 128 == 0), no out_scale, activation none or ELU.  The profiler label of a launch
@@ -230,8 +232,12 @@ int pd_conv2d_wgrad(const void* x, const void* dy, void* dw, void* dbias, void* 
                     int N, int H, int W, int C, long sN, long sH, long sW, long sC,
                     int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int mode,
                     int affine, float sub, float div, long ldd, int accumulate, unsigned flags, void* stream);
-/* 2 (conv_wgrad_halo_x3_kernel: 3x3 / 5x5, stride 1, zero padding, C % 64 == 0, Cout % 64 == 0, Ho % 2 == 0, Wo % 32 == 0: both
- * operands split once per 2 x 32-pixel tile and read through ds_read_b64_tr_b16) or
+/* 3 (conv_wgrad_roll_x3_kernel: 3x3, stride 1, same-size output, C % 64 == 0, Cout % 64 == 0, Wo % 16 == 0, tile columns long and
+ * many enough for >= 12 tile rows per slice on >= 384 workgroups: all three filter rows per workgroup, input rows rolling
+ * through LDS; PD_CONV_WGRAD_ROW_WORKGROUPS in `flags` declines it),
+ * 2 (conv_wgrad_halo_x3_kernel: 3x3 / 5x5, stride 1, zero or reflection padding, C % 64 == 0 and Cout % 64 == 0 -- or 3x3 with
+ * Cout % 32 == 0, C % 32 == 0 on 1 x 32 tiles --, the output grid a whole number of 1 x 32, 2 x 16, 4 x 8 or (3x3) 8 x 4 pixel tiles: both
+ * operands split once per tile and read through ds_read_b64_tr_b16) or
  * 1 when pd_conv2d_wgrad sends this shape (zero or reflection padding; 16-byte aligned NHWC operands assumed) to the kernel that forms the
  * fp32 products on the bf16 matrix cores, every element split once (conv_wgrad_x3c_kernel; PD_CONV_FP32_MFMA: fp32 MFMA) --
  * the profiler label of a launch and bench.py's roofline object use it. */
