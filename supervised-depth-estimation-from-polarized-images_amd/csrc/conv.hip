@@ -1146,8 +1146,11 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
         float (*red)[BN][2] = reinterpret_cast<float (*)[BN][2]>(smem_all + 4 * RW * 32);
         const int col_l = lane & 31, rbase = 4 * (lane >> 5);
         const bool elu = a.act == ACT_ELU;
-        const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)((long)BM * a.ldy * 4));
-        const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.add ? a.add + m0 * a.ld_add : a.y, a.add ? (unsigned)((long)BM * a.ld_add * 4) : 0u);
+        // (a last, partial tile -- data gradients on grids that are no multiple of 128 pixels: the descriptors end at row M, the
+        //  hardware drops the stores beyond)
+        const long rows_here = a.M - m0 < BM ? a.M - m0 : BM;
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + m0 * a.ldy, (unsigned)(rows_here * a.ldy * 4));
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(a.add ? a.add + m0 * a.ld_add : a.y, a.add ? (unsigned)(rows_here * a.ld_add * 4) : 0u);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float4 addv[4 * RB];
@@ -1182,9 +1185,16 @@ __global__ __launch_bounds__(NT, RB == 2 ? 3 : 4) void conv_igemm_x3_kernel(cons
                 if (a.add) { v[t].x += addv[t].x; v[t].y += addv[t].y; v[t].z += addv[t].z; v[t].w += addv[t].w; }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (rows_here == BM) {
 #pragma unroll
-            for (int t = 0; t < 4 * RB; ++t)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[t]), ry, off_l, t * 8 * (int)a.ldy * 4, 0);
+                for (int t = 0; t < 4 * RB; ++t)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[t]), ry, off_l, t * 8 * (int)a.ldy * 4, 0);
+            } else {                            // partial tile: a row test per lane (the scalar offset is outside the range check)
+#pragma unroll
+                for (int t = 0; t < 4 * RB; ++t)
+                    if (RW * wave + (lane >> 3) + 8 * t < rows_here)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[t]), ry, off_l + (unsigned)(t * 8 * (int)a.ldy * 4), 0, 0);
+            }
             asm volatile("s_nop 1");
             __builtin_amdgcn_sched_barrier(0);
             if (a.stats) {
@@ -1227,7 +1237,9 @@ static bool x3_common_ok(const ConvArgs& a, bool vec) {
 static int x3_eligible(const ConvArgs& a, bool vec) {
     const bool force = (a.flags & PD_CONV_BF16X3) != 0;
     // (C % 4 == 0 is part of `vec`; a partly empty last channel group may at most double the contraction: C >= 8)
-    if (!(x3_common_ok(a, vec) && (a.C + x3::CK - 1) / x3::CK * x3::CK <= 2 * a.C && a.Co % x3::BN == 0 && a.M % 128 == 0))
+    // (whole 128-row tiles, except for a data gradient without BatchNorm statistics: its last tile may be partial)
+    if (!(x3_common_ok(a, vec) && (a.C + x3::CK - 1) / x3::CK * x3::CK <= 2 * a.C && a.Co % x3::BN == 0 &&
+          (a.M % 128 == 0 || (a.mode == MODE_TRANSPOSED && !a.stats))))
         return 0;
     const long ct = a.Co / x3::BN;
     if (a.M % 256 == 0 && (a.M / 256) * ct >= X3_MIN_WG) return 2;
@@ -1245,7 +1257,7 @@ static int x3_nmajor(const ConvArgs& a) { return (long)a.Co * a.K * 4 > (3L << 2
 #include "conv_x3_halo.hpp"
 
 static int launch_conv_x3(ConvArgs& a, int rb, hipStream_t st) {
-    a.mtiles = (int)(a.M / (128 * rb));
+    a.mtiles = (int)((a.M + 128 * rb - 1) / (128 * rb));
     a.ntiles = a.Co / x3::BN;
     a.nmajor = x3_nmajor(a);
     const long nblk = (long)a.mtiles * a.ntiles;

@@ -591,6 +591,33 @@ def test_rolling_row_weight_gradient(case, monkeypatch):
     assert err["roll"] <= 2e-5 and err["roll"] <= 1.5 * err["fp32"] + 2e-7 and err["rows"] <= 1.5 * err["fp32"] + 2e-7, err
 
 
+def test_padded_grid_data_gradient_with_a_partial_last_tile(monkeypatch):
+    """The decoder's deep levels take the data gradient of ReflectionPad2d(1) + Conv3x3 on the PADDED grid (34 x 42 for a 32 x 40
+    plane): M = 16 * 34 * 42 = 22848 = 178 tiles of 128 rows + 64 rows.  The bf16-split gather kernel takes it with a partial
+    last tile (row-tested stores); vs an fp64 transposed convolution, next to the fp32-MFMA kernel; the rows behind the
+    tensor's end stay untouched."""
+    N, Cz, Ci, H, W = 16, 128, 256, 32, 40
+    g = torch.Generator().manual_seed(5)
+    dz = torch.randn(N, Cz, H, W, generator=g)
+    w = torch.randn(Cz, Ci, 3, 3, generator=g) / (Cz * 9) ** 0.5
+    ref = F.conv_transpose2d(dz.double(), w.double())                     # [N, Ci, H + 2, W + 2]
+    dzd = dz.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    err = {}
+    for name, fl in (("x3", ops.CONV_AUTO), ("fp32", ops.CONV_FP32_MFMA)):
+        monkeypatch.setattr(ops, "CONV_FLAGS", fl)
+        ops.PROFILE = []
+        try:
+            dx = ops.conv2d_dgrad(dzd, wd, (H + 2, W + 2), 1, 0)
+            lab = [p[0] for p in ops.PROFILE]
+        finally:
+            ops.PROFILE = None
+        assert lab[0].startswith("conv_igemm_x3_kernel<128,64>" if name == "x3" else "conv_igemm_uni_kernel"), lab
+        assert dx.shape == ref.shape
+        err[name] = (dx.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err["x3"] <= 5e-6 and err["x3"] <= 1.5 * err["fp32"] + 1e-8, err
+
+
 # ------------------------------------------------------------------ the bf16-split kernels on inputs that are not `randn`
 def _field(mask_shape, n, h, w, k):
     """Boolean [N,1,H,W] mask of the output pixels whose k x k window (pad k//2, stride 1) contains input pixel (n, h, w)."""
