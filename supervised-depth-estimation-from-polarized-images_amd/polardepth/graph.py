@@ -14,8 +14,12 @@ Data-parallel runs (one process per GPU, engine.GradReducer): two ways to combin
     (the same per-bucket calls as the overlapped eager path, hence the same bits) and the Adam kernel is launched eagerly:
     one replay + ~8 collectives + 2 launches per step on the host instead of ~520.  What it gives up is the overlap of the
     exchange with backward (85 MB over xGMI: ~1 ms of a 53 ms step);
-  * "capture" (PD_GRAPH_COMM=capture): the all-reduces are captured with everything else (torch's ProcessGroupNCCL records
-    them as graph nodes), overlap included.  Verified on one GPU with a world-1 RCCL group only.
+  * "capture" (PD_GRAPH_COMM=capture + PD_GRAPH_COMM_CAPTURE_UNSAFE=1): the all-reduces are captured with everything else
+    (torch's ProcessGroupNCCL records them as graph nodes), overlap included.  NOT usable on this PyTorch / ROCm build: the
+    Work object of a collective issued during capture still enters the process group's watchdog list, and when the watchdog
+    thread polls its end event -- recorded in the capturing stream -- HIP answers hipErrorCapturedEvent, the thread throws and
+    the rank aborts (seen as an intermittent SIGABRT of the world-1 test, round 4).  The mode is refused unless the second
+    variable says otherwise; bit-equality with eager DP steps was verified on the runs the watchdog did not hit.
 Reference hot loop this replaces: manydepth/trainer.py:430-442 (run_epoch body).
 """
 import os
@@ -41,6 +45,11 @@ class GraphedTrainStep:
         self.comm = (comm or os.environ.get("PD_GRAPH_COMM") or "segmented") if self.dp else None
         if self.comm not in (None, "segmented", "capture"):
             raise ValueError(f"GraphedTrainStep: comm must be 'segmented' or 'capture', got {self.comm!r}")
+        if self.comm == "capture" and os.environ.get("PD_GRAPH_COMM_CAPTURE_UNSAFE") != "1":
+            raise NotImplementedError(
+                "GraphedTrainStep(comm='capture'): collectives captured into the graph leave Work objects whose events the process "
+                "group's watchdog thread polls (hipErrorCapturedEvent -> the rank aborts) on this PyTorch/ROCm build; use "
+                "comm='segmented' (default), or set PD_GRAPH_COMM_CAPTURE_UNSAFE=1 to try it anyway")
         self.segmented = self.comm == "segmented"
         if self.segmented and getattr(getattr(tr, "loss_cfg", None), "global_norm", False):
             raise NotImplementedError("GraphedTrainStep (segmented): the global loss normalisation all-reduces in the middle of "

@@ -81,7 +81,8 @@ def test_production_tile_conv_forward_dgrad_wgrad(case, x3, monkeypatch):
         rb = ops.lib.pd_conv2d_uses_x3(Mx, Cox, Cx, k, k, sx, p, mode, 0, 0, ho, wo, fl)
         want = 0
         if x3 == "1" and Cox % 64 == 0 and Cx % 4 == 0 and -(-Cx // 16) * 16 <= 2 * Cx:
-            want = 2 if (Mx % 256 == 0 and (Mx // 256) * (Cox // 64) >= 512) else 1 if (Mx % 128 == 0 and (Mx // 128) * (Cox // 64) >= 320) else 0
+            # (a data gradient -- mode 2, no BatchNorm statistics -- may end in a partial 128-row tile)
+            want = 2 if (Mx % 256 == 0 and (Mx // 256) * (Cox // 64) >= 512) else 1 if ((Mx % 128 == 0 or mode == 2) and (Mx // 128) * (Cox // 64) >= 320) else 0
             tw = 32 if (wo % 32 == 0 and ho % 8 == 0) else 16 if (wo % 16 == 0 and ho % 16 == 0) else 8 if (wo % 8 == 0 and ho % 32 == 0) else 0
             # the halo-tile kernel: 64-column workgroups where they are >= 512, else 32-column ones (3x3 off the 32 x 8 tiles; 5x5 on them)
             if k in (3, 5) and sx == 1 and Cx % 16 == 0 and tw and Mx >= 65536:
