@@ -66,7 +66,8 @@ def test_graphed_step_with_the_reducer_is_bit_equal_to_eager_dp_steps(tmp_path, 
     assert eager["reducer_active"] and graph["reducer_active"] and graph["adam_steps"] == eager["adam_steps"] == 5
     assert torch.equal(eager["losses"], graph["losses"]), (eager["losses"], graph["losses"])
     assert torch.equal(eager["flat"], graph["flat"])
-    assert graph["graph_host_ms"] < 3.0, graph["graph_host_ms"]
+    # one replay + 8 collectives + 2 launches: 2-3 ms of host time on this pool's hosts (the eager step enqueues 13-35 ms)
+    assert graph["graph_host_ms"] < 8.0, graph["graph_host_ms"]
 
 
 def test_capture_mode_is_refused(tmp_path):
