@@ -70,7 +70,7 @@ def test_graphed_step_is_bit_identical_to_the_eager_step(tmp_path):
     gs.step()
     host = time.perf_counter() - t0
     torch.cuda.synchronize()
-    assert host < 2e-3, f"replay took {host * 1e3:.2f} ms of host time"
+    assert host < 5e-3, f"replay took {host * 1e3:.2f} ms of host time"       # (0.3-1 ms here; headroom for a slow host)
 
 
 def test_run_epoch_with_the_graphed_step_matches_the_eager_epoch(tmp_path, monkeypatch):
