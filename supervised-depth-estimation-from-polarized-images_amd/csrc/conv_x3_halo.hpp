@@ -132,12 +132,14 @@ __global__ __launch_bounds__(NT, 3) void conv_halo_x3_kernel(const ConvArgs a) {
     int s_qb = 0, sb_tap = 0;
     unsigned s_boff = 0, sb_c4 = 0;
     float4 wq;                                                    // this thread's 16 bytes of the chunk in flight
-    auto load_b = [&]() {                                         // chunk s_qb (past the end: chunk 0 again, never used)
+    // NCB = 1: a chunk is 12 MFMAs per wave -- half a chunk is less than an L2 round trip when two or three waves share a SIMD --
+    // so the 8-byte requests run TWO chunks ahead, in two register sets by the parity of the chunk they are for
+    float2 wq2[2];
+    auto load_b = [&](auto set_tag) {                             // chunk s_qb (past the end: chunk 0 again, never used)
         if constexpr (NCB == 2) {
             wq = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_, vb, s_qb < nchunks ? s_boff : 0u, 0));
         } else {
-            const float2 w2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rw_, vb, s_qb < nchunks ? s_boff : 0u, 0));
-            wq.x = w2.x; wq.y = w2.y;
+            wq2[decltype(set_tag)::value] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rw_, vb, s_qb < nchunks ? s_boff : 0u, 0));
         }
         ++s_qb;
         s_boff += tap_bytes;                                      // next tap of the same channel group
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(NT, 3) void conv_halo_x3_kernel(const ConvArgs a) {
     };
 
     auto split_b0 = [&]() {                     // chunk 0 -> planes 0 (prologue only; the loop threads it)
-        const float4 w4 = wq;
+        const float4 w4 = NCB == 2 ? wq : make_float4(wq2[0].x, wq2[0].y, 0.f, 0.f);
         uint2 h, m, l;
         x3::split2(w4.x, w4.y, h.x, m.x, l.x);
         if constexpr (NCB == 2) {
@@ -235,8 +237,14 @@ __global__ __launch_bounds__(NT, 3) void conv_halo_x3_kernel(const ConvArgs a) {
         // next chunk's weights (fp32), requested during the previous chunk: the ONLY vmcnt wait of the loop is taken here, in
         // front of the halo requests (vmcnt counts in order: behind them it would wait for the halo as well; and a branch in
         // the middle of the chunk lets LLVM sink the whole split below it)
-        asm volatile("" : "+v"(wq.x), "+v"(wq.y), "+v"(wq.z), "+v"(wq.w));
-        const float ws[4] = {wq.x, wq.y, wq.z, wq.w};
+        float ws[4];
+        if constexpr (NCB == 2) {
+            asm volatile("" : "+v"(wq.x), "+v"(wq.y), "+v"(wq.z), "+v"(wq.w));
+            ws[0] = wq.x; ws[1] = wq.y; ws[2] = wq.z; ws[3] = wq.w;
+        } else {
+            asm volatile("" : "+v"(wq2[NXT].x), "+v"(wq2[NXT].y));
+            ws[0] = wq2[NXT].x; ws[1] = wq2[NXT].y; ws[2] = 0.f; ws[3] = 0.f;
+        }
         if (halo_issue) halo_load(s_g + 1);
         const int ey = MODE == MODE_TRANSPOSED ? KH - 1 - s_kh : s_kh, ex = MODE == MODE_TRANSPOSED ? KW - 1 - s_kw : s_kw;
         const unsigned fa = fa_base + (unsigned)((ey * HW + ex) * 16);
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(NT, 3) void conv_halo_x3_kernel(const ConvArgs a) {
         mm(PD_I(0), PD_I(3)); PD_SB
         mm(PD_I(1), PD_I(2)); x3::sp_l<0, true>(tw); PD_SB
         mm(PD_I(1), PD_I(3)); x3::sp_l<1, true>(tw); PD_SB
-        load_b();                                   // chunk q + 2's weights: their registers are free, two thirds of a chunk (x 3 waves per SIMD) to land
+        load_b(std::integral_constant<int, 0>{});   // chunk q + 2's weights: their registers are free, two thirds of a chunk (x 3 waves per SIMD) to land
         mm(PD_I(0), PD_I(4)); PD_SB
         mm(PD_I(0), PD_I(5));
         *reinterpret_cast<uint2*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = uint2{tw.h[0] ^ wsign, tw.h[1] ^ wsign};
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(NT, 3) void conv_halo_x3_kernel(const ConvArgs a) {
         mm(PD_I(1), PD_I(1)); PD_SB
         mm(PD_I(0), PD_I(2)); x3::sp_l<0, true>(tw); PD_SB
         mm(PD_I(1), PD_I(2)); PD_SB
-        load_b();
+        load_b(std::integral_constant<int, (int)NXT>{});          // chunk q + 3 into the set chunk q + 1's weights have just left
         mm(PD_I(0), PD_I(3));
         *reinterpret_cast<unsigned*>(lds_c + sp_off + (NXT * 3 + 0) * BP_BYTES) = tw.h[0] ^ wsign;
         *reinterpret_cast<unsigned*>(lds_c + sp_off + (NXT * 3 + 1) * BP_BYTES) = tw.m[0] ^ wsign;
@@ -315,10 +323,11 @@ __global__ __launch_bounds__(NT, 3) void conv_halo_x3_kernel(const ConvArgs a) {
     // ---- prologue: halo of group 0, weights of chunks 0 and 1 (register sets 0, 1); planes of the halo and of chunk 0
     {
         halo_load(0);
-        load_b();
+        load_b(std::integral_constant<int, 0>{});
         halo_split();
         split_b0();
-        load_b();
+        load_b(std::integral_constant<int, 1>{});                 // chunk 1 (NCB = 2: the one set)
+        if constexpr (NCB == 1) load_b(std::integral_constant<int, 0>{});       // ... and chunk 2
         __syncthreads();
     }
     for (int q = 0; q < nchunks; q += 2) {
