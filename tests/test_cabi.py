@@ -289,3 +289,33 @@ def test_toolchain_is_the_pinned_one():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     assert "AMD clang version" in g.toolchain_check()
+
+
+def test_routing_queries_over_a_shape_sweep():
+    """pd_conv2d_uses_x3 / pd_conv2d_wgrad_uses_x3 / pd_conv2d_wgrad_workspace are pure host functions of the shape: over a sweep
+    of layer shapes (the network's and perturbations: odd planes, channel counts off the kernels' grids, both filter sizes,
+    every flags word) they return one of their documented codes, the workspace always covers at least one partial tile, and
+    the rolling-row / halo weight-gradient kernels are only ever chosen together with a workspace that holds their slices."""
+    import itertools
+    lib = _lib.lib
+    planes = [(256, 320), (128, 160), (64, 80), (32, 40), (16, 20), (34, 42), (150, 150), (8, 12), (512, 640)]
+    chans = [(64, 64), (128, 128), (256, 512), (512, 512), (96, 32), (32, 96), (64, 32), (36, 64), (12, 64), (8, 64), (16, 16), (48, 64), (100, 64)]
+    for (H, W), (C, Co), k, N, mode, fl in itertools.product(planes, chans, (1, 3, 4, 5), (1, 16), (0, 1, 2), (0, 1, 2, 4, 8, 16, 32)):
+        if mode == 1 and k != 3:
+            continue
+        M = N * H * W
+        pad = k // 2
+        a = lib.pd_conv2d_uses_x3(M, Co, C, k, k, 1, pad, mode, 0, 0, H, W, fl)
+        assert a in (0, 1, 2, 3), (H, W, C, Co, k, N, mode, fl, a)
+        if fl & 1:
+            assert a == 0
+        if mode != 2:
+            b = lib.pd_conv2d_wgrad_uses_x3(M, Co, C, k, k, 1, pad, mode, H, W, H, W, fl)
+            ws = lib.pd_conv2d_wgrad_workspace(M, Co, k * k * C, fl)
+            per = 4 * (Co * k * k * C + Co)
+            assert b in (0, 1, 2, 3) and ws >= per, (H, W, C, Co, k, N, mode, fl, b, ws)
+            if fl & 1:
+                assert b == 0
+            if b == 3:      # rolling rows: 3x3, whole 64-channel blocks, at least 384 workgroups' worth of slices in the workspace
+                assert k == 3 and C % 64 == 0 and Co % 64 == 0 and not (fl & 32)
+                assert (ws // per) * (C // 64) * (Co // 64) >= 384
